@@ -1,0 +1,101 @@
+"""ctypes binding of include/dsim.h (the C-ABI shared library `csrc/libdsim_hip.so`).
+
+This is the ONLY compute path of the package: there is no CPU / eager fallback.  If the HIP
+library is missing or fails to load, `lib()` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdsim_hip.so")
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+
+
+class ModelDesc(C.Structure):
+    """Mirror of `dsim_model_desc` (include/dsim.h)."""
+    _fields_ = [
+        ("n_links", C.c_int32), ("n_q", C.c_int32), ("n_qd", C.c_int32), ("n_contacts", C.c_int32),
+        ("n_muscles", C.c_int32), ("n_waypoints", C.c_int32),
+        ("joint_type", _i32p), ("joint_parent", _i32p), ("joint_q_start", _i32p), ("joint_qd_start", _i32p),
+        ("joint_X_pj", _f32p), ("joint_X_cm", _f32p), ("joint_axis", _f32p), ("body_I_m", _f32p),
+        ("joint_armature", _f32p), ("joint_target", _f32p), ("joint_target_ke", _f32p), ("joint_target_kd", _f32p),
+        ("joint_limit_lower", _f32p), ("joint_limit_upper", _f32p), ("joint_limit_ke", _f32p),
+        ("joint_limit_kd", _f32p),
+        ("contact_body", _i32p), ("contact_point", _f32p), ("contact_dist", _f32p), ("contact_material", _f32p),
+        ("muscle_start", _i32p), ("muscle_links", _i32p), ("muscle_points", _f32p),
+        ("gravity", C.c_float * 3),
+    ]
+
+
+def make_desc(t):
+    """ArticulationTemplate -> (ModelDesc, keepalive list).  Arrays are borrowed: keep `t` alive."""
+    d = ModelDesc()
+    d.n_links, d.n_q, d.n_qd = t.n_links, t.n_q, t.n_qd
+    d.n_contacts, d.n_muscles, d.n_waypoints = t.n_contacts, t.n_muscles, t.n_waypoints
+    keep = []
+
+    def fp(a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        keep.append(a)
+        return a.ctypes.data_as(_f32p)
+
+    def ip(a):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        keep.append(a)
+        return a.ctypes.data_as(_i32p)
+
+    for name in ("joint_type", "joint_parent", "joint_q_start", "joint_qd_start", "contact_body", "muscle_start",
+                 "muscle_links"):
+        setattr(d, name, ip(getattr(t, name)))
+    for name in ("joint_X_pj", "joint_X_cm", "joint_axis", "body_I_m", "joint_armature", "joint_target",
+                 "joint_target_ke", "joint_target_kd", "joint_limit_lower", "joint_limit_upper", "joint_limit_ke",
+                 "joint_limit_kd", "contact_point", "contact_dist", "contact_material", "muscle_points"):
+        setattr(d, name, fp(getattr(t, name)))
+    for k in range(3):
+        d.gravity[k] = float(t.gravity[k])
+    return d, keep
+
+
+class DsimError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads libdsim_hip.so; raises if it is absent (no fallback by design)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DsimError("HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.dsim_last_error.restype = C.c_char_p
+    L.dsim_version.restype = C.c_int
+    L.dsim_model_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp)]
+    L.dsim_model_destroy.argtypes = [vp]
+    L.dsim_ckpt_floats.argtypes = [vp, C.c_int]
+    L.dsim_ckpt_floats.restype = C.c_int64
+    L.dsim_step_forward.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.dsim_step_backward.argtypes = [vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp,
+                                     vp]
+    for fn in (L.dsim_model_create, L.dsim_model_destroy, L.dsim_step_forward, L.dsim_step_backward):
+        fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise DsimError("dsim error %d: %s" % (rc, lib().dsim_last_error().decode()))
+
+
+EXPORTS = ("dsim_last_error", "dsim_version", "dsim_model_create", "dsim_model_destroy", "dsim_ckpt_floats",
+           "dsim_step_forward", "dsim_step_backward")

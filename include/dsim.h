@@ -1,0 +1,125 @@
+/* dsim.h -- C ABI of the MI355X-native differentiable articulated rigid-body step.
+ *
+ * This is the drop-in boundary for the hot path of NVlabs/DiffRL's dflex:
+ *
+ *   dsim_step_forward   replaces  SimulateFunc.forward  (dflex/dflex/sim.py:2097-2123), i.e. the
+ *                       `substeps` calls of SemiImplicitIntegrator._simulate (sim.py:2225-2601)
+ *                       that one SemiImplicitIntegrator.forward (sim.py:2182-2221) performs:
+ *                       eval_rigid_fk, eval_rigid_id, eval_rigid_contacts_art, eval_muscles,
+ *                       eval_rigid_tau, eval_rigid_jacobian, eval_rigid_mass,
+ *                       eval_dense_gemm_batched x2, eval_dense_cholesky_batched,
+ *                       eval_dense_solve_batched, eval_rigid_integrate
+ *   dsim_step_backward  replaces  SimulateFunc.backward (sim.py:2127-2154) + Tape.replay
+ *                       (dflex/dflex/adjoint.py:2153-2199): the reverse sweep over the same launches
+ *   dsim_model_create   replaces  the tensors ModelBuilder.finalize + Model.collide upload
+ *                       (dflex/dflex/model.py:1646-1879, 424-515) -- but ONE articulation template
+ *                       shared by all environments instead of N replicated copies
+ *
+ * Conventions (same as the reference FFI, dflex/dflex/adjoint.py:1250-1289, where noted):
+ *   - plain pointers + sizes; device pointers are borrowed for the duration of the call;
+ *   - all floating point is IEEE fp32, indices int32;
+ *   - state tensors are environment-major: q[N][n_q], qd[N][n_qd], act[N][n_qd],
+ *     muscle_act[N][n_muscles]  (== the reference's flat joint_q.view(N, -1));
+ *   - spatial_transform = (px,py,pz, qx,qy,qz,qw); spatial_vector = (wx,wy,wz, vx,vy,vz);
+ *     6x6 inertia row-major, rotational block upper-left (dflex/dflex/util.py:340-349);
+ *   - kernels are enqueued on the caller's HIP stream, no host synchronisation inside;
+ *   - gradients are WRITTEN (not accumulated) -- unlike the reference (adjoint.h:335-347) the
+ *     caller does not need to zero them;
+ *   - every function returns DSIM_OK or a negative error code; dsim_last_error() gives the text.
+ *     (The reference has no error returns: with_pytorch_error_handling=False, adjoint.py:1875.)
+ */
+#ifndef DSIM_H
+#define DSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSIM_OK 0
+#define DSIM_ERR_INVALID (-1)   /* bad argument / unsupported model */
+#define DSIM_ERR_HIP (-2)       /* HIP runtime error */
+#define DSIM_ERR_LIMIT (-3)     /* model exceeds a compiled-in limit */
+
+/* joint types, dflex/dflex/model.py:26-31 */
+#define DSIM_JOINT_PRISMATIC 0
+#define DSIM_JOINT_REVOLUTE 1
+#define DSIM_JOINT_BALL 2
+#define DSIM_JOINT_FIXED 3
+#define DSIM_JOINT_FREE 4
+
+/* One articulation ("environment") template. All pointers are HOST pointers and are copied. */
+typedef struct dsim_model_desc {
+    int32_t n_links;      /* L */
+    int32_t n_q;          /* generalized coordinates per articulation */
+    int32_t n_qd;         /* degrees of freedom per articulation */
+    int32_t n_contacts;   /* static ground-contact points (Model.collide) ; 0 if ground is off */
+    int32_t n_muscles;    /* M */
+    int32_t n_waypoints;  /* W = muscle_start[M] */
+    const int32_t* joint_type;      /* [L] */
+    const int32_t* joint_parent;    /* [L]  -1 = world; parents precede children */
+    const int32_t* joint_q_start;   /* [L+1] */
+    const int32_t* joint_qd_start;  /* [L+1] */
+    const float* joint_X_pj;        /* [L][7] joint frame in parent */
+    const float* joint_X_cm;        /* [L][7] body COM frame in child (rotation is identity) */
+    const float* joint_axis;        /* [L][3] */
+    const float* body_I_m;          /* [L][36] spatial inertia at the COM */
+    const float* joint_armature;    /* [n_qd] */
+    const float* joint_target;      /* [n_q] */
+    const float* joint_target_ke;   /* [L] */
+    const float* joint_target_kd;   /* [L] */
+    const float* joint_limit_lower; /* [n_q] */
+    const float* joint_limit_upper; /* [n_q] */
+    const float* joint_limit_ke;    /* [L] */
+    const float* joint_limit_kd;    /* [L] */
+    const int32_t* contact_body;    /* [C] */
+    const float* contact_point;     /* [C][3] */
+    const float* contact_dist;      /* [C] */
+    const float* contact_material;  /* [C][4] (ke, kd, kf, mu) already gathered per contact */
+    const int32_t* muscle_start;    /* [M+1] */
+    const int32_t* muscle_links;    /* [W] */
+    const float* muscle_points;     /* [W][3] */
+    float gravity[3];
+} dsim_model_desc;
+
+typedef struct dsim_model dsim_model; /* opaque, owns device copies of the template */
+
+const char* dsim_last_error(void);
+int dsim_version(void);
+
+/* Uploads the template to the current HIP device. */
+int dsim_model_create(const dsim_model_desc* desc, dsim_model** out);
+int dsim_model_destroy(dsim_model* m);
+
+/* Floats per environment of the per-substep checkpoint the forward pass leaves for the adjoint:
+ * substeps * (n_q + n_qd).  (The reference instead keeps all 14 State tensors of every substep
+ * alive on its Tape, sim.py:2111 / model.py:338-392.) */
+int64_t dsim_ckpt_floats(const dsim_model* m, int substeps);
+
+/* One env.step() worth of simulation for N environments: `substeps` semi-implicit substeps of
+ * dt/substeps with joint_act / muscle_act held fixed; mass matrix + Cholesky factor refreshed on
+ * substeps i with i % mm_freq == 0 (sim.py:2113).
+ *   ckpt: [N][substeps][n_q+n_qd] or NULL (no-grad fast path == dflex.config.no_grad, sim.py:2201)
+ *   muscle_act may be NULL when n_muscles == 0.  q_out/qd_out may alias q_in/qd_in. */
+int dsim_step_forward(const dsim_model* m, int n_envs,
+                      const float* q_in, const float* qd_in, const float* act, const float* muscle_act,
+                      float dt, int substeps, int mm_freq,
+                      float* q_out, float* qd_out, float* ckpt, void* hip_stream);
+
+/* Reverse sweep of the same step.  Needs the checkpoint of the forward call and the same act /
+ * muscle_act.  Outputs: gq_in[N][n_q], gqd_in[N][n_qd], gact[N][n_qd], gmuscle_act[N][M]
+ * (gact / gmuscle_act may be NULL to skip).  Follows the reference's adjoint conventions
+ * (SURVEY.md App. B): Cholesky treated as constant, dH = -(LL^T)^-1 g_qdd * qdd^T accumulated over
+ * the substeps that reuse a factor (matnn.h:310-336), min/max/clamp/step/normalize rules of
+ * adjoint.h:129-190 and vec3.h:204-222. */
+int dsim_step_backward(const dsim_model* m, int n_envs,
+                       const float* ckpt, const float* act, const float* muscle_act,
+                       float dt, int substeps, int mm_freq,
+                       const float* gq_out, const float* gqd_out,
+                       float* gq_in, float* gqd_in, float* gact, float* gmuscle_act, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSIM_H */

@@ -1,0 +1,81 @@
+"""ctypes driver of the CPU oracle (oracle/libdsim_oracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from diffrl_amd.capi import ModelDesc, make_desc
+from diffrl_amd.template import ArticulationTemplate
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+_lib = None
+
+
+def oracle():
+    global _lib
+    if _lib is None:
+        so = os.path.join(ORACLE_DIR, "libdsim_oracle.so")
+        src = os.path.join(ORACLE_DIR, "dsim_oracle.cpp")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+        _lib = C.CDLL(so)
+    return _lib
+
+
+def golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as d:
+        return {k: d[k] for k in d.files}
+
+
+def template_from_golden(env):
+    return ArticulationTemplate.from_reference_dump(golden(env + "_model"))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def oracle_forward(t, q, qd, act, mact, dt, substeps, mm_freq, debug=False):
+    desc, keep = make_desc(t)
+    N = q.shape[0]
+    q, qd, act = _c(q), _c(qd), _c(act)
+    mact = _c(mact) if mact is not None else np.zeros((N, 0), np.float32)
+    qo, qdo = np.zeros_like(q), np.zeros_like(qd)
+    L, nd = t.n_links, t.n_qd
+    dbg = {}
+    if debug:
+        dbg = dict(X_sc=np.zeros((N, L, 7), np.float32), X_sm=np.zeros((N, L, 7), np.float32),
+                   S_s=np.zeros((N, nd, 6), np.float32), I_s=np.zeros((N, L, 6, 6), np.float32),
+                   v_s=np.zeros((N, L, 6), np.float32), a_s=np.zeros((N, L, 6), np.float32),
+                   f_s=np.zeros((N, L, 6), np.float32), ft_s=np.zeros((N, L, 6), np.float32),
+                   tau=np.zeros((N, nd), np.float32), qdd=np.zeros((N, nd), np.float32),
+                   H=np.zeros((N, nd, nd), np.float32), L=np.zeros((N, nd, nd), np.float32))
+    names = ["X_sc", "X_sm", "S_s", "I_s", "v_s", "a_s", "f_s", "ft_s", "tau", "qdd", "H", "L"]
+    fn = oracle().dsim_oracle_step_forward
+    fn.restype = C.c_int
+    rc = fn(C.byref(desc), C.c_int(N), _p(q), _p(qd), _p(act), _p(mact), C.c_float(dt), C.c_int(substeps),
+            C.c_int(mm_freq), _p(qo), _p(qdo), *[_p(dbg.get(n)) for n in names])
+    assert rc == 0
+    return qo, qdo, dbg
+
+
+def oracle_backward(t, q, qd, act, mact, dt, substeps, mm_freq, gq_out, gqd_out):
+    desc, keep = make_desc(t)
+    N = q.shape[0]
+    q, qd, act, gq_out, gqd_out = _c(q), _c(qd), _c(act), _c(gq_out), _c(gqd_out)
+    mact = _c(mact) if mact is not None else np.zeros((N, 0), np.float32)
+    gq, gqd, ga, gm = np.zeros_like(q), np.zeros_like(qd), np.zeros_like(act), np.zeros_like(mact)
+    qo, qdo = np.zeros_like(q), np.zeros_like(qd)
+    fn = oracle().dsim_oracle_step_backward
+    fn.restype = C.c_int
+    rc = fn(C.byref(desc), C.c_int(N), _p(q), _p(qd), _p(act), _p(mact), C.c_float(dt), C.c_int(substeps),
+            C.c_int(mm_freq), _p(gq_out), _p(gqd_out), _p(gq), _p(gqd), _p(ga), _p(gm), _p(qo), _p(qdo))
+    assert rc == 0
+    return dict(gq=gq, gqd=gqd, gact=ga, gmact=gm, q_out=qo, qd_out=qdo)
