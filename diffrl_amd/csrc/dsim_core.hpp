@@ -1,0 +1,902 @@
+// dsim_core.hpp -- per-environment forward substep and its hand-derived adjoint, written as
+// SPMD "phases" over the 64 lanes of ONE wavefront (one environment per workgroup, all state in LDS).
+//
+// Every phase is `ex.run([&](int lane){...})`: on the GPU `run` executes the body for
+// lane = threadIdx.x and then synchronises the workgroup (see dsim_hip.hip); a phase never reads
+// LDS words that another lane writes in the same phase, so all cross-lane traffic goes
+// LDS-write -> barrier -> LDS-read.  Nothing is kept in registers across phases.
+// (tests/emu/ re-uses this file with an executor that runs the lanes one after another on the host
+// to unit-test the phase logic without a GPU; that harness is test-only and not part of the library.)
+//
+// What is computed (reference: dflex/dflex/sim.py, one call of SemiImplicitIntegrator._simulate,
+// sim.py:2316-2601), restructured for a wavefront instead of "one thread per articulation":
+//   kinematics  level-synchronous over the tree: X_sj, X_sc, COM, motion subspace S, joint twist,
+//               v, a (sim.py:1638-1678, 1323-1387, 1716-1763), world inertia in 10-parameter rigid
+//               form instead of the dense T^T I T product (sim.py:1117-1134), body force (1765-1786)
+//   contacts    one lane per contact point, deterministic per-body gather (sim.py:1137-1206)
+//   muscles     one lane per active segment (sim.py:1209-1265)
+//   tau         flat subtree sums instead of the serial leaf-to-root loop (sim.py:1792-1842)
+//   mass matrix composite-rigid-body form of H = J^T M J (sim.py:2475-2545; spatial.h:691-815 and the
+//               two dense gemms are never formed), + armature, explicit inverse by Gauss-Jordan
+//               instead of Cholesky + two substitutions per substep (matnn.h:140-230)
+//   integrate   sim.py:1505-1636
+// and the reverse sweep with the reference's adjoint conventions.
+#pragma once
+#include "dsim_layout.hpp"
+#include "dsim_math.hpp"
+
+#define DSIM_NL 64
+
+typedef int __attribute__((may_alias)) dsim_int_a;
+
+struct DsimCtx {
+    float* s;  // LDS image base
+    DsimOff o;
+    DsimDims d;
+    float h;   // substep length
+};
+
+#define CI(name) (reinterpret_cast<const dsim_int_a*>(c.s) + c.o.name)
+#define CF(name) (static_cast<const float*>(c.s) + c.o.name)
+#define WF(name) (c.s + c.o.name)
+
+// ================================================================================================
+// forward
+// ================================================================================================
+
+// FK + motion subspace + velocities + world inertia + body force, level by level.
+template <class Exec> DSIM_FN void dsim_fwd_kinematics(const DsimCtx& c, Exec& ex) {
+    const dsim_int_a *jtype = CI(jtype), *parent = CI(parent), *qstart = CI(qstart), *qdstart = CI(qdstart),
+                     *lvl_start = CI(lvl_start), *lvl_links = CI(lvl_links);
+    for (int lv = 0; lv < c.d.D; ++lv) {
+        const int b0 = lvl_start[lv], b1 = lvl_start[lv + 1];
+        ex.run([&](int lane) {
+            for (int idx = b0 + lane; idx < b1; idx += DSIM_NL) {
+                const int i = lvl_links[idx], par = parent[i], type = jtype[i];
+                const int cs = qstart[i], ds = qdstart[i];
+                const float *q = WF(q), *qd = WF(qd);
+                v3 psp = zero3();
+                q4 rsp = mkq(0.f, 0.f, 0.f, 1.f);
+                sv6 vpar = zerosv(), apar = zerosv();
+                if (par >= 0) {
+                    psp = ld3(WF(xsc) + 7 * par);
+                    rsp = ldq(WF(xsc) + 7 * par + 3);
+                    vpar = ldsv(WF(v) + 6 * par);
+                    apar = ldsv(WF(a) + 6 * par);
+                }
+                const v3 ppj = ld3(CF(xpj) + 7 * i);
+                const q4 rpj = ldq(CF(xpj) + 7 * i + 3);
+                const v3 pj = rotate(rsp, ppj) + psp;
+                const q4 rj = qmul(rsp, rpj);
+                st3(WF(xsj) + 7 * i, pj);
+                stq(WF(xsj) + 7 * i + 3, rj);
+                const v3 axis = ld3(CF(axis) + 3 * i);
+                v3 pc = pj;
+                q4 rc = rj;
+                sv6 vj = zerosv();
+                float* S = WF(S);
+                if (type == DSIM_JOINT_PRISMATIC) {
+                    const v3 u = rotate(rj, axis);
+                    pc = pj + u * q[cs];
+                    const sv6 s = mksv(zero3(), u);
+                    stsv(S + 6 * ds, s);
+                    vj = s * qd[ds];
+                } else if (type == DSIM_JOINT_REVOLUTE) {
+                    rc = qmul(rj, quat_axis_angle(axis, q[cs]));
+                    const v3 w = rotate(rj, axis);
+                    const sv6 s = mksv(w, cross(pj, w));
+                    stsv(S + 6 * ds, s);
+                    vj = s * qd[ds];
+                } else if (type == DSIM_JOINT_BALL) {
+                    rc = qmul(rj, ldq(q + cs));
+                    for (int k = 0; k < 3; ++k) {
+                        const v3 e = mk3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f);
+                        const v3 w = rotate(rj, e);
+                        const sv6 s = mksv(w, cross(pj, w));
+                        stsv(S + 6 * (ds + k), s);
+                        vj += s * qd[ds + k];
+                    }
+                } else if (type == DSIM_JOINT_FREE) {
+                    pc = rotate(rj, ld3(q + cs)) + pj;
+                    rc = qmul(rj, ldq(q + cs + 3));
+                    for (int k = 0; k < 6; ++k)
+                        for (int r = 0; r < 6; ++r) S[6 * (ds + k) + r] = (k == r) ? 1.f : 0.f;
+                    vj = ldsv(qd + ds);
+                }
+                st3(WF(xsc) + 7 * i, pc);
+                stq(WF(xsc) + 7 * i + 3, rc);
+                const v3 cm = rotate(rc, ld3(CF(com) + 3 * i)) + pc;
+                st3(WF(pm) + 3 * i, cm);
+                const sv6 v = vpar + vj;
+                const sv6 a = apar + scross(v, vj);
+                stsv(WF(vj) + 6 * i, vj);
+                stsv(WF(v) + 6 * i, v);
+                stsv(WF(a) + 6 * i, a);
+                // world-frame inertia about the origin: Theta = R Ic R^T, A = Theta + m(c.c 1 - c c^T), h = m c
+                const float* ic = CF(ic6) + 6 * i;
+                const float m = CF(mass)[i];
+                const v3 rx = rotate(rc, mk3(1.f, 0.f, 0.f)), ry = rotate(rc, mk3(0.f, 1.f, 0.f)),
+                         rz = rotate(rc, mk3(0.f, 0.f, 1.f));
+                // B = R * Ic (columns of R are rx, ry, rz)
+                const v3 b0 = rx * ic[0] + ry * ic[1] + rz * ic[2];
+                const v3 b1 = rx * ic[1] + ry * ic[3] + rz * ic[4];
+                const v3 b2 = rx * ic[2] + ry * ic[4] + rz * ic[5];
+                inertia10 I;
+                I.m = m;
+                I.h = cm * m;
+                const float cc = dot(cm, cm);
+                I.axx = b0.x * rx.x + b1.x * ry.x + b2.x * rz.x + m * (cc - cm.x * cm.x);
+                I.axy = b0.x * rx.y + b1.x * ry.y + b2.x * rz.y - m * cm.x * cm.y;
+                I.axz = b0.x * rx.z + b1.x * ry.z + b2.x * rz.z - m * cm.x * cm.z;
+                I.ayy = b0.y * rx.y + b1.y * ry.y + b2.y * rz.y + m * (cc - cm.y * cm.y);
+                I.ayz = b0.y * rx.z + b1.y * ry.z + b2.y * rz.z - m * cm.y * cm.z;
+                I.azz = b0.z * rx.z + b1.z * ry.z + b2.z * rz.z + m * (cc - cm.z * cm.z);
+                st_i10(WF(i10) + 10 * i, I);
+                const sv6 fb = inertia_mul(I, a) + scross_dual(v, inertia_mul(I, v));
+                const v3 mg = ld3(CF(grav)) * m;
+                const sv6 fg = mksv(cross(cm, mg), mg);
+                stsv(WF(f) + 6 * i, fb - fg);
+            }
+        });
+    }
+}
+
+// ground contacts (sim.py:1137-1206) and muscle segments (sim.py:1209-1242): per-item wrenches
+template <class Exec> DSIM_FN void dsim_fwd_external(const DsimCtx& c, Exec& ex) {
+    if (c.d.C == 0 && c.d.NS == 0) return;
+    ex.run([&](int lane) {
+        for (int k = lane; k < c.d.C; k += DSIM_NL) {
+            const int b = CI(cbody)[k];
+            const v3 xp = ld3(WF(xsc) + 7 * b);
+            const q4 xq = ldq(WF(xsc) + 7 * b + 3);
+            const sv6 vb = ldsv(WF(v) + 6 * b);
+            const float* mat = CF(cmat) + 4 * k;
+            const float ke = mat[0], kd = mat[1], kf = mat[2], mu = mat[3];
+            v3 p = xp + rotate(xq, ld3(CF(cpoint) + 3 * k));
+            p.y -= CF(cdist)[k];
+            const v3 dpdt = vb.v + cross(vb.w, p);
+            const float cc = p.y;
+            sv6 wr = zerosv();
+            if (cc < 0.0f) {
+                const float vn = dpdt.y;
+                const v3 vt = mk3(dpdt.x, 0.f, dpdt.z);
+                const float fn = cc * ke;
+                const float fd = (vn < 0.0f ? vn : 0.0f) * kd * (0.0f - cc);
+                const float lt = sqrtf(dot(vt, vt));
+                const float a1 = kf * lt, a2 = 0.0f - mu * cc * ke;
+                const float smin = a1 < a2 ? a1 : a2;
+                v3 ft = zero3();
+                if (lt > 0.0f) ft = vt * (smin / lt);
+                const v3 ftot = mk3(ft.x, fn + fd, ft.z);
+                wr = mksv(cross(p, ftot), ftot);
+            }
+            stsv(WF(cw) + 6 * k, wr);
+        }
+        for (int s = lane; s < c.d.NS; s += DSIM_NL) {
+            const int w = CI(seg_wp)[s];
+            const int l0 = CI(mlinks)[w], l1 = CI(mlinks)[w + 1];
+            const v3 pos0 = ld3(WF(xsc) + 7 * l0) + rotate(ldq(WF(xsc) + 7 * l0 + 3), ld3(CF(mpoints) + 3 * w));
+            const v3 pos1 = ld3(WF(xsc) + 7 * l1) + rotate(ldq(WF(xsc) + 7 * l1 + 3), ld3(CF(mpoints) + 3 * w + 3));
+            const v3 d = pos1 - pos0;
+            const float l = sqrtf(dot(d, d));
+            v3 f = zero3();
+            if (l > 0.0f) f = d * (WF(mact)[CI(seg_m)[s]] / l);
+            float* o = WF(mus) + 9 * s;
+            st3(o, f);
+            st3(o + 3, pos0);
+            st3(o + 6, pos1);
+        }
+    });
+    ex.run([&](int lane) {
+        for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
+            const int i = it / 6, k = it - 6 * i;
+            float acc = WF(f)[it];
+            for (int e = CI(cb_start)[i]; e < CI(cb_start)[i + 1]; ++e) acc += WF(cw)[6 * CI(cb_list)[e] + k];
+            for (int e = CI(ml_start)[i]; e < CI(ml_start)[i + 1]; ++e) {
+                const int code = CI(ml_list)[e], s = code >> 1, side = code & 1;
+                const float* o = WF(mus) + 9 * s;
+                const v3 f = ld3(o);
+                float val;
+                if (k >= 3) {
+                    val = o[k - 3];
+                } else {
+                    const v3 t = cross(ld3(o + 3 + 3 * side), f);
+                    val = k == 0 ? t.x : (k == 1 ? t.y : t.z);
+                }
+                acc += side ? val : -val;
+            }
+            WF(f)[it] = acc;
+        }
+    });
+}
+
+// joint-space forces (sim.py:1421-1502, 1792-1842)
+template <class Exec> DSIM_FN void dsim_fwd_tau(const DsimCtx& c, Exec& ex) {
+    ex.run([&](int lane) {
+        for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
+            const int i = it / 6, k = it - 6 * i;
+            float acc = 0.f;
+            for (int e = CI(sub_start)[i]; e < CI(sub_start)[i + 1]; ++e) acc += WF(f)[6 * CI(sub_list)[e] + k];
+            WF(ftot)[it] = acc;
+        }
+    });
+    ex.run([&](int lane) {
+        for (int d = lane; d < c.d.nd; d += DSIM_NL) {
+            const int i = CI(dof_link)[d], type = CI(jtype)[i];
+            const int cs = CI(qstart)[i], ds = CI(qdstart)[i];
+            float t = 0.0f - sdot(ldsv(WF(S) + 6 * d), ldsv(WF(ftot) + 6 * i));
+            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
+                const float q = WF(q)[cs], qd = WF(qd)[d];
+                const float lower = CF(lower)[cs], upper = CF(upper)[cs], lke = CF(lke)[i];
+                float limit_f = 0.0f;
+                if (q < lower) limit_f = lke * (lower - q);
+                if (q > upper) limit_f = lke * (upper - q);
+                t = t - CF(tke)[i] * (q - CF(target)[cs]) - CF(tkd)[i] * qd + WF(act)[d] + limit_f - CF(lkd)[i] * qd;
+            } else if (type == DSIM_JOINT_BALL) {
+                const int k = d - ds;
+                t = t - WF(qd)[d] * CF(tkd)[i] - WF(q)[cs + k] * CF(tke)[i];
+            }
+            WF(tau)[d] = t;
+        }
+    });
+}
+
+// composite inertias Ic[i] = sum over subtree(i), F_b = Ic[link(b)] S_b
+template <class Exec> DSIM_FN void dsim_fwd_composite(const DsimCtx& c, Exec& ex) {
+    const int nd = c.d.nd;
+    ex.run([&](int lane) {
+        for (int it = lane; it < 10 * c.d.L; it += DSIM_NL) {
+            const int i = it / 10, k = it - 10 * i;
+            float acc = 0.f;
+            for (int e = CI(sub_start)[i]; e < CI(sub_start)[i + 1]; ++e) acc += WF(i10)[10 * CI(sub_list)[e] + k];
+            WF(ic10)[it] = acc;
+        }
+    });
+    ex.run([&](int lane) {
+        for (int b = lane; b < nd; b += DSIM_NL) {
+            const inertia10 I = ld_i10(WF(ic10) + 10 * CI(dof_link)[b]);
+            stsv(WF(F) + 6 * b, inertia_mul(I, ldsv(WF(S) + 6 * b)));
+        }
+    });
+}
+
+// H = J^T M J in composite-rigid-body form + armature, inverted in place (Gauss-Jordan, SPD, no pivoting)
+template <class Exec> DSIM_FN void dsim_fwd_mass(const DsimCtx& c, Exec& ex) {
+    const int nd = c.d.nd;
+    dsim_fwd_composite(c, ex);
+    ex.run([&](int lane) {
+        for (int it = lane; it < nd * nd; it += DSIM_NL) {
+            const int a = it / nd, b = it - nd * a;
+            const int r = CI(rel)[it];
+            float hv = 0.f;
+            if (r == 1) hv = sdot(ldsv(WF(S) + 6 * a), ldsv(WF(F) + 6 * b));
+            else if (r == 2) hv = sdot(ldsv(WF(S) + 6 * b), ldsv(WF(F) + 6 * a));
+            if (a == b) hv += CF(arm)[a];
+            WF(hinv)[it] = hv;
+        }
+    });
+    for (int k = 0; k < nd; ++k) {
+        ex.run([&](int lane) {
+            for (int j = lane; j < nd; j += DSIM_NL) {
+                const float piv = WF(hinv)[k * nd + k];
+                WF(prow)[j] = (j == k ? 1.0f : WF(hinv)[k * nd + j]) / piv;
+                WF(pcol)[j] = WF(hinv)[j * nd + k];
+            }
+        });
+        ex.run([&](int lane) {
+            for (int it = lane; it < nd * nd; it += DSIM_NL) {
+                const int i = it / nd, j = it - nd * i;
+                if (i == k) WF(hinv)[it] = WF(prow)[j];
+                else WF(hinv)[it] = (j == k ? 0.0f : WF(hinv)[it]) - WF(pcol)[i] * WF(prow)[j];
+            }
+        });
+    }
+}
+
+template <class Exec> DSIM_FN void dsim_fwd_solve(const DsimCtx& c, Exec& ex) {
+    const int nd = c.d.nd;
+    ex.run([&](int lane) {
+        for (int i = lane; i < nd; i += DSIM_NL) {
+            float acc = 0.f;
+            for (int j = 0; j < nd; ++j) acc += WF(hinv)[i * nd + j] * WF(tau)[j];
+            WF(qdd)[i] = acc;
+        }
+    });
+}
+
+// semi-implicit Euler (sim.py:1505-1636); in place on q, qd
+template <class Exec> DSIM_FN void dsim_fwd_integrate(const DsimCtx& c, Exec& ex) {
+    ex.run([&](int lane) {
+        const float h = c.h;
+        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+            const int type = CI(jtype)[i], cs = CI(qstart)[i], ds = CI(qdstart)[i];
+            float *q = WF(q), *qd = WF(qd);
+            const float* qdd = WF(qdd);
+            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
+                const float qdn = qd[ds] + qdd[ds] * h;
+                qd[ds] = qdn;
+                q[cs] = q[cs] + qdn * h;
+            } else if (type == DSIM_JOINT_BALL || type == DSIM_JOINT_FREE) {
+                const int ro = type == DSIM_JOINT_FREE ? 3 : 0;  // offset of the quaternion in q
+                const v3 w = ld3(qd + ds) + ld3(qdd + ds) * h;
+                if (type == DSIM_JOINT_FREE) {
+                    const v3 v = ld3(qd + ds + 3) + ld3(qdd + ds + 3) * h;
+                    const v3 p = ld3(q + cs);
+                    st3(q + cs, p + (v + cross(w, p)) * h);
+                    st3(qd + ds + 3, v);
+                }
+                const q4 r = ldq(q + cs + ro);
+                const q4 dr = qmul(mkq(w.x, w.y, w.z, 0.f), r) * 0.5f;
+                const q4 rt = r + dr * h;
+                const float l = sqrtf(qdot(rt, rt));
+                q4 rn = mkq(0.f, 0.f, 0.f, 1.f);
+                if (l > 0.0f) rn = rt * (1.0f / l);
+                stq(q + cs + ro, rn);
+                st3(qd + ds, w);
+            }
+        }
+    });
+}
+
+// one substep on the LDS-resident state
+template <class Exec> DSIM_FN void dsim_fwd_substep(const DsimCtx& c, Exec& ex, bool update_mass) {
+    dsim_fwd_kinematics(c, ex);
+    dsim_fwd_external(c, ex);
+    dsim_fwd_tau(c, ex);
+    if (update_mass) dsim_fwd_mass(c, ex);
+    dsim_fwd_solve(c, ex);
+    dsim_fwd_integrate(c, ex);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one env.step(): `substeps` substeps with act / muscle activations held fixed (sim.py:2104-2116).
+// g_* are this environment's rows of the caller's tensors (global memory); ckpt may be null.
+template <class Exec>
+DSIM_FN void dsim_env_step_forward(const DsimCtx& c, Exec& ex, int substeps, int mm_freq, const float* g_q,
+                                   const float* g_qd, const float* g_act, const float* g_mact, float* g_q_out,
+                                   float* g_qd_out, float* g_ckpt) {
+    const int nq = c.d.nq, nd = c.d.nd, M = c.d.M;
+    ex.run([&](int lane) {
+        for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = g_q[k];
+        for (int k = lane; k < nd; k += DSIM_NL) {
+            WF(qd)[k] = g_qd[k];
+            WF(act)[k] = g_act[k];
+        }
+        for (int k = lane; k < M; k += DSIM_NL) WF(mact)[k] = g_mact[k];
+    });
+    for (int s = 0; s < substeps; ++s) {
+        if (g_ckpt) {
+            float* ck = g_ckpt + (size_t)s * (nq + nd);
+            // no barrier needed after this phase's global stores, but run() keeps the structure uniform
+            ex.run([&](int lane) {
+                for (int k = lane; k < nq; k += DSIM_NL) ck[k] = WF(q)[k];
+                for (int k = lane; k < nd; k += DSIM_NL) ck[nq + k] = WF(qd)[k];
+            });
+        }
+        dsim_fwd_substep(c, ex, (s % mm_freq) == 0);
+    }
+    ex.run([&](int lane) {
+        for (int k = lane; k < nq; k += DSIM_NL) g_q_out[k] = WF(q)[k];
+        for (int k = lane; k < nd; k += DSIM_NL) g_qd_out[k] = WF(qd)[k];
+    });
+}
+
+// ================================================================================================
+// adjoint (hand-derived reverse sweep of one substep)
+// ================================================================================================
+// Preconditions: LDS q/qd hold the substep's INPUT state; kinematics, external, tau and solve have
+// been recomputed for it (and dsim_fwd_composite on an update substep); hinv is the inverse that the
+// forward pass used for this substep; aqn/aqdn hold the cotangents of the substep outputs.
+// Postconditions: aq/aqd = cotangents of the substep inputs; aact/amact/aH accumulated.
+
+// integrate^T, solve^T (matnn.h:310-336), tau^T
+template <class Exec> DSIM_FN void dsim_bwd_joint_space(const DsimCtx& c, Exec& ex) {
+    const int nd = c.d.nd;
+    ex.run([&](int lane) {
+        const float h = c.h;
+        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+            const int type = CI(jtype)[i], cs = CI(qstart)[i], ds = CI(qdstart)[i];
+            const float *q = WF(q), *qd = WF(qd), *qdd = WF(qdd), *aqn = WF(aqn), *aqdn = WF(aqdn);
+            float *aq = WF(aq), *aqd = WF(aqd), *aqdd = WF(aqdd);
+            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
+                const float g = aqdn[ds] + h * aqn[cs];
+                aq[cs] = aqn[cs];
+                aqd[ds] = g;
+                aqdd[ds] = h * g;
+            } else if (type == DSIM_JOINT_BALL || type == DSIM_JOINT_FREE) {
+                const int ro = type == DSIM_JOINT_FREE ? 3 : 0;
+                const v3 w = ld3(qd + ds) + ld3(qdd + ds) * h;
+                const q4 r = ldq(q + cs + ro);
+                const q4 W = mkq(w.x, w.y, w.z, 0.f);
+                const q4 rt = r + qmul(W, r) * (0.5f * h);
+                const float l = sqrtf(qdot(rt, rt));
+                const q4 g_rn = ldq(aqn + cs + ro);
+                q4 g_rt = mkq(0.f, 0.f, 0.f, 0.f);
+                if (l > 0.0f) {
+                    const float il = 1.0f / l;
+                    const q4 rn = rt * il;
+                    g_rt = (g_rn + rn * (-qdot(rn, g_rn))) * il;
+                }
+                const q4 g_r = g_rt + qmul_adj_b(W, g_rt) * (0.5f * h);
+                const q4 g_W = qmul_adj_a(r, g_rt) * (0.5f * h);
+                v3 g_w = qvec(g_W) + ld3(aqdn + ds);
+                if (type == DSIM_JOINT_FREE) {
+                    const v3 p = ld3(q + cs);
+                    const v3 g_pn = ld3(aqn + cs);
+                    const v3 g_dp = g_pn * h;
+                    const v3 g_v = g_dp + ld3(aqdn + ds + 3);
+                    g_w += cross(p, g_dp);
+                    st3(aq + cs, g_pn - cross(w, g_dp));
+                    st3(aqd + ds + 3, g_v);
+                    st3(aqdd + ds + 3, g_v * h);
+                }
+                stq(aq + cs + ro, g_r);
+                st3(aqd + ds, g_w);
+                st3(aqdd + ds, g_w * h);
+            }
+        }
+    });
+    ex.run([&](int lane) {
+        for (int i = lane; i < nd; i += DSIM_NL) {
+            float acc = 0.f;
+            for (int j = 0; j < nd; ++j) acc += WF(hinv)[i * nd + j] * WF(aqdd)[j];  // hinv is symmetric
+            WF(atau)[i] = acc;
+        }
+    });
+    ex.run([&](int lane) {
+        for (int it = lane; it < nd * nd; it += DSIM_NL) {
+            const int i = it / nd, j = it - nd * i;
+            WF(aH)[it] -= WF(atau)[i] * WF(qdd)[j];
+        }
+        for (int d = lane; d < nd; d += DSIM_NL) {
+            const int i = CI(dof_link)[d], type = CI(jtype)[i];
+            const int cs = CI(qstart)[i], ds = CI(qdstart)[i];
+            const float at = WF(atau)[d];
+            stsv(WF(aS) + 6 * d, ldsv(WF(ftot) + 6 * i) * (-at));
+            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
+                const float q = WF(q)[cs];
+                float dq = -CF(tke)[i];
+                if (q < CF(lower)[cs]) dq = -CF(tke)[i] - CF(lke)[i];
+                if (q > CF(upper)[cs]) dq = -CF(tke)[i] - CF(lke)[i];
+                WF(aq)[cs] += dq * at;
+                WF(aqd)[d] += (-CF(tkd)[i] - CF(lkd)[i]) * at;
+                WF(aact)[d] += at;
+            } else if (type == DSIM_JOINT_BALL) {
+                WF(aq)[cs + (d - ds)] += -CF(tke)[i] * at;
+                WF(aqd)[d] += -CF(tkd)[i] * at;
+            }
+        }
+    });
+    ex.run([&](int lane) {
+        for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
+            const int i = it / 6, k = it - 6 * i;
+            float acc = 0.f;
+            for (int d = CI(qdstart)[i]; d < CI(qdstart)[i + 1]; ++d) acc -= WF(S)[6 * d + k] * WF(atau)[d];
+            WF(aftot)[it] = acc;
+        }
+    });
+    ex.run([&](int lane) {
+        for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
+            const int j = it / 6, k = it - 6 * j;
+            float acc = 0.f;
+            for (int e = CI(anc_start)[j]; e < CI(anc_start)[j + 1]; ++e) acc += WF(aftot)[6 * CI(anc_list)[e] + k];
+            WF(af)[it] = acc;
+        }
+    });
+}
+
+// contacts^T and muscles^T: per-item cotangents of (X_sc, v_s) / (X_sc, activation)
+template <class Exec> DSIM_FN void dsim_bwd_external(const DsimCtx& c, Exec& ex) {
+    if (c.d.C == 0 && c.d.NS == 0) return;
+    ex.run([&](int lane) {
+        for (int k = lane; k < c.d.C; k += DSIM_NL) {
+            float* o = WF(acx) + 13 * k;
+            for (int r = 0; r < 13; ++r) o[r] = 0.f;
+            const int b = CI(cbody)[k];
+            const v3 xp = ld3(WF(xsc) + 7 * b);
+            const q4 xq = ldq(WF(xsc) + 7 * b + 3);
+            const sv6 vb = ldsv(WF(v) + 6 * b);
+            const float* mat = CF(cmat) + 4 * k;
+            const float ke = mat[0], kd = mat[1], kf = mat[2], mu = mat[3];
+            const v3 cp = ld3(CF(cpoint) + 3 * k);
+            v3 p = xp + rotate(xq, cp);
+            p.y -= CF(cdist)[k];
+            const float cc = p.y;
+            if (cc < 0.0f) {
+                const v3 dpdt = vb.v + cross(vb.w, p);
+                const float vn = dpdt.y;
+                const v3 vt = mk3(dpdt.x, 0.f, dpdt.z);
+                const float fn = cc * ke;
+                const float vmin = vn < 0.0f ? vn : 0.0f;
+                const float fd = vmin * kd * (0.0f - cc);
+                const float lt = sqrtf(dot(vt, vt));
+                const float a1 = kf * lt, a2 = 0.0f - mu * cc * ke;
+                const bool first = a1 < a2;
+                const float smin = first ? a1 : a2;
+                v3 nhat = zero3();
+                if (lt > 0.0f) nhat = vt * (1.0f / lt);
+                const v3 ft = nhat * smin;
+                const v3 F = mk3(ft.x, fn + fd, ft.z);
+                const sv6 A = ldsv(WF(af) + 6 * b);  // cotangent of body_f_s[b]
+                v3 a_p = cross(F, A.w);
+                const v3 a_F = A.v + cross(A.w, p);
+                const float a_fnfd = a_F.y;
+                const v3 a_ft = a_F;  // ft.y == 0 and receives a_F.y too, but vt.y has no dependence (see below)
+                const float a_s = dot(nhat, a_ft);
+                const v3 a_nhat = a_ft * smin;
+                float a_lt = 0.f, a_c = 0.f, a_vn = 0.f;
+                if (first) a_lt += kf * a_s;
+                else a_c += -mu * ke * a_s;
+                v3 a_vt = zero3();
+                if (lt > 0.0f) a_vt = (a_nhat - nhat * dot(nhat, a_nhat)) * (1.0f / lt) + nhat * a_lt;
+                if (vn < 0.0f) a_vn += kd * (0.0f - cc) * a_fnfd;
+                a_c += -vmin * kd * a_fnfd;
+                a_c += ke * a_fnfd;
+                // vt = dpdt - n*vn ; vn = n.dpdt  (n = +y)
+                v3 a_dp = a_vt;
+                a_vn += -a_vt.y;
+                a_dp.y += a_vn;
+                a_p.y += a_c;
+                // dpdt = v + w x p
+                const v3 a_vv = a_dp;
+                const v3 a_vw = cross(p, a_dp);
+                a_p += cross(a_dp, vb.w);
+                st3(o, a_p);
+                stq(o + 3, rotate_adj_q(xq, cp, a_p));
+                st3(o + 7, a_vw);
+                st3(o + 10, a_vv);
+            }
+        }
+        for (int s = lane; s < c.d.NS; s += DSIM_NL) {
+            const int w = CI(seg_wp)[s];
+            const int l0 = CI(mlinks)[w], l1 = CI(mlinks)[w + 1];
+            const float* mu_ = WF(mus) + 9 * s;
+            const v3 f = ld3(mu_), pos0 = ld3(mu_ + 3), pos1 = ld3(mu_ + 6);
+            const float act = WF(mact)[CI(seg_m)[s]];
+            const sv6 A0 = ldsv(WF(af) + 6 * l0), A1 = ldsv(WF(af) + 6 * l1);
+            const v3 a_f = cross(A1.w, pos1) + A1.v - cross(A0.w, pos0) - A0.v;
+            v3 a_p0 = -cross(f, A0.w);
+            v3 a_p1 = cross(f, A1.w);
+            const v3 d = pos1 - pos0;
+            const float l = sqrtf(dot(d, d));
+            float a_act = 0.f;
+            if (l > 0.0f) {
+                const v3 n = d * (1.0f / l);
+                a_act = dot(n, a_f);
+                const v3 a_n = a_f * act;
+                const v3 a_d = (a_n - n * dot(n, a_n)) * (1.0f / l);
+                a_p1 += a_d;
+                a_p0 -= a_d;
+            }
+            float* o = WF(amus) + 15 * s;
+            st3(o, a_p0);
+            stq(o + 3, rotate_adj_q(ldq(WF(xsc) + 7 * l0 + 3), ld3(CF(mpoints) + 3 * w), a_p0));
+            st3(o + 7, a_p1);
+            stq(o + 10, rotate_adj_q(ldq(WF(xsc) + 7 * l1 + 3), ld3(CF(mpoints) + 3 * w + 3), a_p1));
+            o[14] = a_act;
+        }
+    });
+}
+
+// mass matrix^T (update substeps): aH -> aS (added), ai10m
+template <class Exec> DSIM_FN void dsim_bwd_mass(const DsimCtx& c, Exec& ex) {
+    const int nd = c.d.nd;
+    ex.run([&](int lane) {
+        for (int a = lane; a < nd; a += DSIM_NL) {
+            const int la = CI(dof_link)[a];
+            sv6 acc = zerosv(), u = zerosv();
+            for (int b = 0; b < nd; ++b) {
+                const int r = CI(rel)[a * nd + b];
+                if (r == 0) continue;
+                // H[a][b] and H[b][a] are both S_a^T Ic S_b (for a == b the quadratic form gives the factor 2)
+                const float w = WF(aH)[a * nd + b] + WF(aH)[b * nd + a];
+                if (r == 1 && CI(dof_link)[b] != la) acc += ldsv(WF(F) + 6 * b) * w;
+                else u += ldsv(WF(S) + 6 * b) * w;
+            }
+            acc += inertia_mul(ld_i10(WF(ic10) + 10 * la), u);
+            float* o = WF(aS) + 6 * a;
+            add3(o, acc.w);
+            add3(o + 3, acc.v);
+        }
+        for (int j = lane; j < c.d.L; j += DSIM_NL) {
+            float g[10];
+            for (int k = 0; k < 10; ++k) g[k] = 0.f;
+            for (int b = CI(qdstart)[j]; b < CI(qdstart)[j + 1]; ++b) {
+                const sv6 Sb = ldsv(WF(S) + 6 * b);
+                for (int a = 0; a < nd; ++a) {
+                    const int la = CI(dof_link)[a];
+                    float w;
+                    if (la == j) {
+                        if (a > b) continue;
+                        w = (a == b) ? WF(aH)[a * nd + a] : WF(aH)[a * nd + b] + WF(aH)[b * nd + a];
+                    } else if (CI(rel)[a * nd + b] == 1) {
+                        w = WF(aH)[a * nd + b] + WF(aH)[b * nd + a];
+                    } else {
+                        continue;
+                    }
+                    inertia_bilinear_adj(g, ldsv(WF(S) + 6 * a), Sb, w);
+                }
+            }
+            for (int k = 0; k < 10; ++k) WF(aic10)[10 * j + k] = g[k];
+        }
+    });
+    ex.run([&](int lane) {
+        for (int it = lane; it < 10 * c.d.L; it += DSIM_NL) {
+            const int i = it / 10, k = it - 10 * i;
+            float acc = 0.f;
+            for (int e = CI(anc_start)[i]; e < CI(anc_start)[i + 1]; ++e) acc += WF(aic10)[10 * CI(anc_list)[e] + k];
+            WF(ai10m)[it] = acc;
+        }
+    });
+}
+
+// body level: f^T, velocity/acceleration recursions^T, joint motion^T, pose cotangents, FK^T
+template <class Exec> DSIM_FN void dsim_bwd_bodies(const DsimCtx& c, Exec& ex, bool update_mass) {
+    ex.run([&](int lane) {
+        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+            const inertia10 I = ld_i10(WF(i10) + 10 * i);
+            const sv6 v = ldsv(WF(v) + 6 * i), a = ldsv(WF(a) + 6 * i), r = ldsv(WF(af) + 6 * i);
+            const sv6 hv = inertia_mul(I, v);
+            sv6 a_v, a_hv;
+            a_v.w = cross(hv.w, r.w) + cross(hv.v, r.v);
+            a_v.v = cross(hv.v, r.w);
+            a_hv.w = cross(r.w, v.w);
+            a_hv.v = cross(r.w, v.v) + cross(r.v, v.w);
+            a_v += inertia_mul(I, a_hv);
+            float g[10];
+            for (int k = 0; k < 10; ++k) g[k] = update_mass ? WF(ai10m)[10 * i + k] : 0.f;
+            inertia_bilinear_adj(g, r, a, 1.0f);
+            inertia_bilinear_adj(g, a_hv, v, 1.0f);
+            for (int k = 0; k < 10; ++k) WF(ai10)[10 * i + k] = g[k];
+            stsv(WF(aa) + 6 * i, inertia_mul(I, r));
+            st3(WF(ac) + 3 * i, cross(r.w, ld3(CF(grav)) * I.m));
+            // gather contact / muscle cotangents of this body
+            v3 xp = zero3();
+            q4 xq = mkq(0.f, 0.f, 0.f, 0.f);
+            for (int e = CI(cb_start)[i]; e < CI(cb_start)[i + 1]; ++e) {
+                const float* o = WF(acx) + 13 * CI(cb_list)[e];
+                xp += ld3(o);
+                xq += ldq(o + 3);
+                a_v.w += ld3(o + 7);
+                a_v.v += ld3(o + 10);
+            }
+            for (int e = CI(ml_start)[i]; e < CI(ml_start)[i + 1]; ++e) {
+                const int code = CI(ml_list)[e];
+                const float* o = WF(amus) + 15 * (code >> 1) + 7 * (code & 1);
+                xp += ld3(o);
+                xq += ldq(o + 3);
+            }
+            st3(WF(axsc) + 7 * i, xp);
+            stq(WF(axsc) + 7 * i + 3, xq);
+            stsv(WF(av) + 6 * i, a_v);
+        }
+        for (int m = lane; m < c.d.M; m += DSIM_NL) {
+            float acc = 0.f;
+            for (int s = CI(ms_start)[m]; s < CI(ms_start)[m + 1]; ++s) acc += WF(amus)[15 * s + 14];
+            WF(amact)[m] += acc;
+        }
+    });
+    ex.run([&](int lane) {
+        for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
+            const int i = it / 6, k = it - 6 * i;
+            float acc = 0.f;
+            for (int e = CI(sub_start)[i]; e < CI(sub_start)[i + 1]; ++e) acc += WF(aa)[6 * CI(sub_list)[e] + k];
+            WF(aatot)[it] = acc;
+        }
+    });
+    ex.run([&](int lane) {
+        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+            const sv6 v = ldsv(WF(v) + 6 * i), vj = ldsv(WF(vj) + 6 * i), A = ldsv(WF(aatot) + 6 * i);
+            sv6 a_v = ldsv(WF(av) + 6 * i), a_vj;
+            a_v.w += cross(vj.w, A.w) + cross(vj.v, A.v);
+            a_v.v += cross(vj.w, A.v);
+            a_vj.w = cross(A.w, v.w) + cross(A.v, v.v);
+            a_vj.v = cross(A.v, v.w);
+            stsv(WF(av) + 6 * i, a_v);
+            stsv(WF(avj) + 6 * i, a_vj);
+        }
+    });
+    ex.run([&](int lane) {
+        for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
+            const int i = it / 6, k = it - 6 * i;
+            float acc = 0.f;
+            for (int e = CI(sub_start)[i]; e < CI(sub_start)[i + 1]; ++e) acc += WF(av)[6 * CI(sub_list)[e] + k];
+            WF(avtot)[it] = acc;
+        }
+    });
+    ex.run([&](int lane) {
+        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+            const int type = CI(jtype)[i], ds = CI(qdstart)[i];
+            const sv6 a_vj = ldsv(WF(avj) + 6 * i) + ldsv(WF(avtot) + 6 * i);
+            const float* qd = WF(qd);
+            // vj = S qd
+            if (type == DSIM_JOINT_FREE) {
+                add3(WF(aqd) + ds, a_vj.w);
+                add3(WF(aqd) + ds + 3, a_vj.v);
+            } else {
+                for (int d = ds; d < CI(qdstart)[i + 1]; ++d) {
+                    WF(aqd)[d] += sdot(ldsv(WF(S) + 6 * d), a_vj);
+                    float* o = WF(aS) + 6 * d;
+                    add3(o, a_vj.w * qd[d]);
+                    add3(o + 3, a_vj.v * qd[d]);
+                }
+            }
+            // cotangents of the poses: COM / inertia / gravity -> X_sc ; S -> X_sj
+            const q4 rc = ldq(WF(xsc) + 7 * i + 3);
+            const v3 cm = ld3(WF(pm) + 3 * i);
+            const float* g = WF(ai10) + 10 * i;
+            const float m = CF(mass)[i];
+            const float gxx = g[4], gxy = g[5], gxz = g[6], gyy = g[7], gyz = g[8], gzz = g[9];
+            v3 a_c = ld3(WF(ac) + 3 * i) + ld3(g + 1) * m;
+            a_c.x += m * (2.0f * cm.x * (gyy + gzz) - gxy * cm.y - gxz * cm.z);
+            a_c.y += m * (2.0f * cm.y * (gxx + gzz) - gxy * cm.x - gyz * cm.z);
+            a_c.z += m * (2.0f * cm.z * (gxx + gyy) - gxz * cm.x - gyz * cm.y);
+            q4 a_rc = rotate_adj_q(rc, ld3(CF(com) + 3 * i), a_c);
+            {
+                const float* ic = CF(ic6) + 6 * i;
+                const v3 ex_ = mk3(1.f, 0.f, 0.f), ey_ = mk3(0.f, 1.f, 0.f), ez_ = mk3(0.f, 0.f, 1.f);
+                const v3 rx = rotate(rc, ex_), ry = rotate(rc, ey_), rz = rotate(rc, ez_);
+                const v3 b0 = rx * ic[0] + ry * ic[1] + rz * ic[2];
+                const v3 b1 = rx * ic[1] + ry * ic[3] + rz * ic[4];
+                const v3 b2 = rx * ic[2] + ry * ic[4] + rz * ic[5];
+                // adj_R[:,k] = 2 G b_k with 2G = [[2gxx,gxy,gxz],[gxy,2gyy,gyz],[gxz,gyz,2gzz]]
+                const v3 c0 = mk3(2.f * gxx * b0.x + gxy * b0.y + gxz * b0.z, gxy * b0.x + 2.f * gyy * b0.y + gyz * b0.z,
+                                  gxz * b0.x + gyz * b0.y + 2.f * gzz * b0.z);
+                const v3 c1 = mk3(2.f * gxx * b1.x + gxy * b1.y + gxz * b1.z, gxy * b1.x + 2.f * gyy * b1.y + gyz * b1.z,
+                                  gxz * b1.x + gyz * b1.y + 2.f * gzz * b1.z);
+                const v3 c2 = mk3(2.f * gxx * b2.x + gxy * b2.y + gxz * b2.z, gxy * b2.x + 2.f * gyy * b2.y + gyz * b2.z,
+                                  gxz * b2.x + gyz * b2.y + 2.f * gzz * b2.z);
+                a_rc += rotate_adj_q(rc, ex_, c0);
+                a_rc += rotate_adj_q(rc, ey_, c1);
+                a_rc += rotate_adj_q(rc, ez_, c2);
+            }
+            add3(WF(axsc) + 7 * i, a_c);
+            addq(WF(axsc) + 7 * i + 3, a_rc);
+            const v3 pj = ld3(WF(xsj) + 7 * i);
+            const q4 rj = ldq(WF(xsj) + 7 * i + 3);
+            v3 a_pj = zero3();
+            q4 a_rj = mkq(0.f, 0.f, 0.f, 0.f);
+            if (type == DSIM_JOINT_PRISMATIC) {
+                a_rj = rotate_adj_q(rj, ld3(CF(axis) + 3 * i), ld3(WF(aS) + 6 * ds + 3));
+            } else if (type == DSIM_JOINT_REVOLUTE || type == DSIM_JOINT_BALL) {
+                for (int d = ds; d < CI(qdstart)[i + 1]; ++d) {
+                    const int k = d - ds;
+                    const v3 ax = type == DSIM_JOINT_REVOLUTE
+                                      ? ld3(CF(axis) + 3 * i)
+                                      : mk3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f);
+                    const v3 w = rotate(rj, ax);
+                    const v3 sw = ld3(WF(aS) + 6 * d), sv_ = ld3(WF(aS) + 6 * d + 3);
+                    a_pj += cross(w, sv_);
+                    a_rj += rotate_adj_q(rj, ax, sw - cross(pj, sv_));
+                }
+            }
+            st3(WF(axsj) + 7 * i, a_pj);
+            stq(WF(axsj) + 7 * i + 3, a_rj);
+        }
+    });
+    // FK^T, leaves to root
+    for (int lv = c.d.D - 1; lv >= 0; --lv) {
+        const int b0 = CI(lvl_start)[lv], b1 = CI(lvl_start)[lv + 1];
+        ex.run([&](int lane) {
+            for (int idx = b0 + lane; idx < b1; idx += DSIM_NL) {
+                const int i = CI(lvl_links)[idx], par = CI(parent)[i], type = CI(jtype)[i], cs = CI(qstart)[i];
+                v3 a_pc = ld3(WF(axsc) + 7 * i);
+                q4 a_rc = ldq(WF(axsc) + 7 * i + 3);
+                for (int e = CI(child_start)[i]; e < CI(child_start)[i + 1]; ++e) {
+                    const float* o = WF(topar) + 7 * CI(child_list)[e];
+                    a_pc += ld3(o);
+                    a_rc += ldq(o + 3);
+                }
+                const v3 pj = ld3(WF(xsj) + 7 * i);
+                const q4 rj = ldq(WF(xsj) + 7 * i + 3);
+                v3 a_pj = ld3(WF(axsj) + 7 * i) + a_pc;
+                q4 a_rj = ldq(WF(axsj) + 7 * i + 3);
+                const v3 axis = ld3(CF(axis) + 3 * i);
+                const float* q = WF(q);
+                float* aq = WF(aq);
+                if (type == DSIM_JOINT_PRISMATIC) {
+                    // pc = pj + rotate(rj, axis) q ; rc = rj
+                    const v3 u = rotate(rj, axis);
+                    aq[cs] += dot(u, a_pc);
+                    a_rj += rotate_adj_q(rj, axis, a_pc * q[cs]);
+                    a_rj += a_rc;
+                } else if (type == DSIM_JOINT_REVOLUTE) {
+                    const q4 rjc = quat_axis_angle(axis, q[cs]);
+                    aq[cs] += quat_axis_angle_adj(axis, q[cs], qmul_adj_b(rj, a_rc));
+                    a_rj += qmul_adj_a(rjc, a_rc);
+                } else if (type == DSIM_JOINT_BALL) {
+                    const q4 rjc = ldq(q + cs);
+                    addq(aq + cs, qmul_adj_b(rj, a_rc));
+                    a_rj += qmul_adj_a(rjc, a_rc);
+                } else if (type == DSIM_JOINT_FREE) {
+                    const v3 pjc = ld3(q + cs);
+                    const q4 rjc = ldq(q + cs + 3);
+                    add3(aq + cs, rotate_inv(rj, a_pc));
+                    addq(aq + cs + 3, qmul_adj_b(rj, a_rc));
+                    a_rj += rotate_adj_q(rj, pjc, a_pc);
+                    a_rj += qmul_adj_a(rjc, a_rc);
+                } else {
+                    a_rj += a_rc;
+                }
+                (void)pj;
+                if (par >= 0) {
+                    const q4 rsp = ldq(WF(xsc) + 7 * par + 3);
+                    const v3 ppj = ld3(CF(xpj) + 7 * i);
+                    const q4 rpj = ldq(CF(xpj) + 7 * i + 3);
+                    float* o = WF(topar) + 7 * i;
+                    st3(o, a_pj);
+                    stq(o + 3, rotate_adj_q(rsp, ppj, a_pj) + qmul_adj_a(rpj, a_rj));
+                }
+            }
+        });
+    }
+}
+
+template <class Exec> DSIM_FN void dsim_bwd_substep(const DsimCtx& c, Exec& ex, bool update_mass) {
+    dsim_bwd_joint_space(c, ex);
+    dsim_bwd_external(c, ex);
+    if (update_mass) dsim_bwd_mass(c, ex);
+    dsim_bwd_bodies(c, ex, update_mass);
+}
+
+// Reverse sweep of one env.step().  g_ckpt is this environment's [substeps][nq+nd] checkpoint.
+template <class Exec>
+DSIM_FN void dsim_env_step_backward(const DsimCtx& c, Exec& ex, int substeps, int mm_freq, const float* g_ckpt,
+                                    const float* g_act, const float* g_mact, const float* g_gq_out,
+                                    const float* g_gqd_out, float* g_gq_in, float* g_gqd_in, float* g_gact,
+                                    float* g_gmact) {
+    const int nq = c.d.nq, nd = c.d.nd, M = c.d.M;
+    ex.run([&](int lane) {
+        for (int k = lane; k < nq; k += DSIM_NL) WF(aqn)[k] = g_gq_out[k];
+        for (int k = lane; k < nd; k += DSIM_NL) {
+            WF(aqdn)[k] = g_gqd_out[k];
+            WF(act)[k] = g_act[k];
+            WF(aact)[k] = 0.f;
+        }
+        for (int k = lane; k < M; k += DSIM_NL) {
+            WF(mact)[k] = g_mact[k];
+            WF(amact)[k] = 0.f;
+        }
+    });
+    const int groups = (substeps + mm_freq - 1) / mm_freq;
+    for (int g = groups - 1; g >= 0; --g) {
+        const int s0 = g * mm_freq, s1 = (s0 + mm_freq < substeps) ? s0 + mm_freq : substeps;
+        // the factor this group of substeps used: rebuild it from the state at s0
+        {
+            const float* ck = g_ckpt + (size_t)s0 * (nq + nd);
+            ex.run([&](int lane) {
+                for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = ck[k];
+                for (int k = lane; k < nd; k += DSIM_NL) WF(qd)[k] = ck[nq + k];
+                for (int k = lane; k < nd * nd; k += DSIM_NL) WF(aH)[k] = 0.f;
+            });
+            dsim_fwd_kinematics(c, ex);
+            dsim_fwd_mass(c, ex);
+        }
+        for (int s = s1 - 1; s >= s0; --s) {
+            const float* ck = g_ckpt + (size_t)s * (nq + nd);
+            ex.run([&](int lane) {
+                for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = ck[k];
+                for (int k = lane; k < nd; k += DSIM_NL) WF(qd)[k] = ck[nq + k];
+            });
+            dsim_fwd_kinematics(c, ex);
+            dsim_fwd_external(c, ex);
+            dsim_fwd_tau(c, ex);
+            if (s == s0) dsim_fwd_composite(c, ex);
+            dsim_fwd_solve(c, ex);
+            dsim_bwd_substep(c, ex, s == s0);
+            ex.run([&](int lane) {
+                for (int k = lane; k < nq; k += DSIM_NL) WF(aqn)[k] = WF(aq)[k];
+                for (int k = lane; k < nd; k += DSIM_NL) WF(aqdn)[k] = WF(aqd)[k];
+            });
+        }
+    }
+    ex.run([&](int lane) {
+        for (int k = lane; k < nq; k += DSIM_NL) g_gq_in[k] = WF(aqn)[k];
+        for (int k = lane; k < nd; k += DSIM_NL) {
+            g_gqd_in[k] = WF(aqdn)[k];
+            if (g_gact) g_gact[k] = WF(aact)[k];
+        }
+        if (g_gmact)
+            for (int k = lane; k < M; k += DSIM_NL) g_gmact[k] = WF(amact)[k];
+    });
+}

@@ -1,0 +1,216 @@
+// dsim_hip.hip -- gfx950 kernels + the C ABI of include/dsim.h.
+//
+// Mapping: ONE environment per workgroup, ONE wavefront (64 lanes) per workgroup.  The articulation
+// template (a few KB) is copied from global memory into LDS once per launch, the environment's state
+// row is loaded with one coalesced read per tensor, all `substeps` substeps run out of LDS, and only
+// (q, qd) [+ the per-substep checkpoint when gradients are wanted] go back to HBM.  N=1024
+// environments therefore put exactly one wave on each of the 1024 SIMDs of an MI355X; larger N
+// stacks waves per SIMD (LDS per workgroup: Ant 8.6 KB fwd / 15 KB bwd) and hides LDS/VALU latency.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC dsim_hip.hip -o libdsim_hip.so
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <string>
+
+#define DSIM_FN __device__ __forceinline__
+#include "dsim_core.hpp"
+
+namespace {
+
+struct DevExec {
+    template <class F> __device__ __forceinline__ void run(F&& f) {
+        f((int)threadIdx.x);
+        __syncthreads();
+    }
+};
+
+struct KCommon {
+    DsimOff o;
+    DsimDims d;
+    const uint32_t* cblob;
+    float h;
+    int substeps, mm_freq, n_envs;
+};
+
+__device__ __forceinline__ void load_constants(float* lds, const KCommon& k) {
+    uint32_t* l = reinterpret_cast<uint32_t*>(lds);
+    for (int i = threadIdx.x; i < k.o.const_words; i += DSIM_NL) l[i] = k.cblob[i];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(DSIM_NL) void dsim_fwd_kernel(KCommon k, const float* __restrict__ q_in,
+                                                           const float* __restrict__ qd_in,
+                                                           const float* __restrict__ act,
+                                                           const float* __restrict__ mact, float* q_out,
+                                                           float* qd_out, float* ckpt) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int e = blockIdx.x;
+    if (e >= k.n_envs) return;
+    load_constants(lds, k);
+    DsimCtx c;
+    c.s = lds;
+    c.o = k.o;
+    c.d = k.d;
+    c.h = k.h;
+    DevExec ex;
+    const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
+    dsim_env_step_forward(c, ex, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, act + e * nd,
+                          M ? mact + e * M : nullptr, q_out + e * nq, qd_out + e * nd,
+                          ckpt ? ckpt + (size_t)e * k.substeps * (nq + nd) : nullptr);
+}
+
+__global__ __launch_bounds__(DSIM_NL) void dsim_bwd_kernel(KCommon k, const float* __restrict__ ckpt,
+                                                           const float* __restrict__ act,
+                                                           const float* __restrict__ mact,
+                                                           const float* __restrict__ gq_out,
+                                                           const float* __restrict__ gqd_out, float* gq_in,
+                                                           float* gqd_in, float* gact, float* gmact) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int e = blockIdx.x;
+    if (e >= k.n_envs) return;
+    load_constants(lds, k);
+    DsimCtx c;
+    c.s = lds;
+    c.o = k.o;
+    c.d = k.d;
+    c.h = k.h;
+    DevExec ex;
+    const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
+    dsim_env_step_backward(c, ex, k.substeps, k.mm_freq, ckpt + (size_t)e * k.substeps * (nq + nd), act + e * nd,
+                           M ? mact + e * M : nullptr, gq_out + e * nq, gqd_out + e * nd, gq_in + e * nq,
+                           gqd_in + e * nd, gact ? gact + e * nd : nullptr, (gmact && M) ? gmact + e * M : nullptr);
+}
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return DSIM_ERR_HIP;
+}
+
+}  // namespace
+
+struct dsim_model {
+    DsimLayout lay;
+    uint32_t* d_cblob = nullptr;
+    int max_lds_bytes = 0;
+};
+
+extern "C" {
+
+const char* dsim_last_error(void) { return g_err.c_str(); }
+int dsim_version(void) { return 100; }
+
+int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
+    if (!desc || !out) return fail(DSIM_ERR_INVALID, "null argument");
+    dsim_model* m = new (std::nothrow) dsim_model();
+    if (!m) return fail(DSIM_ERR_INVALID, "out of host memory");
+    std::string err = dsim_build_layout(*desc, m->lay);
+    if (!err.empty()) {
+        delete m;
+        return fail(DSIM_ERR_INVALID, err);
+    }
+    const int bytes = m->lay.o.total_words * 4;
+    if (bytes > 160 * 1024) {
+        delete m;
+        return fail(DSIM_ERR_LIMIT, "model needs more than 160 KiB of LDS per environment");
+    }
+    hipError_t e = hipMalloc(&m->d_cblob, sizeof(uint32_t) * m->lay.cblob.size());
+    if (e != hipSuccess) {
+        delete m;
+        return hip_fail(e, "hipMalloc(model constants)");
+    }
+    e = hipMemcpy(m->d_cblob, m->lay.cblob.data(), sizeof(uint32_t) * m->lay.cblob.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(m->d_cblob);
+        delete m;
+        return hip_fail(e, "hipMemcpy(model constants)");
+    }
+    if (bytes > 64 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsim_bwd_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) {
+            hipFree(m->d_cblob);
+            delete m;
+            return hip_fail(e, "hipFuncSetAttribute(bwd LDS)");
+        }
+    }
+    if (m->lay.o.fwd_words * 4 > 64 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsim_fwd_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, m->lay.o.fwd_words * 4);
+        if (e != hipSuccess) {
+            hipFree(m->d_cblob);
+            delete m;
+            return hip_fail(e, "hipFuncSetAttribute(fwd LDS)");
+        }
+    }
+    *out = m;
+    return DSIM_OK;
+}
+
+int dsim_model_destroy(dsim_model* m) {
+    if (!m) return DSIM_OK;
+    if (m->d_cblob) hipFree(m->d_cblob);
+    delete m;
+    return DSIM_OK;
+}
+
+int64_t dsim_ckpt_floats(const dsim_model* m, int substeps) {
+    if (!m || substeps <= 0) return 0;
+    return (int64_t)substeps * (m->lay.d.nq + m->lay.d.nd);
+}
+
+static int make_common(const dsim_model* m, int n_envs, float dt, int substeps, int mm_freq, KCommon& k) {
+    if (!m) return fail(DSIM_ERR_INVALID, "null model");
+    if (n_envs <= 0) return fail(DSIM_ERR_INVALID, "n_envs must be positive");
+    if (substeps <= 0 || mm_freq <= 0) return fail(DSIM_ERR_INVALID, "substeps and mm_freq must be positive");
+    if (!(dt > 0.f)) return fail(DSIM_ERR_INVALID, "dt must be positive");
+    k.o = m->lay.o;
+    k.d = m->lay.d;
+    k.cblob = m->d_cblob;
+    k.h = dt / float(substeps);
+    k.substeps = substeps;
+    k.mm_freq = mm_freq;
+    k.n_envs = n_envs;
+    return DSIM_OK;
+}
+
+int dsim_step_forward(const dsim_model* m, int n_envs, const float* q_in, const float* qd_in, const float* act,
+                      const float* muscle_act, float dt, int substeps, int mm_freq, float* q_out, float* qd_out,
+                      float* ckpt, void* hip_stream) {
+    KCommon k;
+    int rc = make_common(m, n_envs, dt, substeps, mm_freq, k);
+    if (rc) return rc;
+    if (!q_in || !qd_in || !act || !q_out || !qd_out) return fail(DSIM_ERR_INVALID, "null state pointer");
+    if (k.d.M > 0 && !muscle_act) return fail(DSIM_ERR_INVALID, "model has muscles but muscle_act is null");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipLaunchKernelGGL(dsim_fwd_kernel, dim3(n_envs), dim3(DSIM_NL), (size_t)k.o.fwd_words * 4, st, k, q_in, qd_in, act,
+                       muscle_act, q_out, qd_out, ckpt);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch dsim_fwd_kernel");
+    return DSIM_OK;
+}
+
+int dsim_step_backward(const dsim_model* m, int n_envs, const float* ckpt, const float* act, const float* muscle_act,
+                       float dt, int substeps, int mm_freq, const float* gq_out, const float* gqd_out, float* gq_in,
+                       float* gqd_in, float* gact, float* gmuscle_act, void* hip_stream) {
+    KCommon k;
+    int rc = make_common(m, n_envs, dt, substeps, mm_freq, k);
+    if (rc) return rc;
+    if (!ckpt || !act || !gq_out || !gqd_out || !gq_in || !gqd_in)
+        return fail(DSIM_ERR_INVALID, "null pointer (ckpt/act/grad)");
+    if (k.d.M > 0 && !muscle_act) return fail(DSIM_ERR_INVALID, "model has muscles but muscle_act is null");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipLaunchKernelGGL(dsim_bwd_kernel, dim3(n_envs), dim3(DSIM_NL), (size_t)k.o.total_words * 4, st, k, ckpt, act,
+                       muscle_act, gq_out, gqd_out, gq_in, gqd_in, gact, gmuscle_act);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch dsim_bwd_kernel");
+    return DSIM_OK;
+}
+
+}  // extern "C"

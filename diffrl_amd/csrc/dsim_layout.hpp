@@ -1,0 +1,255 @@
+// dsim_layout.hpp -- host-side analysis of one articulation template and the LDS image layout.
+//
+// `dsim_model_create` (include/dsim.h) turns the reference-style flat model arrays
+// (dflex/dflex/model.py:1646-1879) into ONE packed constant block that every workgroup copies into
+// LDS at kernel start, followed by the per-environment work arrays.  All offsets are in 32-bit
+// words from the start of the workgroup's dynamic LDS segment and are passed to the kernels by
+// value (they live in SGPRs).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/dsim.h"
+
+struct DsimDims {
+    int L, nq, nd, C, M, W, NS, D;  // links, coords, dofs, contacts, muscles, waypoints, active muscle segments, tree levels
+};
+
+struct DsimOff {
+    // ---- constant block: ints
+    int jtype, parent, qstart, qdstart, lvl_start, lvl_links, dof_link;
+    int anc_start, anc_list;    // ancestors-or-self of link i, root first
+    int sub_start, sub_list;    // subtree of link i (self first, then descendants ascending)
+    int child_start, child_list;
+    int cb_start, cb_list;      // contacts of body i
+    int rel;                    // [nd*nd] 0 unrelated, 1: link(b) in subtree(link(a)), 2: link(a) strictly below link(b)
+    int cbody;
+    int seg_wp, seg_m;          // active muscle segment -> first waypoint index / muscle index
+    int ml_start, ml_list;      // link -> list of (segment*2 + side)
+    int ms_start;               // muscle -> [first, last) active segment
+    int mlinks;
+    // ---- constant block: floats
+    int xpj, com, axis, ic6, mass, tke, tkd, lke, lkd, target, lower, upper, arm;
+    int cpoint, cdist, cmat, grav, mpoints;
+    int const_words;
+    // ---- forward work arrays (floats)
+    int q, qd, act, mact, xsj, xsc, pm, S, vj, v, a, i10, f, ftot, cw, tau, qdd, ic10, F, hinv, prow, pcol, mus;
+    int fwd_words;
+    // ---- adjoint work arrays (floats)
+    int aq, aqd, aqn, aqdn, aact, amact, aqdd, atau, aS, aftot, af, acx, axsc, axsj, ac, av, aa, aatot, avtot, avj,
+        ai10, ai10m, aic10, aH, topar, amus;
+    int total_words;
+};
+
+struct DsimLayout {
+    DsimDims d;
+    DsimOff o;
+    std::vector<uint32_t> cblob;  // const_words words
+};
+
+namespace dsim_detail {
+inline uint32_t f2u(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+}  // namespace dsim_detail
+
+// Returns "" on success, otherwise an error description.
+inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) {
+    using dsim_detail::f2u;
+    const int L = m.n_links, nq = m.n_q, nd = m.n_qd, C = m.n_contacts, M = m.n_muscles, W = m.n_waypoints;
+    if (L <= 0 || L > 64) return "n_links must be in [1,64]";
+    if (nd <= 0 || nd > 64) return "n_qd must be in [1,64]";
+    if (nq <= 0 || nq > 96) return "n_q must be in [1,96]";
+    if (C < 0 || M < 0 || W < 0) return "negative count";
+    if (m.joint_q_start[L] != nq || m.joint_qd_start[L] != nd) return "joint_q_start/joint_qd_start sentinel mismatch";
+    std::vector<int> level(L), dof_link(nd, -1);
+    int D = 0;
+    for (int i = 0; i < L; ++i) {
+        int p = m.joint_parent[i];
+        if (p >= i || p < -1) return "joint_parent must precede child";
+        level[i] = p < 0 ? 0 : level[p] + 1;
+        if (level[i] + 1 > D) D = level[i] + 1;
+        int t = m.joint_type[i];
+        int ncoord = m.joint_q_start[i + 1] - m.joint_q_start[i], ndof = m.joint_qd_start[i + 1] - m.joint_qd_start[i];
+        static const int ec[5] = {1, 1, 4, 0, 7}, ed[5] = {1, 1, 3, 0, 6};
+        if (t < 0 || t > 4) return "unknown joint type";
+        if (ncoord != ec[t] || ndof != ed[t]) return "joint coordinate/dof count does not match its type";
+        for (int d = m.joint_qd_start[i]; d < m.joint_qd_start[i + 1]; ++d) dof_link[d] = i;
+        // I_m must be diag(Ic (symmetric), m*1): that is what ModelBuilder.finalize produces (util.py:340-349)
+        const float* I = m.body_I_m + 36 * i;
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) {
+                bool offblock = (r < 3) != (c < 3);
+                if (offblock && I[6 * r + c] != 0.f) return "body_I_m must be block diagonal";
+                if (r >= 3 && c >= 3 && r != c && I[6 * r + c] != 0.f) return "body_I_m mass block must be m*identity";
+            }
+        if (I[21] != I[28] || I[21] != I[35]) return "body_I_m mass block must be m*identity";
+        if (I[1] != I[6] || I[2] != I[12] || I[8] != I[13]) return "body_I_m rotational block must be symmetric";
+        const float* xc = m.joint_X_cm + 7 * i;
+        if (xc[3] != 0.f || xc[4] != 0.f || xc[5] != 0.f || xc[6] != 1.f) return "joint_X_cm rotation must be identity";
+    }
+    for (int c = 0; c < C; ++c)
+        if (m.contact_body[c] < 0 || m.contact_body[c] >= L) return "contact_body out of range";
+    for (int w = 0; w < W; ++w)
+        if (m.muscle_links[w] < 0 || m.muscle_links[w] >= L) return "muscle_links out of range";
+    if (M > 0 && (m.muscle_start[0] != 0 || m.muscle_start[M] != W)) return "muscle_start must span the waypoints";
+
+    // ---- tree tables
+    std::vector<int> lvl_start(D + 1, 0), lvl_links;
+    for (int lv = 0; lv < D; ++lv) {
+        lvl_start[lv] = (int)lvl_links.size();
+        for (int i = 0; i < L; ++i)
+            if (level[i] == lv) lvl_links.push_back(i);
+    }
+    lvl_start[D] = (int)lvl_links.size();
+    std::vector<int> anc_start(L + 1, 0), anc_list, sub_start(L + 1, 0), sub_list, child_start(L + 1, 0), child_list;
+    std::vector<std::vector<int>> anc(L), sub(L), child(L);
+    for (int i = 0; i < L; ++i) {
+        std::vector<int> chain;
+        for (int j = i; j != -1; j = m.joint_parent[j]) chain.push_back(j);
+        anc[i].assign(chain.rbegin(), chain.rend());
+        for (int j : chain) sub[j].push_back(i);  // ascending in i because i ascends
+        if (m.joint_parent[i] >= 0) child[m.joint_parent[i]].push_back(i);
+    }
+    auto flatten = [](const std::vector<std::vector<int>>& v, std::vector<int>& start, std::vector<int>& list) {
+        for (size_t i = 0; i < v.size(); ++i) {
+            start[i] = (int)list.size();
+            list.insert(list.end(), v[i].begin(), v[i].end());
+        }
+        start[v.size()] = (int)list.size();
+    };
+    flatten(anc, anc_start, anc_list);
+    flatten(sub, sub_start, sub_list);
+    flatten(child, child_start, child_list);
+    std::vector<std::vector<int>> cb(L);
+    for (int c = 0; c < C; ++c) cb[m.contact_body[c]].push_back(c);
+    std::vector<int> cb_start(L + 1, 0), cb_list;
+    flatten(cb, cb_start, cb_list);
+    auto in_subtree = [&](int a, int b) {  // is b in subtree(a)?
+        for (int j = b; j != -1; j = m.joint_parent[j])
+            if (j == a) return true;
+        return false;
+    };
+    std::vector<int> rel(nd * nd, 0);
+    for (int a = 0; a < nd; ++a)
+        for (int b = 0; b < nd; ++b) {
+            int la = dof_link[a], lb = dof_link[b];
+            if (in_subtree(la, lb)) rel[a * nd + b] = 1;
+            else if (in_subtree(lb, la)) rel[a * nd + b] = 2;
+        }
+    // ---- muscles: active segments (consecutive waypoints on different links, sim.py:1219-1223)
+    std::vector<int> seg_wp, seg_m, ms_start(M + 1, 0);
+    for (int mi = 0; mi < M; ++mi) {
+        ms_start[mi] = (int)seg_wp.size();
+        for (int w = m.muscle_start[mi]; w < m.muscle_start[mi + 1] - 1; ++w)
+            if (m.muscle_links[w] != m.muscle_links[w + 1]) {
+                seg_wp.push_back(w);
+                seg_m.push_back(mi);
+            }
+    }
+    ms_start[M] = (int)seg_wp.size();
+    const int NS = (int)seg_wp.size();
+    std::vector<std::vector<int>> ml(L);
+    for (int s = 0; s < NS; ++s) {
+        ml[m.muscle_links[seg_wp[s]]].push_back(2 * s + 0);
+        ml[m.muscle_links[seg_wp[s] + 1]].push_back(2 * s + 1);
+    }
+    std::vector<int> ml_start(L + 1, 0), ml_list;
+    flatten(ml, ml_start, ml_list);
+
+    DsimOff o;
+    memset(&o, 0, sizeof(o));
+    std::vector<uint32_t>& blob = out.cblob;
+    blob.clear();
+    auto put_i = [&](const int* p, size_t n) {
+        int off = (int)blob.size();
+        for (size_t k = 0; k < n; ++k) blob.push_back((uint32_t)p[k]);
+        return off;
+    };
+    auto put_f = [&](const float* p, size_t n) {
+        int off = (int)blob.size();
+        for (size_t k = 0; k < n; ++k) blob.push_back(f2u(p[k]));
+        return off;
+    };
+    o.jtype = put_i(m.joint_type, L);
+    o.parent = put_i(m.joint_parent, L);
+    o.qstart = put_i(m.joint_q_start, L + 1);
+    o.qdstart = put_i(m.joint_qd_start, L + 1);
+    o.lvl_start = put_i(lvl_start.data(), D + 1);
+    o.lvl_links = put_i(lvl_links.data(), L);
+    o.dof_link = put_i(dof_link.data(), nd);
+    o.anc_start = put_i(anc_start.data(), L + 1);
+    o.anc_list = put_i(anc_list.data(), anc_list.size());
+    o.sub_start = put_i(sub_start.data(), L + 1);
+    o.sub_list = put_i(sub_list.data(), sub_list.size());
+    o.child_start = put_i(child_start.data(), L + 1);
+    o.child_list = put_i(child_list.data(), child_list.size());
+    o.cb_start = put_i(cb_start.data(), L + 1);
+    o.cb_list = put_i(cb_list.data(), cb_list.size());
+    o.rel = put_i(rel.data(), rel.size());
+    o.cbody = put_i(m.contact_body, C);
+    o.seg_wp = put_i(seg_wp.data(), NS);
+    o.seg_m = put_i(seg_m.data(), NS);
+    o.ml_start = put_i(ml_start.data(), L + 1);
+    o.ml_list = put_i(ml_list.data(), ml_list.size());
+    o.ms_start = put_i(ms_start.data(), M + 1);
+    o.mlinks = put_i(m.muscle_links, W);
+    o.xpj = put_f(m.joint_X_pj, 7 * L);
+    std::vector<float> com(3 * L), ic6(6 * L), mass(L);
+    for (int i = 0; i < L; ++i) {
+        for (int k = 0; k < 3; ++k) com[3 * i + k] = m.joint_X_cm[7 * i + k];
+        const float* I = m.body_I_m + 36 * i;
+        ic6[6 * i + 0] = I[0]; ic6[6 * i + 1] = I[1]; ic6[6 * i + 2] = I[2];
+        ic6[6 * i + 3] = I[7]; ic6[6 * i + 4] = I[8]; ic6[6 * i + 5] = I[14];
+        mass[i] = I[21];
+    }
+    o.com = put_f(com.data(), com.size());
+    o.axis = put_f(m.joint_axis, 3 * L);
+    o.ic6 = put_f(ic6.data(), ic6.size());
+    o.mass = put_f(mass.data(), L);
+    o.tke = put_f(m.joint_target_ke, L);
+    o.tkd = put_f(m.joint_target_kd, L);
+    o.lke = put_f(m.joint_limit_ke, L);
+    o.lkd = put_f(m.joint_limit_kd, L);
+    o.target = put_f(m.joint_target, nq);
+    o.lower = put_f(m.joint_limit_lower, nq);
+    o.upper = put_f(m.joint_limit_upper, nq);
+    o.arm = put_f(m.joint_armature, nd);
+    o.cpoint = put_f(m.contact_point, 3 * C);
+    o.cdist = put_f(m.contact_dist, C);
+    o.cmat = put_f(m.contact_material, 4 * C);
+    o.grav = put_f(m.gravity, 3);
+    o.mpoints = put_f(m.muscle_points, 3 * W);
+    while (blob.size() % 4) blob.push_back(0);
+    o.const_words = (int)blob.size();
+
+    int cur = o.const_words;
+    auto take = [&](int n) {
+        int off = cur;
+        cur += (n + 3) & ~3;
+        return off;
+    };
+    o.q = take(nq); o.qd = take(nd); o.act = take(nd); o.mact = take(M);
+    o.xsj = take(7 * L); o.xsc = take(7 * L); o.pm = take(3 * L); o.S = take(6 * nd);
+    o.vj = take(6 * L); o.v = take(6 * L); o.a = take(6 * L); o.i10 = take(10 * L);
+    o.f = take(6 * L); o.ftot = take(6 * L); o.cw = take(6 * C); o.tau = take(nd); o.qdd = take(nd);
+    o.ic10 = take(10 * L); o.F = take(6 * nd); o.hinv = take(nd * nd); o.prow = take(nd); o.pcol = take(nd);
+    o.mus = take(9 * NS);
+    o.fwd_words = cur;
+    o.aq = take(nq); o.aqd = take(nd); o.aqn = take(nq); o.aqdn = take(nd); o.aact = take(nd); o.amact = take(M);
+    o.aqdd = take(nd); o.atau = take(nd); o.aS = take(6 * nd); o.aftot = take(6 * L); o.af = take(6 * L);
+    o.acx = take(13 * C); o.axsc = take(7 * L); o.axsj = take(7 * L); o.ac = take(3 * L);
+    o.av = take(6 * L); o.aa = take(6 * L); o.aatot = take(6 * L); o.avtot = take(6 * L); o.avj = take(6 * L);
+    o.ai10 = take(10 * L); o.ai10m = take(10 * L); o.aic10 = take(10 * L); o.aH = take(nd * nd);
+    o.topar = take(7 * L); o.amus = take(15 * NS);
+    o.total_words = cur;
+
+    out.o = o;
+    out.d = DsimDims{L, nq, nd, C, M, W, NS, D};
+    return "";
+}

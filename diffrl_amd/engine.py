@@ -1,0 +1,116 @@
+"""Torch-facing wrapper of the HIP library: device memory + stream plumbing and the autograd node.
+
+`SimStep` replaces `dflex.sim.SimulateFunc` (dflex/dflex/sim.py:2086-2154): one autograd node per
+env.step(); forward = one fused kernel launch over all substeps, backward = one fused adjoint launch.
+"""
+import ctypes as C
+
+import torch
+
+from . import capi
+from .template import ArticulationTemplate
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Engine:
+    """Owns the device copy of one articulation template on one GPU."""
+
+    def __init__(self, template: ArticulationTemplate, device):
+        self.template = template
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise capi.DsimError("diffrl_amd runs on MI355X only (device=%s); there is no CPU path" % device)
+        self._lib = capi.lib()
+        self._desc, self._keep = capi.make_desc(template)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            capi.check(self._lib.dsim_model_create(C.byref(self._desc), C.byref(h)))
+        self._h = h
+        self.n_q, self.n_qd, self.n_muscles = template.n_q, template.n_qd, template.n_muscles
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.dsim_model_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _check(self, t, cols, name):
+        if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+            raise capi.DsimError("%s must be a contiguous float32 tensor on %s" % (name, self.device))
+        if t.numel() % max(cols, 1) != 0:
+            raise capi.DsimError("%s has %d elements, not a multiple of %d" % (name, t.numel(), cols))
+
+    def forward(self, q, qd, act, mact, dt, substeps, mm_freq, need_ckpt):
+        self._check(q, self.n_q, "joint_q")
+        self._check(qd, self.n_qd, "joint_qd")
+        self._check(act, self.n_qd, "joint_act")
+        n = q.numel() // self.n_q
+        if qd.numel() != n * self.n_qd or act.numel() != n * self.n_qd:
+            raise capi.DsimError("state tensors disagree on the number of environments")
+        if self.n_muscles:
+            self._check(mact, self.n_muscles, "muscle_activation")
+            if mact.numel() != n * self.n_muscles:
+                raise capi.DsimError("muscle_activation has the wrong size")
+        q_out = torch.empty_like(q)
+        qd_out = torch.empty_like(qd)
+        ckpt = None
+        if need_ckpt:
+            ckpt = torch.empty((n, substeps, self.n_q + self.n_qd), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            capi.check(self._lib.dsim_step_forward(self._h, n, _ptr(q), _ptr(qd), _ptr(act),
+                                                   _ptr(mact) if self.n_muscles else None, C.c_float(dt), substeps,
+                                                   mm_freq, _ptr(q_out), _ptr(qd_out), _ptr(ckpt), st))
+        return q_out, qd_out, ckpt
+
+    def backward(self, ckpt, act, mact, dt, substeps, mm_freq, gq_out, gqd_out):
+        n = ckpt.shape[0]
+        gq_out = gq_out.contiguous()
+        gqd_out = gqd_out.contiguous()
+        gq = torch.empty(n * self.n_q, dtype=torch.float32, device=self.device)
+        gqd = torch.empty(n * self.n_qd, dtype=torch.float32, device=self.device)
+        gact = torch.empty(n * self.n_qd, dtype=torch.float32, device=self.device)
+        gm = torch.empty(n * self.n_muscles, dtype=torch.float32, device=self.device) if self.n_muscles else None
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            capi.check(self._lib.dsim_step_backward(self._h, n, _ptr(ckpt), _ptr(act),
+                                                    _ptr(mact) if self.n_muscles else None, C.c_float(dt), substeps,
+                                                    mm_freq, _ptr(gq_out), _ptr(gqd_out), _ptr(gq), _ptr(gqd),
+                                                    _ptr(gact), _ptr(gm), st))
+        return gq, gqd, gact, gm
+
+
+class SimStep(torch.autograd.Function):
+    """(joint_q, joint_qd, joint_act, muscle_activation) -> (joint_q', joint_qd') for one env.step()."""
+
+    @staticmethod
+    def forward(ctx, engine, dt, substeps, mm_freq, q, qd, act, mact):
+        q, qd, act = q.contiguous(), qd.contiguous(), act.contiguous()
+        mact = mact.contiguous() if mact is not None else None
+        need = any(t is not None and t.requires_grad for t in (q, qd, act, mact))
+        q_out, qd_out, ckpt = engine.forward(q.detach(), qd.detach(), act.detach(),
+                                             mact.detach() if mact is not None else None, dt, substeps, mm_freq, need)
+        ctx.engine, ctx.dt, ctx.substeps, ctx.mm_freq = engine, dt, substeps, mm_freq
+        ctx.has_mact = mact is not None
+        ctx.shapes = (q.shape, qd.shape, act.shape, mact.shape if mact is not None else None)
+        if need:
+            ctx.save_for_backward(ckpt, act.detach(), mact.detach() if mact is not None else act.new_empty(0))
+        return q_out.view(q.shape), qd_out.view(qd.shape)
+
+    @staticmethod
+    def backward(ctx, gq_out, gqd_out):
+        ckpt, act, mact = ctx.saved_tensors
+        e = ctx.engine
+        if gq_out is None:
+            gq_out = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=ckpt.device)
+        if gqd_out is None:
+            gqd_out = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=ckpt.device)
+        gq, gqd, gact, gm = e.backward(ckpt, act, mact if ctx.has_mact else None, ctx.dt, ctx.substeps, ctx.mm_freq,
+                                       gq_out, gqd_out)
+        return (None, None, None, None, gq.view(ctx.shapes[0]), gqd.view(ctx.shapes[1]), gact.view(ctx.shapes[2]),
+                gm.view(ctx.shapes[3]) if ctx.has_mact else None)

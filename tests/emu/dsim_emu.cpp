@@ -1,0 +1,99 @@
+// dsim_emu.cpp -- TEST-ONLY harness: runs the kernel phase code of diffrl_amd/csrc/dsim_core.hpp with a
+// lane-serial executor on the host so that the phase logic (indexing, adjoint algebra) can be
+// unit-tested in the GPU-less build container.  It is NOT a CPU fallback: nothing in diffrl_amd/
+// loads it, and it is built only by tests/emu/Makefile.  The GPU tests (-m gpu) exercise the real
+// HIP kernels through the C ABI.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define DSIM_FN static inline
+#include "../../diffrl_amd/csrc/dsim_core.hpp"
+
+struct HostExec {
+    template <class F> void run(F&& f) {
+        for (int lane = 0; lane < DSIM_NL; ++lane) f(lane);
+    }
+};
+
+static void make_ctx(const DsimLayout& lay, std::vector<float>& lds, DsimCtx& c, float h) {
+    lds.assign(lay.o.total_words, 0.f);
+    memcpy(lds.data(), lay.cblob.data(), sizeof(uint32_t) * lay.o.const_words);
+    c.s = lds.data();
+    c.o = lay.o;
+    c.d = lay.d;
+    c.h = h;
+}
+
+extern "C" {
+
+int dsim_emu_layout(const dsim_model_desc* m, int* off_out, int n_off, int* dims_out) {
+    DsimLayout lay;
+    std::string err = dsim_build_layout(*m, lay);
+    if (!err.empty()) return -1;
+    const int n = (int)(sizeof(DsimOff) / sizeof(int));
+    if (n_off < n) return n;
+    memcpy(off_out, &lay.o, sizeof(DsimOff));
+    memcpy(dims_out, &lay.d, sizeof(DsimDims));
+    return n;
+}
+
+// one substep (with mass-matrix refresh) for ONE env; returns the LDS image for inspection
+int dsim_emu_substep_image(const dsim_model_desc* m, const float* q, const float* qd, const float* act,
+                           const float* mact, float h, float* image) {
+    DsimLayout lay;
+    if (!dsim_build_layout(*m, lay).empty()) return -1;
+    std::vector<float> lds;
+    DsimCtx c;
+    make_ctx(lay, lds, c, h);
+    memcpy(lds.data() + lay.o.q, q, 4 * lay.d.nq);
+    memcpy(lds.data() + lay.o.qd, qd, 4 * lay.d.nd);
+    memcpy(lds.data() + lay.o.act, act, 4 * lay.d.nd);
+    if (lay.d.M) memcpy(lds.data() + lay.o.mact, mact, 4 * lay.d.M);
+    HostExec ex;
+    dsim_fwd_kinematics(c, ex);
+    dsim_fwd_external(c, ex);
+    dsim_fwd_tau(c, ex);
+    dsim_fwd_mass(c, ex);
+    dsim_fwd_solve(c, ex);
+    memcpy(image, lds.data(), 4 * lay.o.total_words);
+    return 0;
+}
+
+int dsim_emu_step_forward(const dsim_model_desc* m, int n_envs, const float* q_in, const float* qd_in,
+                          const float* act, const float* mact, float dt, int substeps, int mm_freq, float* q_out,
+                          float* qd_out, float* ckpt) {
+    DsimLayout lay;
+    if (!dsim_build_layout(*m, lay).empty()) return -1;
+    const int nq = lay.d.nq, nd = lay.d.nd, M = lay.d.M;
+    HostExec ex;
+    for (int e = 0; e < n_envs; ++e) {
+        std::vector<float> lds;
+        DsimCtx c;
+        make_ctx(lay, lds, c, dt / float(substeps));
+        dsim_env_step_forward(c, ex, substeps, mm_freq, q_in + (size_t)e * nq, qd_in + (size_t)e * nd,
+                              act + (size_t)e * nd, M ? mact + (size_t)e * M : nullptr, q_out + (size_t)e * nq,
+                              qd_out + (size_t)e * nd, ckpt ? ckpt + (size_t)e * substeps * (nq + nd) : nullptr);
+    }
+    return 0;
+}
+}
+
+extern "C" int dsim_emu_step_backward(const dsim_model_desc* m, int n_envs, const float* ckpt, const float* act,
+                                      const float* mact, float dt, int substeps, int mm_freq, const float* gq_out,
+                                      const float* gqd_out, float* gq_in, float* gqd_in, float* gact, float* gmact) {
+    DsimLayout lay;
+    if (!dsim_build_layout(*m, lay).empty()) return -1;
+    const int nq = lay.d.nq, nd = lay.d.nd, M = lay.d.M;
+    HostExec ex;
+    for (int e = 0; e < n_envs; ++e) {
+        std::vector<float> lds;
+        DsimCtx c;
+        make_ctx(lay, lds, c, dt / float(substeps));
+        dsim_env_step_backward(c, ex, substeps, mm_freq, ckpt + (size_t)e * substeps * (nq + nd), act + (size_t)e * nd,
+                               M ? mact + (size_t)e * M : nullptr, gq_out + (size_t)e * nq, gqd_out + (size_t)e * nd,
+                               gq_in + (size_t)e * nq, gqd_in + (size_t)e * nd, gact ? gact + (size_t)e * nd : nullptr,
+                               (gmact && M) ? gmact + (size_t)e * M : nullptr);
+    }
+    return 0;
+}

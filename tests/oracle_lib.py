@@ -79,3 +79,30 @@ def oracle_backward(t, q, qd, act, mact, dt, substeps, mm_freq, gq_out, gqd_out)
             C.c_int(mm_freq), _p(gq_out), _p(gqd_out), _p(gq), _p(gqd), _p(ga), _p(gm), _p(qo), _p(qdo))
     assert rc == 0
     return dict(gq=gq, gqd=gqd, gact=ga, gmact=gm, q_out=qo, qd_out=qdo)
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def project_tangent(t, q, g):
+    """Removes from a joint_q cotangent `g` the component along each unit-quaternion coordinate block
+    (free joint q[3:7], ball joint q[0:4]).  The reference differentiates formulas that are only
+    meaningful on |quat| = 1 literally, so its gradient has a radial part that depends on how the
+    (mathematically identical) rotation formulas are written; that part is annihilated by the
+    integrator's quaternion normalisation (sim.py:1552, 1616) in every upstream propagation, see
+    DESIGN.md "Quaternion radial component"."""
+    g = np.array(g, np.float64).reshape(-1, t.n_q)
+    q = np.asarray(q, np.float64).reshape(-1, t.n_q)
+    for i in range(t.n_links):
+        ty, cs = int(t.joint_type[i]), int(t.joint_q_start[i])
+        if ty == 4:
+            sl = slice(cs + 3, cs + 7)
+        elif ty == 2:
+            sl = slice(cs, cs + 4)
+        else:
+            continue
+        u = q[:, sl] / np.linalg.norm(q[:, sl], axis=1, keepdims=True)
+        g[:, sl] -= u * (u * g[:, sl]).sum(1, keepdims=True)
+    return g

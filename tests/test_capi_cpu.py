@@ -1,0 +1,46 @@
+"""CPU-only checks of the C-ABI library: it loads and exports every symbol include/dsim.h declares.
+(No compute calls: there is no GPU in the build container and no CPU fallback in the product.)"""
+import ctypes
+import os
+import re
+
+import pytest
+
+import diffrl_amd.capi as capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "dsim.h")).read()
+    return sorted(set(re.findall(r"\b(dsim_[a-z_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert sorted(capi.EXPORTS) == _declared()
+
+
+def test_library_exports_all_symbols():
+    if not os.path.exists(capi.LIB_PATH):
+        pytest.skip("libdsim_hip.so not built yet (run __graft_entry__.build())")
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), name
+    assert lib.dsim_version() >= 100
+
+
+def test_modeldesc_matches_header_field_order():
+    src = open(os.path.join(ROOT, "include", "dsim.h")).read()
+    body = src[src.index("typedef struct dsim_model_desc {"):src.index("} dsim_model_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"\b([a-zA-Z_0-9]+)(?:\[3\])?;", body)
+    assert names == [f[0] for f in capi.ModelDesc._fields_]
+
+
+def test_engine_refuses_cpu():
+    import numpy as np
+
+    from diffrl_amd.engine import Engine
+    from oracle_lib import template_from_golden
+    with pytest.raises(capi.DsimError):
+        Engine(template_from_golden("cartpole"), "cpu")

@@ -1,0 +1,148 @@
+"""-m gpu: the real HIP kernels, through the C ABI, against (a) the golden vectors generated from the
+reference and (b) the CPU oracle on larger seeded batches.  Tolerances (stated, fp32):
+one env-step state 1e-4, one env-step gradients 1e-3 max-norm relative."""
+import numpy as np
+import pytest
+import torch
+
+from oracle_lib import golden, oracle_backward, oracle_forward, project_tangent, relerr, template_from_golden
+
+pytestmark = pytest.mark.gpu
+ENVS = ["cartpole", "ant", "humanoid", "snu"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+def _engine(env, dev):
+    from diffrl_amd.engine import Engine
+    t = template_from_golden(env)
+    return t, Engine(t, dev)
+
+
+def _run(eng, dev, q, qd, act, mact, dt, S, mm, gq, gqd):
+    tq = torch.tensor(q, device=dev).reshape(-1)
+    tqd = torch.tensor(qd, device=dev).reshape(-1)
+    ta = torch.tensor(act, device=dev).reshape(-1)
+    tm = torch.tensor(mact, device=dev).reshape(-1) if mact is not None else None
+    qo, qdo, ck = eng.forward(tq, tqd, ta, tm, dt, S, mm, True)
+    r = eng.backward(ck, ta, tm, dt, S, mm, torch.tensor(gq, device=dev).reshape(-1),
+                     torch.tensor(gqd, device=dev).reshape(-1))
+    torch.cuda.synchronize()
+    n = q.shape[0]
+    out = dict(q=qo.cpu().numpy().reshape(n, -1), qd=qdo.cpu().numpy().reshape(n, -1),
+               gq=r[0].cpu().numpy().reshape(n, -1), gqd=r[1].cpu().numpy().reshape(n, -1),
+               gact=r[2].cpu().numpy().reshape(n, -1), ckpt=ck.cpu().numpy())
+    if r[3] is not None:
+        out["gmact"] = r[3].cpu().numpy().reshape(n, -1)
+    return out
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_step_vs_reference_golden(env, dev):
+    t, eng = _engine(env, dev)
+    g = golden(env + "_step")
+    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
+    r = _run(eng, dev, g["q_in"], g["qd_in"], g["act_in"], g.get("muscle_act_in"), dt, S, mm, g["gq_out"], g["gqd_out"])
+    assert relerr(r["q"], g["q_out"]) < 1e-4
+    assert relerr(r["qd"], g["qd_out"]) < 1e-4
+    assert np.array_equal(r["ckpt"][:, 0, :t.n_q], g["q_in"])  # first checkpoint is the input state, bit-exact
+    assert relerr(project_tangent(t, g["q_in"], r["gq"]), project_tangent(t, g["q_in"], g["gq_in"])) < 1e-3
+    assert relerr(r["gqd"], g["gqd_in"]) < 1e-3
+    if "gact_in" in g:
+        assert relerr(r["gact"], g["gact_in"]) < 1e-3
+    else:
+        assert relerr(r["gmact"], g["gmuscle_act_in"]) < 1e-3
+
+
+@pytest.mark.parametrize("env,n", [("cartpole", 256), ("ant", 192), ("humanoid", 24), ("snu", 16)])
+def test_step_vs_oracle_batch(env, n, dev):
+    """seeded perturbations of the golden states; sizes the scalar oracle finishes in seconds"""
+    t, eng = _engine(env, dev)
+    g = golden(env + "_step")
+    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
+    rng = np.random.default_rng(5)
+    idx = rng.integers(0, g["q_in"].shape[0], n)
+    q = g["q_in"][idx] + rng.normal(0, 0.01, (n, t.n_q)).astype(np.float32)
+    for i in range(t.n_links):  # keep unit quaternions
+        ty, cs = int(t.joint_type[i]), int(t.joint_q_start[i])
+        sl = slice(cs + 3, cs + 7) if ty == 4 else (slice(cs, cs + 4) if ty == 2 else None)
+        if sl is not None:
+            q[:, sl] /= np.linalg.norm(q[:, sl], axis=1, keepdims=True)
+    qd = g["qd_in"][idx] + rng.normal(0, 0.05, (n, t.n_qd)).astype(np.float32)
+    act = g["act_in"][idx] * rng.uniform(0.5, 1.0, (n, 1)).astype(np.float32)
+    mact = g["muscle_act_in"][idx] * rng.uniform(0.5, 1.0, (n, 1)).astype(np.float32) if "muscle_act_in" in g else None
+    gq = rng.normal(0, 1, (n, t.n_q)).astype(np.float32)
+    gqd = rng.normal(0, 1, (n, t.n_qd)).astype(np.float32)
+    r = _run(eng, dev, q, qd, act, mact, dt, S, mm, gq, gqd)
+    o = oracle_backward(t, q, qd, act, mact, dt, S, mm, gq, gqd)
+    assert relerr(r["q"], o["q_out"]) < 1e-4
+    assert relerr(r["qd"], o["qd_out"]) < 1e-4
+    assert relerr(project_tangent(t, q, r["gq"]), project_tangent(t, q, o["gq"])) < 1e-3
+    assert relerr(r["gqd"], o["gqd"]) < 1e-3
+    if mact is None:
+        assert relerr(r["gact"], o["gact"]) < 1e-3
+    else:
+        assert relerr(r["gmact"], o["gmact"]) < 1e-3
+
+
+def test_determinism_and_inplace(dev):
+    """fixed reduction order per env: two launches are bit-identical; q_out may alias q_in"""
+    t, eng = _engine("ant", dev)
+    g = golden("ant_step")
+    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
+    q = torch.tensor(np.tile(g["q_in"], (100, 1)), device=dev).reshape(-1)
+    qd = torch.tensor(np.tile(g["qd_in"], (100, 1)), device=dev).reshape(-1)
+    a = torch.tensor(np.tile(g["act_in"], (100, 1)), device=dev).reshape(-1)
+    r1 = eng.forward(q, qd, a, None, dt, S, mm, True)
+    r2 = eng.forward(q, qd, a, None, dt, S, mm, True)
+    assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1]) and torch.equal(r1[2], r2[2])
+    gq = torch.randn_like(q)
+    gqd = torch.randn_like(qd)
+    b1 = eng.backward(r1[2], a, None, dt, S, mm, gq, gqd)
+    b2 = eng.backward(r1[2], a, None, dt, S, mm, gq, gqd)
+    assert all(torch.equal(x, y) for x, y in zip(b1[:3], b2[:3]))
+    # all 100 replicas of the same env agree bit-for-bit
+    assert torch.equal(r1[0].view(100, -1, t.n_q)[0], r1[0].view(100, -1, t.n_q)[57])
+
+
+def test_full_size_properties(dev):
+    """BASELINE config size (Ant 1024 envs): size-independent properties instead of the scalar oracle:
+    linearity of the adjoint in its seed, zero seed -> zero gradient, replicas identical, and the no-grad
+    path (ckpt = NULL) returns the same states."""
+    t, eng = _engine("ant", dev)
+    g = golden("ant_step")
+    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
+    reps = 1024 // g["q_in"].shape[0] + 1
+    q = torch.tensor(np.tile(g["q_in"], (reps, 1))[:1024], device=dev).reshape(-1)
+    qd = torch.tensor(np.tile(g["qd_in"], (reps, 1))[:1024], device=dev).reshape(-1)
+    a = torch.tensor(np.tile(g["act_in"], (reps, 1))[:1024], device=dev).reshape(-1)
+    qo, qdo, ck = eng.forward(q, qd, a, None, dt, S, mm, True)
+    qo2, qdo2, none = eng.forward(q, qd, a, None, dt, S, mm, False)
+    assert none is None and torch.equal(qo, qo2) and torch.equal(qdo, qdo2)
+    g1q, g1d = torch.randn_like(q), torch.randn_like(qd)
+    g2q, g2d = torch.randn_like(q), torch.randn_like(qd)
+    b1 = eng.backward(ck, a, None, dt, S, mm, g1q, g1d)
+    b2 = eng.backward(ck, a, None, dt, S, mm, g2q, g2d)
+    b3 = eng.backward(ck, a, None, dt, S, mm, g1q + 2 * g2q, g1d + 2 * g2d)
+    for x1, x2, x3 in zip(b1[:3], b2[:3], b3[:3]):
+        assert torch.isfinite(x3).all()
+        assert (x3 - (x1 + 2 * x2)).abs().max() <= 2e-4 * x3.abs().max()
+    b0 = eng.backward(ck, a, None, dt, S, mm, torch.zeros_like(q), torch.zeros_like(qd))
+    assert all(float(x.abs().max()) == 0.0 for x in b0[:3])
+
+
+def test_error_paths(dev):
+    from diffrl_amd import capi
+    t, eng = _engine("cartpole", dev)
+    q = torch.zeros(2 * t.n_q, device=dev)
+    qd = torch.zeros(2 * t.n_qd, device=dev)
+    with pytest.raises(capi.DsimError):
+        eng.forward(q, qd, torch.zeros(3, device=dev), None, 1 / 60, 4, 4, False)
+    with pytest.raises(capi.DsimError):
+        eng.forward(q, qd, torch.zeros_like(qd), None, 1 / 60, 0, 4, False)
+    with pytest.raises(capi.DsimError):
+        eng.forward(q.double(), qd, torch.zeros_like(qd), None, 1 / 60, 4, 4, False)
