@@ -1,0 +1,169 @@
+"""Headline benchmark: forward + adjoint env-steps/s, Ant 1024 envs x H=32 per GPU (BASELINE.json).
+
+One bench "step" = one rollout through the DFlexEnv surface: H env.step() calls with fixed synthetic
+actions, loss = -sum(reward), one backward through all H steps (what algorithms/shac.py:169-300 +
+shac.py:411 do, minus the actor network).  N GPUs = N processes (torch.distributed.run), each with its own
+shard of environments; no collective touches the data path (the all_reduce below only combines timings).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the adjoint kernel), `cpu_baseline`
+times the scalar CPU oracle on a bounded sample of the same workload on the box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+ALG_BYTES = {"ant": 748, "humanoid": 1424, "snu": 2884, "cartpole": 104}  # per env-step fwd+adjoint, SURVEY.md 8(d)
+HBM_PEAK_GBS = 8000.0
+MM_FREQ = {"ant": 16, "humanoid": 48, "snu": 8, "cartpole": 4}  # examples/cfg/shac/*.yaml
+
+
+def make_env(name, n, device):
+    from diffrl_amd import envs
+    cls = {"ant": envs.AntEnv, "humanoid": envs.HumanoidEnv, "snu": envs.SNUHumanoidEnv,
+           "cartpole": envs.CartPoleSwingUpEnv}[name]
+    kw = dict(num_envs=n, device=device, render=False, seed=0, episode_length=100000, no_grad=False,
+              stochastic_init=False, MM_caching_frequency=MM_FREQ[name])
+    if name in ("ant", "cartpole"):
+        kw["early_termination"] = False
+    return cls(**kw)
+
+
+def rollout(env, actions, kernel_events=None):
+    env.clear_grad()
+    env.reset()
+    env.initialize_trajectory()
+    acts = actions.detach().requires_grad_(True)
+    loss = 0.0
+    for t in range(acts.shape[0]):
+        obs, rew, done, info = env.step(acts[t])
+        loss = loss - rew.sum()
+    loss.backward()
+    return acts.grad
+
+
+def time_backward_kernel(env, name, n, H, reps, device):
+    """average duration of the adjoint kernel, HIP events on the launch stream, same shapes as the rollout"""
+    eng = env.model.engine()
+    S, mm = env.sim_substeps, MM_FREQ[name]
+    q = env.model.joint_q.clone()
+    qd = env.model.joint_qd.clone()
+    act = torch.zeros_like(qd)
+    mact = torch.zeros(n * eng.n_muscles, device=device) if eng.n_muscles else None
+    _, _, ck = eng.forward(q, qd, act, mact, env.sim_dt, S, mm, True)
+    gq, gqd = torch.randn_like(q), torch.randn_like(qd)
+    for _ in range(3):
+        eng.backward(ck, act, mact, env.sim_dt, S, mm, gq, gqd)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        eng.backward(ck, act, mact, env.sim_dt, S, mm, gq, gqd)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def cpu_baseline(name, budget_s=15.0):
+    """scalar CPU oracle (oracle/dsim_oracle.cpp, a port of the reference's CPU path) on a bounded sample"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import golden, oracle_backward, template_from_golden
+    t = template_from_golden(name)
+    g = golden(name + "_step")
+    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
+    args = (g["q_in"], g["qd_in"], g["act_in"], g.get("muscle_act_in"), dt, S, mm, g["gq_out"], g["gqd_out"])
+    oracle_backward(t, *args)  # warm up
+    n = g["q_in"].shape[0]
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        oracle_backward(t, *args)
+        done += n
+    el = time.perf_counter() - t0
+    return {"value": done / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d %s env-steps (fwd + taped adjoint, %d substeps each) in %.1f s on 1 of %d host cores"
+                      % (done, name, S, el, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--env", default="ant")
+    ap.add_argument("--envs-per-gpu", type=int, default=1024)
+    ap.add_argument("--horizon", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = world > 1
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if dist:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=device)
+
+    n, H = a.envs_per_gpu, a.horizon
+    env = make_env(a.env, n, str(device))
+    gen = torch.Generator().manual_seed(1 + rank)
+    actions = torch.tanh(2.0 * torch.rand((H, n, env.num_actions), generator=gen) - 1.0).to(device)
+
+    def barrier():
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        rollout(env, actions)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        grad = rollout(env, actions)
+    barrier()
+    el = time.perf_counter() - t0
+    assert torch.isfinite(grad).all()
+    if dist:
+        tt = torch.tensor([el], device=device, dtype=torch.float64)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        el = float(tt.item())
+    total_env_steps = a.steps * world * n * H
+    value = total_env_steps / el
+
+    if rank == 0:
+        t_bwd = time_backward_kernel(env, a.env, n, H, 50, device)
+        bwd_bytes = n * (ALG_BYTES[a.env] - 4 * (2 * env.num_joint_q + 2 * env.num_joint_qd + 0))  # placeholder, fixed below
+        # algorithmic bytes of ONE adjoint launch: re-read (q,qd,act) + read (gq',gqd') + write (gq,gqd,gact)
+        nq, nd = env.num_joint_q, env.num_joint_qd
+        na_in = env.model.muscles_per_articulation if env.model.muscle_count else nd
+        bwd_bytes = 4 * n * ((nq + nd + na_in) + (nq + nd) + (nq + nd + na_in))
+        achieved = bwd_bytes / t_bwd / 1e9
+        out = {
+            "metric": "fwd+adjoint env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s %d envs/GPU x H=%d through DFlexEnv.step, loss=-sum(rew), 1 backward"
+                                   % (a.env, n, H), "envs_per_gpu": n, "horizon": H, "substeps": env.sim_substeps,
+                       "mm_freq": MM_FREQ[a.env], "sharding": "envs by index, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "dsim_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": t_bwd * 1e3, "alg_bytes_per_launch": bwd_bytes,
+                         "note": "fused kernel is VALU/latency-bound by construction (SURVEY 8d); see DESIGN.md"},
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.env)
+        print(json.dumps(out))
+    if dist:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,199 @@
+"""DFlexEnv surface (envs/dflex_env.py + the per-env step/reset/clear_grad protocol of the reference,
+e.g. envs/ant.py:156-264) on top of the fused HIP step.
+
+What `algorithms/shac.py` relies on and is kept verbatim: constructor keywords, `num_envs`, `num_obs`,
+`num_actions`, `episode_length`, `step(actions) -> (obs, rew, done, extras)` with
+`extras['obs_before_reset']` / `extras['episode_end']` when gradients are on, `reset`, `clear_grad`,
+`initialize_trajectory`, `get_state` / `reset_with_state`, `get_checkpoint`; `obs` and `rew` carry
+`grad_fn` back to the actions and to the previous state.
+
+Structure differs from the reference (which repeats the protocol in every environment file): the
+protocol lives here once; an environment supplies its asset, action mapping, observation and reward.
+"""
+import os
+
+import numpy as np
+import torch
+
+from .. import dflex as df
+
+ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+
+
+def find_asset(name):
+    """Original asset file if available ($DIFFRL_ASSETS, the package's assets/ dir, or a reference
+    checkout), else None -> the environment falls back to its compiled asset (.npz builder snapshot)."""
+    roots = [os.environ.get("DIFFRL_ASSETS"), ASSET_DIR, "/root/reference/envs/assets"]
+    for r in roots:
+        if r and os.path.exists(os.path.join(r, name)):
+            return os.path.join(r, name)
+    return None
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (rl_games only reads low / high / shape)."""
+
+    def __init__(self, low, high):
+        self.low, self.high = np.asarray(low, np.float32), np.asarray(high, np.float32)
+        self.shape = self.low.shape
+        self.dtype = np.float32
+
+
+class DFlexEnv:
+    # subclasses set these
+    sim_substeps = 16
+    sanitize_grads = False   # nan_to_num hooks on the state / action gradients (humanoid.py:195-206)
+    keep_act_on_clear = False
+
+    def __init__(self, num_envs, num_obs, num_act, episode_length, MM_caching_frequency=1, seed=0, no_grad=True,
+                 render=False, device="cuda:0"):
+        self.seed = seed
+        self.no_grad = no_grad
+        df.config.no_grad = self.no_grad
+        self.episode_length = episode_length
+        self.device = device
+        self.visualize = False
+        if render:
+            print("[diffrl_amd] USD rendering is not part of the MI355X hot path; render=True is ignored")
+        self.sim_time = 0.0
+        self.num_frames = 0
+        self.num_environments = num_envs
+        self.num_agents = 1
+        self.MM_caching_frequency = MM_caching_frequency
+        self.num_observations = num_obs
+        self.num_actions = num_act
+        self.obs_space = Box(np.ones(num_obs) * -np.inf, np.ones(num_obs) * np.inf)
+        self.act_space = Box(np.ones(num_act) * -1.0, np.ones(num_act) * 1.0)
+        dev = self.device
+        self.obs_buf = torch.zeros((num_envs, num_obs), device=dev, dtype=torch.float)
+        self.rew_buf = torch.zeros(num_envs, device=dev, dtype=torch.float)
+        self.reset_buf = torch.ones(num_envs, device=dev, dtype=torch.long)
+        self.termination_buf = torch.zeros(num_envs, device=dev, dtype=torch.long)
+        self.progress_buf = torch.zeros(num_envs, device=dev, dtype=torch.long)
+        self.actions = torch.zeros((num_envs, num_act), device=dev, dtype=torch.float)
+        self.extras = {}
+        self.dt = 1.0 / 60.0
+        self.sim_dt = self.dt
+
+    # ---- bookkeeping the callers read ------------------------------------------------------------
+    def get_number_of_agents(self):
+        return self.num_agents
+
+    observation_space = property(lambda self: self.obs_space)
+    action_space = property(lambda self: self.act_space)
+    num_envs = property(lambda self: self.num_environments)
+    num_acts = property(lambda self: self.num_actions)
+    num_obs = property(lambda self: self.num_observations)
+
+    # ---- model construction ----------------------------------------------------------------------
+    def _finalize(self, builder, ground, gravity=(0.0, -9.81, 0.0)):
+        """builder holds ONE articulation; the model replicates it num_envs times on the device."""
+        builder.replicate(self.num_environments)
+        self.builder = builder
+        self.model = builder.finalize(self.device)
+        self.model.ground = ground
+        self.model.gravity = torch.tensor(gravity, dtype=torch.float32, device=self.device)
+        self.integrator = df.sim.SemiImplicitIntegrator()
+        self.state = self.model.state()
+        if ground:
+            self.model.collide(self.state)
+        self.num_joint_q = self.model.coords_per_articulation
+        self.num_joint_qd = self.model.dofs_per_articulation
+
+    def _q(self):
+        return self.state.joint_q.view(self.num_envs, -1)
+
+    def _qd(self):
+        return self.state.joint_qd.view(self.num_envs, -1)
+
+    # ---- hooks an environment implements ---------------------------------------------------------
+    def apply_actions(self, actions):
+        raise NotImplementedError
+
+    def reset_state(self, env_ids):
+        raise NotImplementedError
+
+    def calculateObservations(self):
+        raise NotImplementedError
+
+    def calculateReward(self):
+        raise NotImplementedError
+
+    def render(self, mode="human"):
+        pass
+
+    # ---- the protocol ------------------------------------------------------------------------------
+    def step(self, actions):
+        actions = torch.clip(actions.view((self.num_envs, self.num_actions)), -1.0, 1.0)
+        if self.sanitize_grads:
+            def scrub(grad):
+                return torch.nan_to_num(grad, 0.0, 0.0, 0.0)
+            for t in (self.state.joint_q, self.state.joint_qd, actions):
+                if t.requires_grad:
+                    t.register_hook(scrub)
+        self.apply_actions(actions)
+        self.state = self.integrator.forward(self.model, self.state, self.sim_dt, self.sim_substeps,
+                                             self.MM_caching_frequency)
+        self.sim_time += self.sim_dt
+        self.reset_buf = torch.zeros_like(self.reset_buf)
+        self.progress_buf += 1
+        self.num_frames += 1
+        self.calculateObservations()
+        self.calculateReward()
+        env_ids = self.reset_buf.nonzero(as_tuple=False).squeeze(-1)
+        if not self.no_grad:
+            self.obs_buf_before_reset = self.obs_buf.clone()
+            self.extras = {"obs_before_reset": self.obs_buf_before_reset, "episode_end": self.termination_buf}
+        if len(env_ids) > 0:
+            self.reset(env_ids)
+        return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def reset(self, env_ids=None, force_reset=True):
+        if env_ids is None and force_reset:
+            env_ids = torch.arange(self.num_envs, dtype=torch.long, device=self.device)
+        if env_ids is not None:
+            # fresh tensors: the old ones may be part of an autograd graph
+            self.state.joint_q = self.state.joint_q.clone()
+            self.state.joint_qd = self.state.joint_qd.clone()
+            self.reset_state(env_ids)
+            self.progress_buf[env_ids] = 0
+            self.calculateObservations()
+        return self.obs_buf
+
+    def clear_grad(self, checkpoint=None):
+        """Cuts the graph between the current state and everything before it."""
+        with torch.no_grad():
+            if checkpoint is None:
+                checkpoint = self.get_checkpoint()
+            act = self.state.joint_act.clone() if self.keep_act_on_clear else None
+            self.state = self.model.state()
+            self.state.joint_q = checkpoint["joint_q"].clone()
+            self.state.joint_qd = checkpoint["joint_qd"].clone()
+            if act is not None:
+                self.state.joint_act = act
+            self.actions = checkpoint["actions"].clone()
+            self.progress_buf = checkpoint["progress_buf"].clone()
+
+    def initialize_trajectory(self):
+        self.clear_grad()
+        self.calculateObservations()
+        return self.obs_buf
+
+    def get_checkpoint(self):
+        return {"joint_q": self.state.joint_q.clone(), "joint_qd": self.state.joint_qd.clone(),
+                "actions": self.actions.clone(), "progress_buf": self.progress_buf.clone()}
+
+    def get_state(self):
+        return self.state.joint_q.clone(), self.state.joint_qd.clone()
+
+    def reset_with_state(self, init_joint_q, init_joint_qd, env_ids=None, force_reset=True):
+        if env_ids is None and force_reset:
+            env_ids = torch.arange(self.num_envs, dtype=torch.long, device=self.device)
+        if env_ids is not None:
+            self.state.joint_q = self.state.joint_q.clone()
+            self.state.joint_qd = self.state.joint_qd.clone()
+            self._q()[env_ids, :] = init_joint_q.view(-1, self.num_joint_q)[env_ids, :].clone()
+            self._qd()[env_ids, :] = init_joint_qd.view(-1, self.num_joint_qd)[env_ids, :].clone()
+            self.progress_buf[env_ids] = 0
+            self.calculateObservations()
+        return self.obs_buf

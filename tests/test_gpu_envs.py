@@ -1,0 +1,92 @@
+"""-m gpu: the DFlexEnv surface (step / obs / reward / autograd) against rollouts recorded from the
+reference environments (tests/golden/<env>_rollout.npz, oracle/gen_golden.py:rollout_golden).
+Stated tolerance for short-horizon trajectories and gradients: 1e-3 max-norm relative, cosine >= 0.9999
+(BASELINE.md section 4)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle_lib import golden, relerr
+
+pytestmark = pytest.mark.gpu
+CASES = ["cartpole", "ant", "humanoid", "snu"]
+
+
+def _make(env, n, no_grad=False):
+    from diffrl_amd import envs
+    cls = {"cartpole": envs.CartPoleSwingUpEnv, "ant": envs.AntEnv, "humanoid": envs.HumanoidEnv,
+           "snu": envs.SNUHumanoidEnv}[env]
+    mm = {"cartpole": 4, "ant": 16, "humanoid": 48, "snu": 8}[env]
+    kw = dict(num_envs=n, device="cuda:0", render=False, seed=0, episode_length=1000, no_grad=no_grad,
+              stochastic_init=False, MM_caching_frequency=mm)
+    if env in ("cartpole", "ant"):
+        kw["early_termination"] = False
+    return cls(**kw)
+
+
+@pytest.mark.parametrize("env", CASES)
+def test_rollout_matches_reference(env):
+    g = golden(env + "_rollout")
+    H, n = g["actions"].shape[0], g["actions"].shape[1]
+    e = _make(env, n)
+    dev = torch.device("cuda:0")
+    e.clear_grad()
+    e.reset()
+    e.reset_with_state(torch.tensor(g["q0"], device=dev).reshape(-1), torch.tensor(g["qd0"], device=dev).reshape(-1))
+    obs0 = e.initialize_trajectory()
+    na = e.num_actions if getattr(e, "obs_has_actions", False) else 0
+    ref0 = g["obs0"]
+    keep = ref0.shape[1] - na
+    assert relerr(obs0.detach().cpu().numpy()[:, :keep], ref0[:, :keep]) < 1e-5
+    acts = torch.tensor(g["actions"], device=dev, requires_grad=True)
+    loss = 0.0
+    for t in range(H):
+        obs, rew, done, info = e.step(acts[t])
+        assert int(done.sum()) == 0
+        assert obs.grad_fn is not None and rew.grad_fn is not None
+        assert "obs_before_reset" in info and "episode_end" in info
+        assert relerr(obs.detach().cpu().numpy(), g["obs"][t]) < 1e-3, t
+        assert np.abs(rew.detach().cpu().numpy() - g["rew"][t]).max() < 1e-3 * max(1.0, np.abs(g["rew"]).max()), t
+        loss = loss - rew.sum()
+    loss.backward()
+    ga, gr = acts.grad.cpu().numpy().astype(np.float64), g["grad_actions"].astype(np.float64)
+    assert relerr(ga, gr) < 1e-3
+    cos = (ga * gr).sum() / (np.linalg.norm(ga) * np.linalg.norm(gr))
+    assert cos > 0.9999
+    assert relerr(e.state.joint_q.detach().cpu().numpy().reshape(n, -1), g["q_final"]) < 1e-3
+
+
+def test_no_grad_path_and_autoreset():
+    """dflex.config.no_grad fast path (no checkpoints) gives the same states; episode_length resets work"""
+    g = golden("ant_rollout")
+    H, n = g["actions"].shape[0], g["actions"].shape[1]
+    dev = torch.device("cuda:0")
+    e = _make("ant", n, no_grad=True)
+    e.episode_length = 3
+    e.reset()
+    e.reset_with_state(torch.tensor(g["q0"], device=dev).reshape(-1), torch.tensor(g["qd0"], device=dev).reshape(-1))
+    for t in range(3):
+        obs, rew, done, info = e.step(torch.tensor(g["actions"][t], device=dev))
+        assert obs.grad_fn is None
+        if t < 2:
+            assert int(done.sum()) == 0
+            assert relerr(obs.cpu().numpy(), g["obs"][t]) < 1e-3
+    assert int(done.sum()) == n                       # episode_length reached -> every env reset
+    assert int(e.progress_buf.sum()) == 0
+    assert torch.allclose(e.state.joint_q.view(n, -1)[:, 1], torch.full((n,), 0.75, device=dev))
+
+
+def test_shac_style_usage():
+    """the call pattern of algorithms/shac.py:184-251 (initialize_trajectory, H steps, backward, clear)"""
+    e = _make("ant", 64)
+    dev = torch.device("cuda:0")
+    actor = torch.nn.Linear(e.num_obs, e.num_actions).to(dev)
+    obs = e.initialize_trajectory()
+    total = 0.0
+    for t in range(4):
+        obs, rew, done, info = e.step(torch.tanh(actor(obs)))
+        total = total - rew.sum()
+    total.backward()
+    assert all(torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0 for p in actor.parameters())
+    e.clear_grad()
+    assert not e.state.joint_q.requires_grad
