@@ -102,15 +102,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from diffrl_amd import sharding
+    rank, local, world = sharding.world()
     dist = world > 1
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     if dist:
         import torch.distributed as td
-        td.init_process_group("nccl", device_id=device)
+        sharding.init("nccl", device)
 
     n, H = a.envs_per_gpu, a.horizon
     env = make_env(a.env, n, str(device))
@@ -131,21 +130,25 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     assert torch.isfinite(grad).all()
-    if dist:
-        tt = torch.tensor([el], device=device, dtype=torch.float64)
-        td.all_reduce(tt, op=td.ReduceOp.MAX)
-        el = float(tt.item())
+    el = sharding.max_over_ranks(el, device)
     total_env_steps = a.steps * world * n * H
     value = total_env_steps / el
 
     if rank == 0:
         t_bwd = time_backward_kernel(env, a.env, n, H, 50, device)
-        bwd_bytes = n * (ALG_BYTES[a.env] - 4 * (2 * env.num_joint_q + 2 * env.num_joint_qd + 0))  # placeholder, fixed below
         # algorithmic bytes of ONE adjoint launch: re-read (q,qd,act) + read (gq',gqd') + write (gq,gqd,gact)
         nq, nd = env.num_joint_q, env.num_joint_qd
         na_in = env.model.muscles_per_articulation if env.model.muscle_count else nd
         bwd_bytes = 4 * n * ((nq + nd + na_in) + (nq + nd) + (nq + nd + na_in))
         achieved = bwd_bytes / t_bwd / 1e9
+        traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
+        try:
+            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
+            if a.env == "ant" and n == 1024 and pmc.get("kernel") == "dsim_bwd_kernel":
+                traffic = pmc["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "fwd+adjoint env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
@@ -154,7 +157,7 @@ def main():
                                    % (a.env, n, H), "envs_per_gpu": n, "horizon": H, "substeps": env.sim_substeps,
                        "mm_freq": MM_FREQ[a.env], "sharding": "envs by index, no collective"},
             "roofline": {"bound": "hbm", "kernel": "dsim_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": t_bwd * 1e3, "alg_bytes_per_launch": bwd_bytes,
                          "note": "fused kernel is VALU/latency-bound by construction (SURVEY 8d); see DESIGN.md"},
         }

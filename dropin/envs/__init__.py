@@ -1,0 +1,7 @@
+"""`import envs` -> diffrl_amd.envs (same class names as the reference's envs/__init__.py)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from diffrl_amd.envs import *  # noqa: F401,F403,E402
+from diffrl_amd.envs import AntEnv, CartPoleSwingUpEnv, DFlexEnv, HumanoidEnv, SNUHumanoidEnv  # noqa: F401,E402
