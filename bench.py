@@ -52,20 +52,20 @@ def rollout(env, actions, kernel_events=None):
 def time_backward_kernel(env, name, n, H, reps, device):
     """average duration of the adjoint kernel, HIP events on the launch stream, same shapes as the rollout"""
     eng = env.model.engine()
+    spec = env._spec()
     S, mm = env.sim_substeps, MM_FREQ[name]
-    q = env.model.joint_q.clone()
-    qd = env.model.joint_qd.clone()
-    act = torch.zeros_like(qd)
-    mact = torch.zeros(n * eng.n_muscles, device=device) if eng.n_muscles else None
-    _, _, ck = eng.forward(q, qd, act, mact, env.sim_dt, S, mm, True)
-    gq, gqd = torch.randn_like(q), torch.randn_like(qd)
+    q = env.state.joint_q.detach().clone()
+    qd = env.state.joint_qd.detach().clone()
+    acts = torch.zeros((n, env.num_actions), device=device)
+    qo, qdo, obs, rew, ck = eng.env_forward(spec, q, qd, acts, env.sim_dt, S, mm, True)
+    gq, gqd, go, gr = torch.randn_like(q), torch.randn_like(qd), torch.randn_like(obs), torch.randn_like(rew)
     for _ in range(3):
-        eng.backward(ck, act, mact, env.sim_dt, S, mm, gq, gqd)
+        eng.env_backward(spec, ck, acts, qo, qdo, env.sim_dt, S, mm, gq, gqd, go, gr)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):
-        eng.backward(ck, act, mact, env.sim_dt, S, mm, gq, gqd)
+        eng.env_backward(spec, ck, acts, qo, qdo, env.sim_dt, S, mm, gq, gqd, go, gr)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e-3
@@ -137,6 +137,7 @@ def main():
     if rank == 0:
         t_bwd = time_backward_kernel(env, a.env, n, H, 50, device)
         # algorithmic bytes of ONE adjoint launch: re-read (q,qd,act) + read (gq',gqd') + write (gq,gqd,gact)
+        # (the fused kernel additionally reads the obs/reward cotangents; not counted, SURVEY's figure is kept)
         nq, nd = env.num_joint_q, env.num_joint_qd
         na_in = env.model.muscles_per_articulation if env.model.muscle_count else nd
         bwd_bytes = 4 * n * ((nq + nd + na_in) + (nq + nd) + (nq + nd + na_in))
@@ -145,7 +146,7 @@ def main():
         try:
             pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
-            if a.env == "ant" and n == 1024 and pmc.get("kernel") == "dsim_bwd_kernel":
+            if a.env == "ant" and n == 1024 and pmc.get("kernel") in ("dsim_bwd_kernel", "dsim_env_bwd_kernel"):
                 traffic = pmc["traffic_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -156,7 +157,7 @@ def main():
             "config": {"workload": "%s %d envs/GPU x H=%d through DFlexEnv.step, loss=-sum(rew), 1 backward"
                                    % (a.env, n, H), "envs_per_gpu": n, "horizon": H, "substeps": env.sim_substeps,
                        "mm_freq": MM_FREQ[a.env], "sharding": "envs by index, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "dsim_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "dsim_env_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": t_bwd * 1e3, "alg_bytes_per_launch": bwd_bytes,
                          "note": "fused kernel is VALU/latency-bound by construction (SURVEY 8d); see DESIGN.md"},

@@ -31,6 +31,40 @@ class ModelDesc(C.Structure):
     ]
 
 
+class EnvSpec(C.Structure):
+    """Mirror of `dsim_env_spec` (include/dsim.h)."""
+    _fields_ = [
+        ("kind", C.c_int32), ("rew_kind", C.c_int32), ("n_act", C.c_int32), ("n_obs", C.c_int32),
+        ("act_offset", C.c_int32), ("act_muscle", C.c_int32), ("obs_actions", C.c_int32),
+        ("inv_start_rot", C.c_float * 4), ("target_x", C.c_float), ("target_z", C.c_float),
+        ("termination_height", C.c_float), ("termination_tolerance", C.c_float), ("height_rew_scale", C.c_float),
+        ("action_penalty", C.c_float), ("joint_vel_obs_scaling", C.c_float), ("cartpole_penalties", C.c_float * 4),
+        ("act_scale", C.c_void_p),
+    ]
+
+
+ENV_LOCOMOTION, ENV_CARTPOLE = 1, 2
+REW_ANT, REW_HUMANOID, REW_SNU, REW_CARTPOLE = 0, 1, 2, 3
+
+
+def make_env_spec(kind, rew_kind, n_act, n_obs, act_scale_ptr, act_offset=0, act_muscle=False, obs_actions=False,
+                  inv_start_rot=(0.0, 0.0, 0.0, 1.0), target_xz=(0.0, 0.0), termination_height=0.0,
+                  termination_tolerance=0.0, height_rew_scale=0.0, action_penalty=0.0, joint_vel_obs_scaling=0.1,
+                  cartpole_penalties=(0.0, 0.0, 0.0, 0.0)):
+    e = EnvSpec()
+    e.kind, e.rew_kind, e.n_act, e.n_obs = kind, rew_kind, n_act, n_obs
+    e.act_offset, e.act_muscle, e.obs_actions = act_offset, int(bool(act_muscle)), int(bool(obs_actions))
+    for k in range(4):
+        e.inv_start_rot[k] = float(inv_start_rot[k])
+        e.cartpole_penalties[k] = float(cartpole_penalties[k])
+    e.target_x, e.target_z = float(target_xz[0]), float(target_xz[1])
+    e.termination_height, e.termination_tolerance = float(termination_height), float(termination_tolerance)
+    e.height_rew_scale, e.action_penalty = float(height_rew_scale), float(action_penalty)
+    e.joint_vel_obs_scaling = float(joint_vel_obs_scaling)
+    e.act_scale = act_scale_ptr
+    return e
+
+
 def make_desc(t):
     """ArticulationTemplate -> (ModelDesc, keepalive list).  Arrays are borrowed: keep `t` alive."""
     d = ModelDesc()
@@ -86,7 +120,13 @@ def lib():
     L.dsim_step_forward.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp]
     L.dsim_step_backward.argtypes = [vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp,
                                      vp]
-    for fn in (L.dsim_model_create, L.dsim_model_destroy, L.dsim_step_forward, L.dsim_step_backward):
+    ep = C.POINTER(EnvSpec)
+    L.dsim_env_step_forward.argtypes = [vp, ep, C.c_int, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.dsim_env_step_backward.argtypes = [vp, ep, C.c_int, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp,
+                                         vp, vp, vp, vp]
+    L.dsim_env_observe.argtypes = [vp, ep, C.c_int, vp, vp, vp, vp, vp, vp]
+    for fn in (L.dsim_model_create, L.dsim_model_destroy, L.dsim_step_forward, L.dsim_step_backward,
+               L.dsim_env_step_forward, L.dsim_env_step_backward, L.dsim_env_observe):
         fn.restype = C.c_int
     _lib = L
     return L
@@ -98,4 +138,5 @@ def check(rc):
 
 
 EXPORTS = ("dsim_last_error", "dsim_version", "dsim_model_create", "dsim_model_destroy", "dsim_ckpt_floats",
-           "dsim_step_forward", "dsim_step_backward")
+           "dsim_step_forward", "dsim_step_backward", "dsim_env_step_forward", "dsim_env_step_backward",
+           "dsim_env_observe")

@@ -900,3 +900,312 @@ DSIM_FN void dsim_env_step_backward(const DsimCtx& c, Exec& ex, int substeps, in
             for (int k = lane; k < M; k += DSIM_NL) g_gmact[k] = WF(amact)[k];
     });
 }
+
+// ================================================================================================
+// fused environment surface: action clip/scale -> joint_act / muscle
+// activations, observation vector and reward computed by the step kernels, adjoint fused likewise.
+// Reference: envs/ant.py:156-174,266-307, envs/humanoid.py:186-215,314-356,
+// envs/snu_humanoid.py:243-275,376-416, envs/cartpole_swing_up.py:113-125,204-225.
+// ================================================================================================
+#define DSIM_ENV_LOCOMOTION 1   // free-floating root: [h, quat, lin vel, ang vel, joint q, joint qd*s, up, heading, (actions)]
+#define DSIM_ENV_CARTPOLE 2     // [x, xdot, sin th, cos th, thdot]
+#define DSIM_REW_ANT 0
+#define DSIM_REW_HUMANOID 1
+#define DSIM_REW_SNU 2
+#define DSIM_REW_CARTPOLE 3
+
+struct DsimEnvSpec {
+    int kind, rew_kind;
+    int n_act, n_obs;
+    int act_offset;      // joint_act[act_offset + k] = clip(a_k) * act_scale[k]            (act_muscle == 0)
+    int act_muscle;      // muscle_act[k] = (clip(a_k) * 0.5 + 0.5) * act_scale[k]           (act_muscle == 1)
+    int obs_actions;     // append the (clipped / remapped) actions to the observation
+    float isr[4];        // conjugate of the start rotation
+    float tgt_x, tgt_z;  // targets + start_pos (x, z)
+    float term_h, term_tol, h_scale, act_pen, vel_scale;
+    float pen[4];        // cartpole: pole angle, pole velocity, cart position, cart velocity penalties
+    const float* act_scale;  // [n_act], device memory
+};
+
+// actions -> LDS: ua (what the env stores as self.actions), act / mact
+template <class Exec>
+DSIM_FN void dsim_env_load_actions(const DsimCtx& c, Exec& ex, const DsimEnvSpec& sp, const float* g_actions) {
+    ex.run([&](int lane) {
+        for (int k = lane; k < c.d.nd; k += DSIM_NL) WF(act)[k] = 0.f;
+    });
+    ex.run([&](int lane) {
+        for (int k = lane; k < sp.n_act; k += DSIM_NL) {
+            float a = g_actions[k];
+            a = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
+            if (sp.act_muscle) {
+                a = a * 0.5f + 0.5f;
+                WF(mact)[k] = a * sp.act_scale[k];
+            } else {
+                WF(act)[sp.act_offset + k] = a * sp.act_scale[k];
+            }
+            WF(ua)[k] = a;
+        }
+    });
+}
+
+template <class Exec>
+DSIM_FN void dsim_env_observe(const DsimCtx& c, Exec& ex, const DsimEnvSpec& sp, float* g_obs, float* g_rew) {
+    const int nq = c.d.nq, nd = c.d.nd;
+    ex.run([&](int lane) {
+        const float *q = WF(q), *qd = WF(qd);
+        float* o = WF(obs);
+        if (sp.kind == DSIM_ENV_LOCOMOTION) {
+            const int nj = nq - 7, njd = nd - 6;
+            if (lane == 0) {
+                const v3 pos = ld3(q), w = ld3(qd), vl = ld3(qd + 3);
+                const q4 r = ldq(q + 3);
+                o[0] = pos.y;
+                stq(o + 1, r);
+                st3(o + 5, vl - cross(pos, w));
+                st3(o + 8, w);
+                const q4 tq = qmul(r, mkq(sp.isr[0], sp.isr[1], sp.isr[2], sp.isr[3]));
+                const v3 up = rotate(tq, mk3(0.f, 1.f, 0.f)), hd = rotate(tq, mk3(1.f, 0.f, 0.f));
+                const float tx = sp.tgt_x - pos.x, tz = sp.tgt_z - pos.z;
+                float l = sqrtf(tx * tx + tz * tz);
+                l = l < 1e-9f ? 1e-9f : l;
+                o[11 + nj + njd] = up.y;
+                o[12 + nj + njd] = hd.x * (tx / l) + hd.z * (tz / l);
+            }
+            for (int k = lane; k < nj; k += DSIM_NL) o[11 + k] = q[7 + k];
+            for (int k = lane; k < njd; k += DSIM_NL) o[11 + nj + k] = sp.vel_scale * qd[6 + k];
+            if (sp.obs_actions)
+                for (int k = lane; k < sp.n_act; k += DSIM_NL) o[13 + nj + njd + k] = WF(ua)[k];
+        } else if (sp.kind == DSIM_ENV_CARTPOLE) {
+            if (lane == 0) {
+                o[0] = q[0];
+                o[1] = qd[0];
+                o[2] = sinf(q[1]);
+                o[3] = cosf(q[1]);
+                o[4] = qd[1];
+            }
+        }
+    });
+    ex.run([&](int lane) {
+        const float* o = WF(obs);
+        for (int k = lane; k < sp.n_obs; k += DSIM_NL) g_obs[k] = o[k];
+        if (lane == 0) {
+            float r = 0.f;
+            if (sp.kind == DSIM_ENV_LOCOMOTION) {
+                const int iu = 11 + (nq - 7) + (nd - 6);
+                r = o[5] + 0.1f * o[iu] + o[iu + 1];
+                float pen = 0.f;
+                if (sp.rew_kind == DSIM_REW_SNU) {
+                    for (int k = 0; k < sp.n_act; ++k) pen += fabsf(WF(ua)[k]);
+                } else {
+                    for (int k = 0; k < sp.n_act; ++k) pen += WF(ua)[k] * WF(ua)[k];
+                }
+                r += pen * sp.act_pen;
+                if (sp.rew_kind == DSIM_REW_ANT) {
+                    r += o[0] - sp.term_h;
+                } else if (sp.rew_kind == DSIM_REW_HUMANOID) {
+                    float hr = o[0] - (sp.term_h + sp.term_tol);
+                    hr = hr < -1.0f ? -1.0f : (hr > sp.term_tol ? sp.term_tol : hr);
+                    if (hr < 0.0f) hr = -200.0f * hr * hr;
+                    if (hr > 0.0f) hr = sp.h_scale * hr;
+                    r += hr;
+                }
+            } else if (sp.kind == DSIM_ENV_CARTPOLE) {
+                const float th = atan2f(o[2], o[3]);
+                const float a = WF(ua)[0];
+                r = -th * th * sp.pen[0] - o[4] * o[4] * sp.pen[1] - o[0] * o[0] * sp.pen[2] - o[1] * o[1] * sp.pen[3] -
+                    a * a * sp.act_pen;
+            }
+            g_rew[0] = r;
+        }
+    });
+}
+
+// obs/reward^T: adds into aqn/aqdn (cotangents of the step's output state) and writes gua (d/d stored action)
+template <class Exec>
+DSIM_FN void dsim_env_observe_adjoint(const DsimCtx& c, Exec& ex, const DsimEnvSpec& sp, const float* g_gobs,
+                                      const float* g_grew) {
+    const int nq = c.d.nq, nd = c.d.nd;
+    // q/qd in LDS hold the step's OUTPUT state, ua the stored actions
+    ex.run([&](int lane) {
+        for (int k = lane; k < sp.n_obs; k += DSIM_NL) WF(obs)[k] = g_gobs[k];  // obs buffer reused for its cotangent
+    });
+    ex.run([&](int lane) {
+        const float *q = WF(q), *qd = WF(qd);
+        const float gr = g_grew[0];
+        float* go = WF(obs);
+        if (sp.kind == DSIM_ENV_LOCOMOTION) {
+            const int nj = nq - 7, njd = nd - 6, iu = 11 + nj + njd;
+            for (int k = lane; k < nj; k += DSIM_NL) WF(aqn)[7 + k] += go[11 + k];
+            for (int k = lane; k < njd; k += DSIM_NL) WF(aqdn)[6 + k] += sp.vel_scale * go[11 + nj + k];
+            for (int k = lane; k < sp.n_act; k += DSIM_NL) {
+                const float a = WF(ua)[k];
+                float g = sp.obs_actions ? go[iu + 2 + k] : 0.f;
+                if (sp.rew_kind == DSIM_REW_SNU) g += gr * sp.act_pen * (a < 0.0f ? -1.0f : (a > 0.0f ? 1.0f : 0.0f));
+                else g += gr * sp.act_pen * 2.0f * a;
+                WF(gua)[k] = g;
+            }
+            if (lane == 0) {
+                const v3 pos = ld3(q), w = ld3(qd);
+                const q4 r = ldq(q + 3);
+                // reward -> obs cotangents
+                float g_h = go[0], g_up = go[iu] + 0.1f * gr, g_hd = go[iu + 1] + gr;
+                v3 g_lv = ld3(go + 5);
+                g_lv.x += gr;
+                if (sp.rew_kind == DSIM_REW_ANT) {
+                    g_h += gr;
+                } else if (sp.rew_kind == DSIM_REW_HUMANOID) {
+                    const float d = pos.y - (sp.term_h + sp.term_tol);
+                    float dh = 0.f;  // d(height reward)/d(height)
+                    if (d >= -1.0f && d <= sp.term_tol) {
+                        if (d < 0.0f) dh = -400.0f * d;
+                        else if (d > 0.0f) dh = sp.h_scale;
+                        else dh = 1.0f;
+                    }
+                    g_h += gr * dh;
+                }
+                v3 g_pos = mk3(0.f, g_h, 0.f);
+                v3 g_w = ld3(go + 8);
+                // lin_vel = vl - pos x w
+                g_pos += cross(g_lv, w);
+                g_w += cross(pos, g_lv);
+                const q4 isr = mkq(sp.isr[0], sp.isr[1], sp.isr[2], sp.isr[3]);
+                const q4 tq = qmul(r, isr);
+                const v3 ey = mk3(0.f, 1.f, 0.f), ex_ = mk3(1.f, 0.f, 0.f);
+                const v3 hd = rotate(tq, ex_);
+                const float tx = sp.tgt_x - pos.x, tz = sp.tgt_z - pos.z;
+                float l = sqrtf(tx * tx + tz * tz);
+                const bool clamped = l < 1e-9f;
+                l = clamped ? 1e-9f : l;
+                const float dx = tx / l, dz = tz / l;
+                q4 g_tq = rotate_adj_q(tq, ey, mk3(0.f, g_up, 0.f));
+                g_tq += rotate_adj_q(tq, ex_, mk3(dx * g_hd, 0.f, dz * g_hd));
+                q4 g_r = ldq(go + 1) + qmul_adj_a(isr, g_tq);
+                if (!clamped) {
+                    const float gdx = hd.x * g_hd, gdz = hd.z * g_hd;
+                    const float dd = dx * gdx + dz * gdz;
+                    g_pos.x -= (gdx - dx * dd) / l;
+                    g_pos.z -= (gdz - dz * dd) / l;
+                }
+                add3(WF(aqn), g_pos);
+                addq(WF(aqn) + 3, g_r);
+                add3(WF(aqdn), g_w);
+                add3(WF(aqdn) + 3, g_lv);
+            }
+        } else if (sp.kind == DSIM_ENV_CARTPOLE) {
+            if (lane == 0) {
+                const float th = atan2f(sinf(q[1]), cosf(q[1]));
+                WF(aqn)[0] += go[0] - gr * 2.0f * q[0] * sp.pen[2];
+                WF(aqdn)[0] += go[1] - gr * 2.0f * qd[0] * sp.pen[3];
+                WF(aqn)[1] += go[2] * cosf(q[1]) - go[3] * sinf(q[1]) - gr * 2.0f * th * sp.pen[0];
+                WF(aqdn)[1] += go[4] - gr * 2.0f * qd[1] * sp.pen[1];
+                WF(gua)[0] = -gr * 2.0f * WF(ua)[0] * sp.act_pen;
+            }
+        }
+    });
+}
+
+// whole fused env.step(): actions -> sim -> (q', qd', obs, rew)
+template <class Exec>
+DSIM_FN void dsim_env_fused_forward(const DsimCtx& c, Exec& ex, const DsimEnvSpec& sp, int substeps, int mm_freq,
+                                    const float* g_q, const float* g_qd, const float* g_actions, float* g_q_out,
+                                    float* g_qd_out, float* g_obs, float* g_rew, float* g_ckpt) {
+    const int nq = c.d.nq, nd = c.d.nd;
+    ex.run([&](int lane) {
+        for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = g_q[k];
+        for (int k = lane; k < nd; k += DSIM_NL) WF(qd)[k] = g_qd[k];
+    });
+    dsim_env_load_actions(c, ex, sp, g_actions);
+    for (int s = 0; s < substeps; ++s) {
+        if (g_ckpt) {
+            float* ck = g_ckpt + (size_t)s * (nq + nd);
+            ex.run([&](int lane) {
+                for (int k = lane; k < nq; k += DSIM_NL) ck[k] = WF(q)[k];
+                for (int k = lane; k < nd; k += DSIM_NL) ck[nq + k] = WF(qd)[k];
+            });
+        }
+        dsim_fwd_substep(c, ex, (s % mm_freq) == 0);
+    }
+    ex.run([&](int lane) {
+        for (int k = lane; k < nq; k += DSIM_NL) g_q_out[k] = WF(q)[k];
+        for (int k = lane; k < nd; k += DSIM_NL) g_qd_out[k] = WF(qd)[k];
+    });
+    dsim_env_observe(c, ex, sp, g_obs, g_rew);
+}
+
+// state-only observation (reset / initialize_trajectory path): obs of (q, qd) with the given stored actions
+template <class Exec>
+DSIM_FN void dsim_env_observe_only(const DsimCtx& c, Exec& ex, const DsimEnvSpec& sp, const float* g_q, const float* g_qd,
+                                   const float* g_stored_actions, float* g_obs, float* g_rew) {
+    ex.run([&](int lane) {
+        for (int k = lane; k < c.d.nq; k += DSIM_NL) WF(q)[k] = g_q[k];
+        for (int k = lane; k < c.d.nd; k += DSIM_NL) WF(qd)[k] = g_qd[k];
+        for (int k = lane; k < sp.n_act; k += DSIM_NL) WF(ua)[k] = g_stored_actions[k];
+    });
+    dsim_env_observe(c, ex, sp, g_obs, g_rew);
+}
+
+// reverse of dsim_env_fused_forward; g_q_out/g_qd_out are the forward OUTPUT state (needed by obs^T)
+template <class Exec>
+DSIM_FN void dsim_env_fused_backward(const DsimCtx& c, Exec& ex, const DsimEnvSpec& sp, int substeps, int mm_freq,
+                                     const float* g_ckpt, const float* g_actions, const float* g_q_out,
+                                     const float* g_qd_out, const float* g_gq_out, const float* g_gqd_out,
+                                     const float* g_gobs, const float* g_grew, float* g_gq_in, float* g_gqd_in,
+                                     float* g_gactions) {
+    const int nq = c.d.nq, nd = c.d.nd, M = c.d.M;
+    ex.run([&](int lane) {
+        for (int k = lane; k < nq; k += DSIM_NL) {
+            WF(q)[k] = g_q_out[k];
+            WF(aqn)[k] = g_gq_out[k];
+        }
+        for (int k = lane; k < nd; k += DSIM_NL) {
+            WF(qd)[k] = g_qd_out[k];
+            WF(aqdn)[k] = g_gqd_out[k];
+            WF(aact)[k] = 0.f;
+        }
+        for (int k = lane; k < M; k += DSIM_NL) WF(amact)[k] = 0.f;
+    });
+    dsim_env_load_actions(c, ex, sp, g_actions);
+    dsim_env_observe_adjoint(c, ex, sp, g_gobs, g_grew);
+    const int groups = (substeps + mm_freq - 1) / mm_freq;
+    for (int g = groups - 1; g >= 0; --g) {
+        const int s0 = g * mm_freq, s1 = (s0 + mm_freq < substeps) ? s0 + mm_freq : substeps;
+        {
+            const float* ck = g_ckpt + (size_t)s0 * (nq + nd);
+            ex.run([&](int lane) {
+                for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = ck[k];
+                for (int k = lane; k < nd; k += DSIM_NL) WF(qd)[k] = ck[nq + k];
+                for (int k = lane; k < nd * nd; k += DSIM_NL) WF(aH)[k] = 0.f;
+            });
+            dsim_fwd_kinematics(c, ex);
+            dsim_fwd_mass(c, ex);
+        }
+        for (int s = s1 - 1; s >= s0; --s) {
+            const float* ck = g_ckpt + (size_t)s * (nq + nd);
+            ex.run([&](int lane) {
+                for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = ck[k];
+                for (int k = lane; k < nd; k += DSIM_NL) WF(qd)[k] = ck[nq + k];
+            });
+            dsim_fwd_kinematics(c, ex);
+            dsim_fwd_external(c, ex);
+            dsim_fwd_tau(c, ex);
+            if (s == s0) dsim_fwd_composite(c, ex);
+            dsim_fwd_solve(c, ex);
+            dsim_bwd_substep(c, ex, s == s0);
+            ex.run([&](int lane) {
+                for (int k = lane; k < nq; k += DSIM_NL) WF(aqn)[k] = WF(aq)[k];
+                for (int k = lane; k < nd; k += DSIM_NL) WF(aqdn)[k] = WF(aqd)[k];
+            });
+        }
+    }
+    ex.run([&](int lane) {
+        for (int k = lane; k < nq; k += DSIM_NL) g_gq_in[k] = WF(aqn)[k];
+        for (int k = lane; k < nd; k += DSIM_NL) g_gqd_in[k] = WF(aqdn)[k];
+        for (int k = lane; k < sp.n_act; k += DSIM_NL) {
+            const float a = g_actions[k];
+            float g = WF(gua)[k];
+            if (sp.act_muscle) g = 0.5f * (g + sp.act_scale[k] * WF(amact)[k]);
+            else g += sp.act_scale[k] * WF(aact)[sp.act_offset + k];
+            g_gactions[k] = (a >= -1.0f && a <= 1.0f) ? g : 0.f;
+        }
+    });
+}

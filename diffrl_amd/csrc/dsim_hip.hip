@@ -82,6 +82,66 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_bwd_kernel(KCommon k, const floa
                            gqd_in + e * nd, gact ? gact + e * nd : nullptr, (gmact && M) ? gmact + e * M : nullptr);
 }
 
+__device__ __forceinline__ DsimCtx make_ctx(float* lds, const KCommon& k) {
+    DsimCtx c;
+    c.s = lds;
+    c.o = k.o;
+    c.d = k.d;
+    c.h = k.h;
+    return c;
+}
+
+__global__ __launch_bounds__(DSIM_NL) void dsim_env_fwd_kernel(KCommon k, DsimEnvSpec sp, const float* __restrict__ q_in,
+                                                               const float* __restrict__ qd_in,
+                                                               const float* __restrict__ actions, float* q_out,
+                                                               float* qd_out, float* obs, float* rew, float* ckpt) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int e = blockIdx.x;
+    if (e >= k.n_envs) return;
+    load_constants(lds, k);
+    DsimCtx c = make_ctx(lds, k);
+    DevExec ex;
+    const size_t nq = k.d.nq, nd = k.d.nd;
+    dsim_env_fused_forward(c, ex, sp, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, actions + (size_t)e * sp.n_act,
+                           q_out + e * nq, qd_out + e * nd, obs + (size_t)e * sp.n_obs, rew + e,
+                           ckpt ? ckpt + (size_t)e * k.substeps * (nq + nd) : nullptr);
+}
+
+__global__ __launch_bounds__(DSIM_NL) void dsim_env_bwd_kernel(KCommon k, DsimEnvSpec sp, const float* __restrict__ ckpt,
+                                                               const float* __restrict__ actions,
+                                                               const float* __restrict__ q_out,
+                                                               const float* __restrict__ qd_out,
+                                                               const float* __restrict__ gq_out,
+                                                               const float* __restrict__ gqd_out,
+                                                               const float* __restrict__ gobs,
+                                                               const float* __restrict__ grew, float* gq_in,
+                                                               float* gqd_in, float* gactions) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int e = blockIdx.x;
+    if (e >= k.n_envs) return;
+    load_constants(lds, k);
+    DsimCtx c = make_ctx(lds, k);
+    DevExec ex;
+    const size_t nq = k.d.nq, nd = k.d.nd;
+    dsim_env_fused_backward(c, ex, sp, k.substeps, k.mm_freq, ckpt + (size_t)e * k.substeps * (nq + nd),
+                            actions + (size_t)e * sp.n_act, q_out + e * nq, qd_out + e * nd, gq_out + e * nq,
+                            gqd_out + e * nd, gobs + (size_t)e * sp.n_obs, grew + e, gq_in + e * nq, gqd_in + e * nd,
+                            gactions + (size_t)e * sp.n_act);
+}
+
+__global__ __launch_bounds__(DSIM_NL) void dsim_env_obs_kernel(KCommon k, DsimEnvSpec sp, const float* __restrict__ q,
+                                                               const float* __restrict__ qd,
+                                                               const float* __restrict__ stored, float* obs,
+                                                               float* rew) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int e = blockIdx.x;
+    if (e >= k.n_envs) return;
+    DsimCtx c = make_ctx(lds, k);
+    DevExec ex;
+    dsim_env_observe_only(c, ex, sp, q + (size_t)e * k.d.nq, qd + (size_t)e * k.d.nd, stored + (size_t)e * sp.n_act,
+                          obs + (size_t)e * sp.n_obs, rew + e);
+}
+
 thread_local std::string g_err;
 
 int fail(int code, const std::string& msg) {
@@ -134,6 +194,9 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
     if (bytes > 64 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsim_bwd_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsim_env_bwd_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) {
             hipFree(m->d_cblob);
             delete m;
@@ -143,6 +206,12 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
     if (m->lay.o.fwd_words * 4 > 64 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsim_fwd_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, m->lay.o.fwd_words * 4);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsim_env_fwd_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, m->lay.o.fwd_words * 4);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsim_env_obs_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, m->lay.o.fwd_words * 4);
         if (e != hipSuccess) {
             hipFree(m->d_cblob);
             delete m;
@@ -210,6 +279,91 @@ int dsim_step_backward(const dsim_model* m, int n_envs, const float* ckpt, const
                        muscle_act, gq_out, gqd_out, gq_in, gqd_in, gact, gmuscle_act);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "launch dsim_bwd_kernel");
+    return DSIM_OK;
+}
+
+static int make_spec(const dsim_model* m, const dsim_env_spec* e, DsimEnvSpec& sp) {
+    if (!e) return fail(DSIM_ERR_INVALID, "null env spec");
+    const DsimDims& d = m->lay.d;
+    if (e->kind != DSIM_ENV_LOCOMOTION && e->kind != DSIM_ENV_CARTPOLE) return fail(DSIM_ERR_INVALID, "unknown env kind");
+    if (e->n_act <= 0 || e->n_act > (d.M > d.nd ? d.M : d.nd)) return fail(DSIM_ERR_INVALID, "n_act out of range");
+    if (!e->act_scale) return fail(DSIM_ERR_INVALID, "null act_scale");
+    if (e->act_muscle) {
+        if (e->n_act != d.M) return fail(DSIM_ERR_INVALID, "muscle actions must match the muscle count");
+    } else if (e->act_offset < 0 || e->act_offset + e->n_act > d.nd) {
+        return fail(DSIM_ERR_INVALID, "action dofs out of range");
+    }
+    int expect;
+    if (e->kind == DSIM_ENV_LOCOMOTION) {
+        if (d.nq < 7 || d.nd < 6 || m->lay.cblob[m->lay.o.jtype] != DSIM_JOINT_FREE)
+            return fail(DSIM_ERR_INVALID, "locomotion observations need a free-floating root joint");
+        expect = 13 + (d.nq - 7) + (d.nd - 6) + (e->obs_actions ? e->n_act : 0);
+    } else {
+        if (d.nq != 2 || d.nd != 2) return fail(DSIM_ERR_INVALID, "cartpole observations need 2 coordinates");
+        expect = 5;
+    }
+    if (e->n_obs != expect) return fail(DSIM_ERR_INVALID, "n_obs does not match the observation layout");
+    sp.kind = e->kind; sp.rew_kind = e->rew_kind; sp.n_act = e->n_act; sp.n_obs = e->n_obs;
+    sp.act_offset = e->act_offset; sp.act_muscle = e->act_muscle; sp.obs_actions = e->obs_actions;
+    for (int k = 0; k < 4; ++k) { sp.isr[k] = e->inv_start_rot[k]; sp.pen[k] = e->cartpole_penalties[k]; }
+    sp.tgt_x = e->target_x; sp.tgt_z = e->target_z; sp.term_h = e->termination_height;
+    sp.term_tol = e->termination_tolerance; sp.h_scale = e->height_rew_scale; sp.act_pen = e->action_penalty;
+    sp.vel_scale = e->joint_vel_obs_scaling; sp.act_scale = e->act_scale;
+    return DSIM_OK;
+}
+
+int dsim_env_step_forward(const dsim_model* m, const dsim_env_spec* env, int n_envs, const float* q_in,
+                          const float* qd_in, const float* actions, float dt, int substeps, int mm_freq, float* q_out,
+                          float* qd_out, float* obs, float* rew, float* ckpt, void* hip_stream) {
+    KCommon k;
+    int rc = make_common(m, n_envs, dt, substeps, mm_freq, k);
+    if (rc) return rc;
+    DsimEnvSpec sp;
+    rc = make_spec(m, env, sp);
+    if (rc) return rc;
+    if (!q_in || !qd_in || !actions || !q_out || !qd_out || !obs || !rew) return fail(DSIM_ERR_INVALID, "null pointer");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipLaunchKernelGGL(dsim_env_fwd_kernel, dim3(n_envs), dim3(DSIM_NL), (size_t)k.o.fwd_words * 4, st, k, sp, q_in,
+                       qd_in, actions, q_out, qd_out, obs, rew, ckpt);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch dsim_env_fwd_kernel");
+    return DSIM_OK;
+}
+
+int dsim_env_step_backward(const dsim_model* m, const dsim_env_spec* env, int n_envs, const float* ckpt,
+                           const float* actions, const float* q_out, const float* qd_out, float dt, int substeps,
+                           int mm_freq, const float* gq_out, const float* gqd_out, const float* gobs, const float* grew,
+                           float* gq_in, float* gqd_in, float* gactions, void* hip_stream) {
+    KCommon k;
+    int rc = make_common(m, n_envs, dt, substeps, mm_freq, k);
+    if (rc) return rc;
+    DsimEnvSpec sp;
+    rc = make_spec(m, env, sp);
+    if (rc) return rc;
+    if (!ckpt || !actions || !q_out || !qd_out || !gq_out || !gqd_out || !gobs || !grew || !gq_in || !gqd_in || !gactions)
+        return fail(DSIM_ERR_INVALID, "null pointer");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipLaunchKernelGGL(dsim_env_bwd_kernel, dim3(n_envs), dim3(DSIM_NL), (size_t)k.o.total_words * 4, st, k, sp, ckpt,
+                       actions, q_out, qd_out, gq_out, gqd_out, gobs, grew, gq_in, gqd_in, gactions);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch dsim_env_bwd_kernel");
+    return DSIM_OK;
+}
+
+int dsim_env_observe(const dsim_model* m, const dsim_env_spec* env, int n_envs, const float* q, const float* qd,
+                     const float* stored_actions, float* obs, float* rew, void* hip_stream) {
+    KCommon k;
+    int rc = make_common(m, n_envs, 1.0f, 1, 1, k);
+    if (rc) return rc;
+    DsimEnvSpec sp;
+    rc = make_spec(m, env, sp);
+    if (rc) return rc;
+    if (!q || !qd || !stored_actions || !obs || !rew) return fail(DSIM_ERR_INVALID, "null pointer");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipLaunchKernelGGL(dsim_env_obs_kernel, dim3(n_envs), dim3(DSIM_NL), (size_t)k.o.fwd_words * 4, st, k, sp, q, qd,
+                       stored_actions, obs, rew);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "launch dsim_env_obs_kernel");
     return DSIM_OK;
 }
 

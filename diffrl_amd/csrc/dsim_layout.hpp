@@ -36,11 +36,11 @@ struct DsimOff {
     int cpoint, cdist, cmat, grav, mpoints;
     int const_words;
     // ---- forward work arrays (floats)
-    int q, qd, act, mact, xsj, xsc, pm, S, vj, v, a, i10, f, ftot, cw, tau, qdd, ic10, F, hinv, prow, pcol, mus;
+    int q, qd, act, mact, ua, obs, xsj, xsc, pm, S, vj, v, a, i10, f, ftot, cw, tau, qdd, ic10, F, hinv, prow, pcol, mus;
     int fwd_words;
     // ---- adjoint work arrays (floats)
     int aq, aqd, aqn, aqdn, aact, amact, aqdd, atau, aS, aftot, af, acx, axsc, axsj, ac, av, aa, aatot, avtot, avj,
-        ai10, ai10m, aic10, aH, topar, amus;
+        ai10, ai10m, aic10, aH, topar, amus, gua;
     int total_words;
 };
 
@@ -235,6 +235,7 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
         return off;
     };
     o.q = take(nq); o.qd = take(nd); o.act = take(nd); o.mact = take(M);
+    o.ua = take(M > nd ? M : nd); o.obs = take(16 + nq + nd + (M > nd ? M : nd));
     o.xsj = take(7 * L); o.xsc = take(7 * L); o.pm = take(3 * L); o.S = take(6 * nd);
     o.vj = take(6 * L); o.v = take(6 * L); o.a = take(6 * L); o.i10 = take(10 * L);
     o.f = take(6 * L); o.ftot = take(6 * L); o.cw = take(6 * C); o.tau = take(nd); o.qdd = take(nd);
@@ -246,7 +247,7 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.acx = take(13 * C); o.axsc = take(7 * L); o.axsj = take(7 * L); o.ac = take(3 * L);
     o.av = take(6 * L); o.aa = take(6 * L); o.aatot = take(6 * L); o.avtot = take(6 * L); o.avj = take(6 * L);
     o.ai10 = take(10 * L); o.ai10m = take(10 * L); o.aic10 = take(10 * L); o.aH = take(nd * nd);
-    o.topar = take(7 * L); o.amus = take(15 * NS);
+    o.topar = take(7 * L); o.amus = take(15 * NS); o.gua = take(M > nd ? M : nd);
     o.total_words = cur;
 
     out.o = o;

@@ -85,6 +85,79 @@ class Engine:
         return gq, gqd, gact, gm
 
 
+    # ---- fused environment surface ------------------------------------------------------------------
+    def env_forward(self, spec, q, qd, actions, dt, substeps, mm_freq, need_ckpt):
+        self._check(q, self.n_q, "joint_q")
+        self._check(qd, self.n_qd, "joint_qd")
+        self._check(actions, spec.n_act, "actions")
+        n = q.numel() // self.n_q
+        if qd.numel() != n * self.n_qd or actions.numel() != n * spec.n_act:
+            raise capi.DsimError("state / action tensors disagree on the number of environments")
+        q_out, qd_out = torch.empty_like(q), torch.empty_like(qd)
+        obs = torch.empty((n, spec.n_obs), dtype=torch.float32, device=self.device)
+        rew = torch.empty(n, dtype=torch.float32, device=self.device)
+        ckpt = torch.empty((n, substeps, self.n_q + self.n_qd), dtype=torch.float32, device=self.device) if need_ckpt else None
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            capi.check(self._lib.dsim_env_step_forward(self._h, C.byref(spec), n, _ptr(q), _ptr(qd), _ptr(actions),
+                                                       C.c_float(dt), substeps, mm_freq, _ptr(q_out), _ptr(qd_out),
+                                                       _ptr(obs), _ptr(rew), _ptr(ckpt), st))
+        return q_out, qd_out, obs, rew, ckpt
+
+    def env_backward(self, spec, ckpt, actions, q_out, qd_out, dt, substeps, mm_freq, gq_out, gqd_out, gobs, grew):
+        n = ckpt.shape[0]
+        gq = torch.empty(n * self.n_q, dtype=torch.float32, device=self.device)
+        gqd = torch.empty(n * self.n_qd, dtype=torch.float32, device=self.device)
+        ga = torch.empty((n, spec.n_act), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            capi.check(self._lib.dsim_env_step_backward(self._h, C.byref(spec), n, _ptr(ckpt), _ptr(actions), _ptr(q_out),
+                                                        _ptr(qd_out), C.c_float(dt), substeps, mm_freq, _ptr(gq_out),
+                                                        _ptr(gqd_out), _ptr(gobs), _ptr(grew), _ptr(gq), _ptr(gqd),
+                                                        _ptr(ga), st))
+        return gq, gqd, ga
+
+    def env_observe(self, spec, q, qd, stored_actions):
+        n = q.numel() // self.n_q
+        obs = torch.empty((n, spec.n_obs), dtype=torch.float32, device=self.device)
+        rew = torch.empty(n, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            capi.check(self._lib.dsim_env_observe(self._h, C.byref(spec), n, _ptr(q), _ptr(qd), _ptr(stored_actions),
+                                                  _ptr(obs), _ptr(rew), st))
+        return obs, rew
+
+
+class EnvStep(torch.autograd.Function):
+    """Fused env.step(): (joint_q, joint_qd, actions) -> (joint_q', joint_qd', obs, rew); ONE launch each way."""
+
+    @staticmethod
+    def forward(ctx, engine, spec, dt, substeps, mm_freq, q, qd, actions):
+        q, qd, actions = q.contiguous(), qd.contiguous(), actions.contiguous()
+        need = q.requires_grad or qd.requires_grad or actions.requires_grad
+        q_out, qd_out, obs, rew, ckpt = engine.env_forward(spec, q.detach(), qd.detach(), actions.detach(), dt, substeps,
+                                                           mm_freq, need)
+        ctx.engine, ctx.spec, ctx.dt, ctx.substeps, ctx.mm_freq = engine, spec, dt, substeps, mm_freq
+        ctx.shapes = (q.shape, qd.shape, actions.shape)
+        if need:
+            ctx.save_for_backward(ckpt, actions.detach(), q_out, qd_out)
+        return q_out.view(q.shape), qd_out.view(qd.shape), obs, rew
+
+    @staticmethod
+    def backward(ctx, gq_out, gqd_out, gobs, grew):
+        ckpt, actions, q_out, qd_out = ctx.saved_tensors
+        dev = ckpt.device
+        n = ckpt.shape[0]
+        z = lambda shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
+        gq_out = gq_out.contiguous() if gq_out is not None else z(ctx.shapes[0])
+        gqd_out = gqd_out.contiguous() if gqd_out is not None else z(ctx.shapes[1])
+        gobs = gobs.contiguous() if gobs is not None else z((n, ctx.spec.n_obs))
+        grew = grew.contiguous() if grew is not None else z((n,))
+        gq, gqd, ga = ctx.engine.env_backward(ctx.spec, ckpt, actions, q_out, qd_out, ctx.dt, ctx.substeps, ctx.mm_freq,
+                                              gq_out, gqd_out, gobs, grew)
+        return None, None, None, None, None, gq.view(ctx.shapes[0]), gqd.view(ctx.shapes[1]), ga.view(ctx.shapes[2])
+
+
 class SimStep(torch.autograd.Function):
     """(joint_q, joint_qd, joint_act, muscle_activation) -> (joint_q', joint_qd') for one env.step()."""
 

@@ -23,6 +23,7 @@ class AntEnv(FloatingBaseEnv):
         super().__init__(num_envs, 37, 8, episode_length, MM_caching_frequency, seed, no_grad, render, device)
         self.stochastic_init = stochastic_init
         self.early_termination = early_termination
+        self.height_terminate = bool(early_termination)
         self._setup_frames()
         builder = self.make_builder()
         self._place_root(builder)
@@ -41,6 +42,11 @@ class AntEnv(FloatingBaseEnv):
         lu.parse_mjcf(xml, b, density=1000.0, stiffness=0.0, damping=1.0, contact_ke=4.e+4, contact_kd=1.e+4,
                       contact_kf=3.e+3, contact_mu=0.75, limit_ke=1.e+3, limit_kd=1.e+1, armature=0.05)
         return b
+
+    def fused_spec(self):
+        from .. import capi
+        return self._locomotion_spec(capi.REW_ANT, torch.full((8,), self.action_strength),
+                                     action_penalty=self.action_penalty)
 
     def apply_actions(self, actions):
         self.actions = actions.clone()

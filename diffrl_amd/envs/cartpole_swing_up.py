@@ -43,6 +43,17 @@ class CartPoleSwingUpEnv(DFlexEnv):
         lu.urdf_load(b, urdf, base, floating=False, shape_kd=1e4, limit_kd=1.0)
         return b
 
+    def fused_spec(self):
+        from .. import capi
+        self._act_scale_dev = torch.full((1,), self.action_strength, device=self.device)
+        return capi.make_env_spec(capi.ENV_CARTPOLE, capi.REW_CARTPOLE, 1, 5, self._act_scale_dev.data_ptr(),
+                                  action_penalty=self.cart_action_penalty,
+                                  cartpole_penalties=(self.pole_angle_penalty, self.pole_velocity_penalty,
+                                                      self.cart_position_penalty, self.cart_velocity_penalty))
+
+    def _may_reset(self):
+        return getattr(self, "_progress_hi", 0) > self.episode_length - 1
+
     def apply_actions(self, actions):
         self.actions = actions
         self.state.joint_act.view(self.num_envs, -1)[:, 0:1] = actions * self.action_strength

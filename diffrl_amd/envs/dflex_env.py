@@ -15,7 +15,9 @@ import os
 import numpy as np
 import torch
 
+from .. import capi
 from .. import dflex as df
+from ..engine import EnvStep
 
 ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
 
@@ -44,6 +46,7 @@ class DFlexEnv:
     sim_substeps = 16
     sanitize_grads = False   # nan_to_num hooks on the state / action gradients (humanoid.py:195-206)
     keep_act_on_clear = False
+    fused = os.environ.get("DIFFRL_AMD_UNFUSED", "0") != "1"   # one launch per env.step
 
     def __init__(self, num_envs, num_obs, num_act, episode_length, MM_caching_frequency=1, seed=0, no_grad=True,
                  render=False, device="cuda:0"):
@@ -106,6 +109,79 @@ class DFlexEnv:
     def _qd(self):
         return self.state.joint_qd.view(self.num_envs, -1)
 
+    # ---- fused path: action mapping + observation + reward inside the step kernels ---------------
+    def fused_spec(self):
+        """capi.EnvSpec describing this environment's action mapping / observation / reward, or None."""
+        return None
+
+    def _spec(self):
+        if getattr(self, "_spec_cache", None) is None:
+            self._spec_cache = self.fused_spec()
+        return self._spec_cache
+
+    def stored_actions(self, actions):
+        """what the environment keeps as self.actions for raw policy actions (clipped, maybe remapped)"""
+        return torch.clip(actions, -1.0, 1.0)
+
+    def _may_reset(self):
+        """False when no environment can possibly be flagged this step (skips the device->host sync)."""
+        return True
+
+    def _step_fused(self, actions, spec):
+        actions = actions.view((self.num_envs, self.num_actions))
+        if self.sanitize_grads:
+            def scrub(grad):
+                return torch.nan_to_num(grad, 0.0, 0.0, 0.0)
+            for t in (self.state.joint_q, self.state.joint_qd, actions):
+                if t.requires_grad:
+                    t.register_hook(scrub)
+        eng = self.model.engine()
+        if self.no_grad:
+            with torch.no_grad():
+                q, qd, obs, rew, _ = eng.env_forward(spec, self.state.joint_q.contiguous(), self.state.joint_qd.contiguous(),
+                                                     actions.contiguous(), float(self.sim_dt), self.sim_substeps,
+                                                     self.MM_caching_frequency, False)
+        else:
+            q, qd, obs, rew = EnvStep.apply(eng, spec, float(self.sim_dt), self.sim_substeps, self.MM_caching_frequency,
+                                            self.state.joint_q, self.state.joint_qd, actions)
+        st = df.State()
+        st.joint_q, st.joint_qd = q, qd
+        st.joint_act = torch.zeros_like(self.model.joint_qd)
+        self.state = st
+        if spec.obs_actions:
+            self.actions = obs[:, self.num_observations - self.num_actions:]
+        else:
+            self.actions = self.stored_actions(actions)
+        self.obs_buf, self.rew_buf = obs, rew
+        self.sim_time += self.sim_dt
+        self.progress_buf += 1
+        self._progress_hi = getattr(self, "_progress_hi", 0) + 1
+        self.num_frames += 1
+        if self._may_reset():
+            self.reset_buf = torch.zeros_like(self.reset_buf)
+            self.flag_resets()
+            env_ids = self.reset_buf.nonzero(as_tuple=False).squeeze(-1)
+        else:
+            self.reset_buf = self._zeros_long()
+            env_ids = ()
+        if not self.no_grad:
+            self.obs_buf_before_reset = self.obs_buf
+            self.extras = {"obs_before_reset": self.obs_buf_before_reset, "episode_end": self.termination_buf}
+        if len(env_ids) > 0:
+            self.reset(env_ids)
+        return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def _zeros_long(self):
+        z = getattr(self, "_zl", None)
+        if z is None:
+            z = self._zl = torch.zeros(self.num_envs, device=self.device, dtype=torch.long)
+        return z
+
+    def flag_resets(self):
+        """sets reset_buf from obs_buf / progress_buf (the tail of the reference's calculateReward)"""
+        self.reset_buf = torch.where(self.progress_buf > self.episode_length - 1, torch.ones_like(self.reset_buf),
+                                     self.reset_buf)
+
     # ---- hooks an environment implements ---------------------------------------------------------
     def apply_actions(self, actions):
         raise NotImplementedError
@@ -124,6 +200,9 @@ class DFlexEnv:
 
     # ---- the protocol ------------------------------------------------------------------------------
     def step(self, actions):
+        spec = self._spec() if (self.fused and torch.device(self.device).type == "cuda") else None
+        if spec is not None:
+            return self._step_fused(actions, spec)
         actions = torch.clip(actions.view((self.num_envs, self.num_actions)), -1.0, 1.0)
         if self.sanitize_grads:
             def scrub(grad):
@@ -157,6 +236,8 @@ class DFlexEnv:
             self.state.joint_qd = self.state.joint_qd.clone()
             self.reset_state(env_ids)
             self.progress_buf[env_ids] = 0
+            if len(env_ids) == self.num_envs:
+                self._progress_hi = 0
             self.calculateObservations()
         return self.obs_buf
 
@@ -172,6 +253,8 @@ class DFlexEnv:
             if act is not None:
                 self.state.joint_act = act
             self.actions = checkpoint["actions"].clone()
+            if not torch.equal(self.progress_buf, checkpoint["progress_buf"]):
+                self._progress_hi = int(checkpoint["progress_buf"].max())
             self.progress_buf = checkpoint["progress_buf"].clone()
 
     def initialize_trajectory(self):

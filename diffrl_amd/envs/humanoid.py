@@ -48,6 +48,12 @@ class HumanoidEnv(FloatingBaseEnv):
                       load_armature=True)
         return b
 
+    def fused_spec(self):
+        from .. import capi
+        return self._locomotion_spec(capi.REW_HUMANOID, self.motor_scale * self.strengths[0],
+                                     termination_tolerance=self.termination_tolerance,
+                                     height_rew_scale=self.height_rew_scale, action_penalty=self.action_penalty)
+
     def apply_actions(self, actions):
         self.actions = actions.clone()
         self.state.joint_act.view(self.num_envs, -1)[:, 6:] = actions * self.motor_scale * self.strengths

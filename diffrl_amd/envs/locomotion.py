@@ -75,7 +75,26 @@ class FloatingBaseEnv(DFlexEnv):
         if self.obs_has_actions:
             parts.append(self.actions.clone())
         self.obs_buf = torch.cat(parts, dim=-1)
-        self._i_up = 11 + (self.num_joint_q - 7) + (self.num_joint_qd - 6)
+
+    height_terminate = True
+
+    def _may_reset(self):
+        return (self.height_terminate or self.check_invalid or
+                getattr(self, "_progress_hi", 0) > self.episode_length - 1)
+
+    def flag_resets(self):
+        self._flag_resets(self.height_terminate)
+
+    def _locomotion_spec(self, rew_kind, act_scale, act_offset=6, act_muscle=False, **kw):
+        from .. import capi
+        self._act_scale_dev = act_scale.to(self.device).float().contiguous()
+        isr = self.inv_start_rot[0].tolist()
+        tgt = (self.targets[0] + self.start_pos[0]).tolist()
+        return capi.make_env_spec(capi.ENV_LOCOMOTION, rew_kind, self.num_actions, self.num_observations,
+                                  self._act_scale_dev.data_ptr(), act_offset=act_offset, act_muscle=act_muscle,
+                                  obs_actions=self.obs_has_actions, inv_start_rot=isr, target_xz=(tgt[0], tgt[2]),
+                                  termination_height=self.termination_height,
+                                  joint_vel_obs_scaling=self.joint_vel_obs_scaling, **kw)
 
     def _flag_resets(self, height_terminate=True):
         if height_terminate:

@@ -58,6 +58,14 @@ class SNUHumanoidEnv(FloatingBaseEnv):
                         contact_kf=1e3, contact_mu=0.5, limit_ke=1e3, limit_kd=1e1, armature=0.05)
         return b, [m.muscle_strength for m in s.muscles]
 
+    def fused_spec(self):
+        from .. import capi
+        return self._locomotion_spec(capi.REW_SNU, self.muscle_strengths[:self.num_muscles], act_offset=0,
+                                     act_muscle=True, action_penalty=self.action_penalty)
+
+    def stored_actions(self, actions):
+        return torch.clip(actions, -1.0, 1.0) * 0.5 + 0.5
+
     def apply_actions(self, actions):
         actions = actions * 0.5 + 0.5
         self.actions = actions.clone()

@@ -119,6 +119,49 @@ int dsim_step_backward(const dsim_model* m, int n_envs,
                        const float* gq_out, const float* gqd_out,
                        float* gq_in, float* gqd_in, float* gact, float* gmuscle_act, void* hip_stream);
 
+/* ---- fused environment surface -------------------------------------
+ * The per-step torch glue of the reference environments -- action clip + scale into joint_act /
+ * muscle activations (envs/ant.py:157-163, humanoid.py:188-211, snu_humanoid.py:245-271,
+ * cartpole_swing_up.py:115-120), calculateObservations and calculateReward (ant.py:266-303,
+ * humanoid.py:314-354, snu_humanoid.py:376-414, cartpole_swing_up.py:204-222) -- evaluated inside the
+ * step kernels, adjoint included, so that one env.step() is ONE launch forward and ONE backward. */
+#define DSIM_ENV_LOCOMOTION 1 /* free root: [h, quat(4), lin vel(3), ang vel(3), q[7:], s*qd[6:], up, heading, (actions)] */
+#define DSIM_ENV_CARTPOLE 2   /* [x, xdot, sin th, cos th, thdot] */
+#define DSIM_REW_ANT 0
+#define DSIM_REW_HUMANOID 1
+#define DSIM_REW_SNU 2
+#define DSIM_REW_CARTPOLE 3
+
+typedef struct dsim_env_spec {
+    int32_t kind, rew_kind;
+    int32_t n_act, n_obs;
+    int32_t act_offset;   /* joint_act[act_offset + k] = clip(a_k,-1,1) * act_scale[k]        (act_muscle == 0) */
+    int32_t act_muscle;   /* muscle_act[k] = (clip(a_k,-1,1) * 0.5 + 0.5) * act_scale[k]      (act_muscle == 1) */
+    int32_t obs_actions;  /* observation ends with the stored actions */
+    float inv_start_rot[4];
+    float target_x, target_z;      /* targets + start_pos */
+    float termination_height, termination_tolerance, height_rew_scale, action_penalty, joint_vel_obs_scaling;
+    float cartpole_penalties[4];   /* pole angle, pole velocity, cart position, cart velocity */
+    const float* act_scale;        /* [n_act] DEVICE pointer, borrowed per call */
+} dsim_env_spec;
+
+/* actions[N][n_act] -> q_out, qd_out, obs[N][n_obs], rew[N]  (+ ckpt as in dsim_step_forward) */
+int dsim_env_step_forward(const dsim_model* m, const dsim_env_spec* env, int n_envs,
+                          const float* q_in, const float* qd_in, const float* actions,
+                          float dt, int substeps, int mm_freq,
+                          float* q_out, float* qd_out, float* obs, float* rew, float* ckpt, void* hip_stream);
+
+/* cotangents (gq_out, gqd_out, gobs, grew) -> (gq_in, gqd_in, gactions).  q_out/qd_out: the forward outputs. */
+int dsim_env_step_backward(const dsim_model* m, const dsim_env_spec* env, int n_envs,
+                           const float* ckpt, const float* actions, const float* q_out, const float* qd_out,
+                           float dt, int substeps, int mm_freq,
+                           const float* gq_out, const float* gqd_out, const float* gobs, const float* grew,
+                           float* gq_in, float* gqd_in, float* gactions, void* hip_stream);
+
+/* observation + reward of a given state with given stored actions (reset / initialize_trajectory path) */
+int dsim_env_observe(const dsim_model* m, const dsim_env_spec* env, int n_envs, const float* q, const float* qd,
+                     const float* stored_actions, float* obs, float* rew, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

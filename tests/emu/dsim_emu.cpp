@@ -97,3 +97,55 @@ extern "C" int dsim_emu_step_backward(const dsim_model_desc* m, int n_envs, cons
     }
     return 0;
 }
+
+// ---- fused env surface (host lane-serial) ----
+static DsimEnvSpec to_spec(const dsim_env_spec* e) {
+    DsimEnvSpec sp;
+    sp.kind = e->kind; sp.rew_kind = e->rew_kind; sp.n_act = e->n_act; sp.n_obs = e->n_obs;
+    sp.act_offset = e->act_offset; sp.act_muscle = e->act_muscle; sp.obs_actions = e->obs_actions;
+    for (int k = 0; k < 4; ++k) { sp.isr[k] = e->inv_start_rot[k]; sp.pen[k] = e->cartpole_penalties[k]; }
+    sp.tgt_x = e->target_x; sp.tgt_z = e->target_z; sp.term_h = e->termination_height;
+    sp.term_tol = e->termination_tolerance; sp.h_scale = e->height_rew_scale; sp.act_pen = e->action_penalty;
+    sp.vel_scale = e->joint_vel_obs_scaling; sp.act_scale = e->act_scale;
+    return sp;
+}
+
+extern "C" int dsim_emu_env_forward(const dsim_model_desc* m, const dsim_env_spec* env, int n_envs, const float* q_in,
+                                    const float* qd_in, const float* actions, float dt, int substeps, int mm_freq,
+                                    float* q_out, float* qd_out, float* obs, float* rew, float* ckpt) {
+    DsimLayout lay;
+    if (!dsim_build_layout(*m, lay).empty()) return -1;
+    const int nq = lay.d.nq, nd = lay.d.nd;
+    DsimEnvSpec sp = to_spec(env);
+    HostExec ex;
+    for (int e = 0; e < n_envs; ++e) {
+        std::vector<float> lds;
+        DsimCtx c;
+        make_ctx(lay, lds, c, dt / float(substeps));
+        dsim_env_fused_forward(c, ex, sp, substeps, mm_freq, q_in + (size_t)e * nq, qd_in + (size_t)e * nd,
+                               actions + (size_t)e * sp.n_act, q_out + (size_t)e * nq, qd_out + (size_t)e * nd,
+                               obs + (size_t)e * sp.n_obs, rew + e, ckpt ? ckpt + (size_t)e * substeps * (nq + nd) : nullptr);
+    }
+    return 0;
+}
+
+extern "C" int dsim_emu_env_backward(const dsim_model_desc* m, const dsim_env_spec* env, int n_envs, const float* ckpt,
+                                     const float* actions, const float* q_out, const float* qd_out, float dt,
+                                     int substeps, int mm_freq, const float* gq_out, const float* gqd_out,
+                                     const float* gobs, const float* grew, float* gq_in, float* gqd_in, float* gactions) {
+    DsimLayout lay;
+    if (!dsim_build_layout(*m, lay).empty()) return -1;
+    const int nq = lay.d.nq, nd = lay.d.nd;
+    DsimEnvSpec sp = to_spec(env);
+    HostExec ex;
+    for (int e = 0; e < n_envs; ++e) {
+        std::vector<float> lds;
+        DsimCtx c;
+        make_ctx(lay, lds, c, dt / float(substeps));
+        dsim_env_fused_backward(c, ex, sp, substeps, mm_freq, ckpt + (size_t)e * substeps * (nq + nd),
+                                actions + (size_t)e * sp.n_act, q_out + (size_t)e * nq, qd_out + (size_t)e * nd,
+                                gq_out + (size_t)e * nq, gqd_out + (size_t)e * nd, gobs + (size_t)e * sp.n_obs, grew + e,
+                                gq_in + (size_t)e * nq, gqd_in + (size_t)e * nd, gactions + (size_t)e * sp.n_act);
+    }
+    return 0;
+}

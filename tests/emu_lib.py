@@ -89,3 +89,63 @@ def emu_backward(t, ckpt, act, mact, dt, substeps, mm_freq, gq_out, gqd_out):
                                       _p(ga), _p(gm))
     assert rc == 0
     return dict(gq=gq, gqd=gqd, gact=ga, gmact=gm)
+
+
+# ---- fused env surface ------------------------------------------------------------------------------
+def env_spec_for(env_name, t):
+    """(capi.EnvSpec, keepalive) with the constants of diffrl_amd.envs.<env> (host act_scale array)."""
+    import math
+
+    from diffrl_amd import capi
+    from diffrl_amd.dflex import util as U
+    if env_name == "cartpole":
+        sc = np.full(1, 1000.0, np.float32)
+        return capi.make_env_spec(capi.ENV_CARTPOLE, capi.REW_CARTPOLE, 1, 5, sc.ctypes.data, action_penalty=0.0,
+                                  cartpole_penalties=(1.0, 0.1, 0.05, 0.1)), sc
+    if env_name == "ant":
+        sr, h, tgt = U.quat_from_axis_angle((1.0, 0.0, 0.0), -math.pi * 0.5), 0.75, 10000.0
+        sc = np.full(8, 200.0, np.float32)
+        kw = dict(rew=capi.REW_ANT, n_act=8, n_obs=37, off=6, mus=False, oa=True, th=0.27, tol=0.0, hs=0.0, pen=0.0)
+    elif env_name == "humanoid":
+        sr, h, tgt = U.quat_from_axis_angle((1.0, 0.0, 0.0), -math.pi * 0.5), 1.35, 200.0
+        ms = [200, 200, 200, 200, 200, 600, 400, 100, 100, 200, 200, 600, 400, 100, 100, 100, 100, 200, 100, 100, 200]
+        sc = (0.35 * np.array(ms, np.float64)).astype(np.float32)
+        kw = dict(rew=capi.REW_HUMANOID, n_act=21, n_obs=76, off=6, mus=False, oa=True, th=0.74, tol=0.1, hs=10.0,
+                  pen=-0.002)
+    else:
+        sr, h, tgt = U.quat_from_axis_angle((0.0, 1.0, 0.0), math.pi * 0.5), 1.0, 10000.0
+        sc = np.ascontiguousarray(t.extras["muscle_strengths"], np.float32)
+        kw = dict(rew=capi.REW_SNU, n_act=152, n_obs=53, off=0, mus=True, oa=False, th=0.46, tol=0.05, hs=4.0, pen=-0.001)
+    isr = (-sr[0], -sr[1], -sr[2], sr[3])
+    isr = tuple(float(np.float32(v)) for v in isr)
+    spec = capi.make_env_spec(capi.ENV_LOCOMOTION, kw["rew"], kw["n_act"], kw["n_obs"], sc.ctypes.data,
+                              act_offset=kw["off"], act_muscle=kw["mus"], obs_actions=kw["oa"], inv_start_rot=isr,
+                              target_xz=(tgt, 0.0), termination_height=kw["th"], termination_tolerance=kw["tol"],
+                              height_rew_scale=kw["hs"], action_penalty=kw["pen"], joint_vel_obs_scaling=0.1)
+    return spec, sc
+
+
+def emu_env_forward(t, spec, q, qd, actions, dt, substeps, mm_freq):
+    desc, keep = make_desc(t)
+    N = q.shape[0]
+    q, qd, actions = _c(q), _c(qd), _c(actions)
+    qo, qdo = np.zeros_like(q), np.zeros_like(qd)
+    obs, rew = np.zeros((N, spec.n_obs), np.float32), np.zeros(N, np.float32)
+    ck = np.zeros((N, substeps, t.n_q + t.n_qd), np.float32)
+    rc = emu().dsim_emu_env_forward(C.byref(desc), C.byref(spec), C.c_int(N), _p(q), _p(qd), _p(actions), C.c_float(dt),
+                                    C.c_int(substeps), C.c_int(mm_freq), _p(qo), _p(qdo), _p(obs), _p(rew), _p(ck))
+    assert rc == 0
+    return qo, qdo, obs, rew, ck
+
+
+def emu_env_backward(t, spec, ck, actions, q_out, qd_out, dt, substeps, mm_freq, gq_out, gqd_out, gobs, grew):
+    desc, keep = make_desc(t)
+    N = actions.shape[0]
+    args = [_c(a) for a in (ck, actions, q_out, qd_out)]
+    g = [_c(a) for a in (gq_out, gqd_out, gobs, grew)]
+    gq, gqd, ga = np.zeros_like(g[0]), np.zeros_like(g[1]), np.zeros_like(args[1])
+    rc = emu().dsim_emu_env_backward(C.byref(desc), C.byref(spec), C.c_int(N), _p(args[0]), _p(args[1]), _p(args[2]),
+                                     _p(args[3]), C.c_float(dt), C.c_int(substeps), C.c_int(mm_freq), _p(g[0]), _p(g[1]),
+                                     _p(g[2]), _p(g[3]), _p(gq), _p(gqd), _p(ga))
+    assert rc == 0
+    return gq, gqd, ga
