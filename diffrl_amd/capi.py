@@ -115,6 +115,8 @@ def lib():
     L.dsim_version.restype = C.c_int
     L.dsim_model_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp)]
     L.dsim_model_destroy.argtypes = [vp]
+    L.dsim_model_variant.argtypes = [vp]
+    L.dsim_model_variant.restype = C.c_int
     L.dsim_ckpt_floats.argtypes = [vp, C.c_int]
     L.dsim_ckpt_floats.restype = C.c_int64
     L.dsim_step_forward.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp]
@@ -137,6 +139,7 @@ def check(rc):
         raise DsimError("dsim error %d: %s" % (rc, lib().dsim_last_error().decode()))
 
 
-EXPORTS = ("dsim_last_error", "dsim_version", "dsim_model_create", "dsim_model_destroy", "dsim_ckpt_floats",
+EXPORTS = ("dsim_last_error", "dsim_version", "dsim_model_create", "dsim_model_destroy", "dsim_model_variant",
+           "dsim_ckpt_floats",
            "dsim_step_forward", "dsim_step_backward", "dsim_env_step_forward", "dsim_env_step_backward",
            "dsim_env_observe")

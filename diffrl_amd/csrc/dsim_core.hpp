@@ -29,23 +29,56 @@
 
 typedef int __attribute__((may_alias)) dsim_int_a;
 
-struct DsimCtx {
+// O / D are either the runtime structs of dsim_layout.hpp (generic kernels: offsets and sizes live in SGPRs)
+// or generated all-constexpr structs (dsim_static_layouts.hpp: per-model specialised kernels in which every
+// LDS offset is an instruction immediate and every size a compile-time loop bound).
+template <class O, class D> struct DsimCtxT {
     float* s;  // LDS image base
-    DsimOff o;
-    DsimDims d;
+    O o;
+    D d;
     float h;   // substep length
 };
+typedef DsimCtxT<DsimOff, DsimDims> DsimCtx;
 
 #define CI(name) (reinterpret_cast<const dsim_int_a*>(c.s) + c.o.name)
 #define CF(name) (static_cast<const float*>(c.s) + c.o.name)
 #define WF(name) (c.s + c.o.name)
+
+// Small reductions out of LDS.  One wavefront per environment means nothing hides LDS latency except ILP,
+// so the loops are unrolled by four with the loads grouped: (index loads) -> (data loads) -> adds, i.e. two
+// LDS round trips per four terms instead of two per term.  Summation order is unchanged.
+DSIM_FN float dsim_gather_sum(const float* data, int stride, int comp, const dsim_int_a* list, int b0, int b1, float acc) {
+    int e = b0;
+    for (; e + 4 <= b1; e += 4) {
+        const int i0 = list[e], i1 = list[e + 1], i2 = list[e + 2], i3 = list[e + 3];
+        const float x0 = data[stride * i0 + comp], x1 = data[stride * i1 + comp], x2 = data[stride * i2 + comp],
+                    x3 = data[stride * i3 + comp];
+        acc = (((acc + x0) + x1) + x2) + x3;
+    }
+    for (; e < b1; ++e) acc += data[stride * list[e] + comp];
+    return acc;
+}
+DSIM_FN float dsim_dot_n(const float* a, const float* b, int n) {
+    float acc = 0.f;
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {
+        const float a0 = a[j], a1 = a[j + 1], a2 = a[j + 2], a3 = a[j + 3];
+        const float b0 = b[j], b1 = b[j + 1], b2 = b[j + 2], b3 = b[j + 3];
+        acc += a0 * b0;
+        acc += a1 * b1;
+        acc += a2 * b2;
+        acc += a3 * b3;
+    }
+    for (; j < n; ++j) acc += a[j] * b[j];
+    return acc;
+}
 
 // ================================================================================================
 // forward
 // ================================================================================================
 
 // FK + motion subspace + velocities + world inertia + body force, level by level.
-template <class Exec> DSIM_FN void dsim_fwd_kinematics(const DsimCtx& c, Exec& ex) {
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, Exec& ex) {
     const dsim_int_a *jtype = CI(jtype), *parent = CI(parent), *qstart = CI(qstart), *qdstart = CI(qdstart),
                      *lvl_start = CI(lvl_start), *lvl_links = CI(lvl_links);
     for (int lv = 0; lv < c.d.D; ++lv) {
@@ -105,44 +138,52 @@ template <class Exec> DSIM_FN void dsim_fwd_kinematics(const DsimCtx& c, Exec& e
                 }
                 st3(WF(xsc) + 7 * i, pc);
                 stq(WF(xsc) + 7 * i + 3, rc);
-                const v3 cm = rotate(rc, ld3(CF(com) + 3 * i)) + pc;
-                st3(WF(pm) + 3 * i, cm);
                 const sv6 v = vpar + vj;
                 const sv6 a = apar + scross(v, vj);
                 stsv(WF(vj) + 6 * i, vj);
                 stsv(WF(v) + 6 * i, v);
                 stsv(WF(a) + 6 * i, a);
-                // world-frame inertia about the origin: Theta = R Ic R^T, A = Theta + m(c.c 1 - c c^T), h = m c
-                const float* ic = CF(ic6) + 6 * i;
-                const float m = CF(mass)[i];
-                const v3 rx = rotate(rc, mk3(1.f, 0.f, 0.f)), ry = rotate(rc, mk3(0.f, 1.f, 0.f)),
-                         rz = rotate(rc, mk3(0.f, 0.f, 1.f));
-                // B = R * Ic (columns of R are rx, ry, rz)
-                const v3 b0 = rx * ic[0] + ry * ic[1] + rz * ic[2];
-                const v3 b1 = rx * ic[1] + ry * ic[3] + rz * ic[4];
-                const v3 b2 = rx * ic[2] + ry * ic[4] + rz * ic[5];
-                inertia10 I;
-                I.m = m;
-                I.h = cm * m;
-                const float cc = dot(cm, cm);
-                I.axx = b0.x * rx.x + b1.x * ry.x + b2.x * rz.x + m * (cc - cm.x * cm.x);
-                I.axy = b0.x * rx.y + b1.x * ry.y + b2.x * rz.y - m * cm.x * cm.y;
-                I.axz = b0.x * rx.z + b1.x * ry.z + b2.x * rz.z - m * cm.x * cm.z;
-                I.ayy = b0.y * rx.y + b1.y * ry.y + b2.y * rz.y + m * (cc - cm.y * cm.y);
-                I.ayz = b0.y * rx.z + b1.y * ry.z + b2.y * rz.z - m * cm.y * cm.z;
-                I.azz = b0.z * rx.z + b1.z * ry.z + b2.z * rz.z + m * (cc - cm.z * cm.z);
-                st_i10(WF(i10) + 10 * i, I);
-                const sv6 fb = inertia_mul(I, a) + scross_dual(v, inertia_mul(I, v));
-                const v3 mg = ld3(CF(grav)) * m;
-                const sv6 fg = mksv(cross(cm, mg), mg);
-                stsv(WF(f) + 6 * i, fb - fg);
             }
         });
     }
+    // everything that does not feed the next tree level runs ONCE for all links: COM, world inertia, body force
+    ex.run([&](int lane) {
+        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+            const v3 pc = ld3(WF(xsc) + 7 * i);
+            const q4 rc = ldq(WF(xsc) + 7 * i + 3);
+            const sv6 v = ldsv(WF(v) + 6 * i), a = ldsv(WF(a) + 6 * i);
+            const v3 cm = rotate(rc, ld3(CF(com) + 3 * i)) + pc;
+            st3(WF(pm) + 3 * i, cm);
+            // world-frame inertia about the origin: Theta = R Ic R^T, A = Theta + m(c.c 1 - c c^T), h = m c
+            const float* ic = CF(ic6) + 6 * i;
+            const float m = CF(mass)[i];
+            const v3 rx = rotate(rc, mk3(1.f, 0.f, 0.f)), ry = rotate(rc, mk3(0.f, 1.f, 0.f)),
+                     rz = rotate(rc, mk3(0.f, 0.f, 1.f));
+            // B = R * Ic (columns of R are rx, ry, rz)
+            const v3 b0 = rx * ic[0] + ry * ic[1] + rz * ic[2];
+            const v3 b1 = rx * ic[1] + ry * ic[3] + rz * ic[4];
+            const v3 b2 = rx * ic[2] + ry * ic[4] + rz * ic[5];
+            inertia10 I;
+            I.m = m;
+            I.h = cm * m;
+            const float cc = dot(cm, cm);
+            I.axx = b0.x * rx.x + b1.x * ry.x + b2.x * rz.x + m * (cc - cm.x * cm.x);
+            I.axy = b0.x * rx.y + b1.x * ry.y + b2.x * rz.y - m * cm.x * cm.y;
+            I.axz = b0.x * rx.z + b1.x * ry.z + b2.x * rz.z - m * cm.x * cm.z;
+            I.ayy = b0.y * rx.y + b1.y * ry.y + b2.y * rz.y + m * (cc - cm.y * cm.y);
+            I.ayz = b0.y * rx.z + b1.y * ry.z + b2.y * rz.z - m * cm.y * cm.z;
+            I.azz = b0.z * rx.z + b1.z * ry.z + b2.z * rz.z + m * (cc - cm.z * cm.z);
+            st_i10(WF(i10) + 10 * i, I);
+            const sv6 fb = inertia_mul(I, a) + scross_dual(v, inertia_mul(I, v));
+            const v3 mg = ld3(CF(grav)) * m;
+            const sv6 fg = mksv(cross(cm, mg), mg);
+            stsv(WF(f) + 6 * i, fb - fg);
+        }
+    });
 }
 
 // ground contacts (sim.py:1137-1206) and muscle segments (sim.py:1209-1242): per-item wrenches
-template <class Exec> DSIM_FN void dsim_fwd_external(const DsimCtx& c, Exec& ex) {
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Exec& ex) {
     if (c.d.C == 0 && c.d.NS == 0) return;
     ex.run([&](int lane) {
         for (int k = lane; k < c.d.C; k += DSIM_NL) {
@@ -181,42 +222,32 @@ template <class Exec> DSIM_FN void dsim_fwd_external(const DsimCtx& c, Exec& ex)
             const float l = sqrtf(dot(d, d));
             v3 f = zero3();
             if (l > 0.0f) f = d * (WF(mact)[CI(seg_m)[s]] / l);
-            float* o = WF(mus) + 9 * s;
-            st3(o, f);
-            st3(o + 3, pos0);
-            st3(o + 6, pos1);
+            // wrenches on the two links, signs applied: entry code 2s+side indexes 6-float rows
+            float* o = WF(mus) + 12 * s;
+            st3(o, -cross(pos0, f));
+            st3(o + 3, -f);
+            st3(o + 6, cross(pos1, f));
+            st3(o + 9, f);
         }
     });
-    ex.run([&](int lane) {
-        for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
-            const int i = it / 6, k = it - 6 * i;
-            float acc = WF(f)[it];
-            for (int e = CI(cb_start)[i]; e < CI(cb_start)[i + 1]; ++e) acc += WF(cw)[6 * CI(cb_list)[e] + k];
-            for (int e = CI(ml_start)[i]; e < CI(ml_start)[i + 1]; ++e) {
-                const int code = CI(ml_list)[e], s = code >> 1, side = code & 1;
-                const float* o = WF(mus) + 9 * s;
-                const v3 f = ld3(o);
-                float val;
-                if (k >= 3) {
-                    val = o[k - 3];
-                } else {
-                    const v3 t = cross(ld3(o + 3 + 3 * side), f);
-                    val = k == 0 ? t.x : (k == 1 ? t.y : t.z);
-                }
-                acc += side ? val : -val;
+    if (c.d.NS > 0) {
+        ex.run([&](int lane) {
+            for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
+                const int i = it / 6, k = it - 6 * i;
+                WF(f)[it] = dsim_gather_sum(WF(mus), 6, k, CI(ml_list), CI(ml_start)[i], CI(ml_start)[i + 1], WF(f)[it]);
             }
-            WF(f)[it] = acc;
-        }
-    });
+        });
+    }
 }
 
 // joint-space forces (sim.py:1421-1502, 1792-1842)
-template <class Exec> DSIM_FN void dsim_fwd_tau(const DsimCtx& c, Exec& ex) {
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_tau(const Ctx& c, Exec& ex) {
+    // f_tot[i] = sum over subtree(i) of (inverse-dynamics force [+ muscle wrenches, gathered per body]) + contact wrenches
     ex.run([&](int lane) {
         for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
             const int i = it / 6, k = it - 6 * i;
-            float acc = 0.f;
-            for (int e = CI(sub_start)[i]; e < CI(sub_start)[i + 1]; ++e) acc += WF(f)[6 * CI(sub_list)[e] + k];
+            float acc = dsim_gather_sum(WF(f), 6, k, CI(sub_list), CI(sub_start)[i], CI(sub_start)[i + 1], 0.f);
+            acc = dsim_gather_sum(WF(cw), 6, k, CI(scb_list), CI(scb_start)[i], CI(scb_start)[i + 1], acc);
             WF(ftot)[it] = acc;
         }
     });
@@ -242,14 +273,12 @@ template <class Exec> DSIM_FN void dsim_fwd_tau(const DsimCtx& c, Exec& ex) {
 }
 
 // composite inertias Ic[i] = sum over subtree(i), F_b = Ic[link(b)] S_b
-template <class Exec> DSIM_FN void dsim_fwd_composite(const DsimCtx& c, Exec& ex) {
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_composite(const Ctx& c, Exec& ex) {
     const int nd = c.d.nd;
     ex.run([&](int lane) {
         for (int it = lane; it < 10 * c.d.L; it += DSIM_NL) {
             const int i = it / 10, k = it - 10 * i;
-            float acc = 0.f;
-            for (int e = CI(sub_start)[i]; e < CI(sub_start)[i + 1]; ++e) acc += WF(i10)[10 * CI(sub_list)[e] + k];
-            WF(ic10)[it] = acc;
+            WF(ic10)[it] = dsim_gather_sum(WF(i10), 10, k, CI(sub_list), CI(sub_start)[i], CI(sub_start)[i + 1], 0.f);
         }
     });
     ex.run([&](int lane) {
@@ -261,7 +290,7 @@ template <class Exec> DSIM_FN void dsim_fwd_composite(const DsimCtx& c, Exec& ex
 }
 
 // H = J^T M J in composite-rigid-body form + armature, inverted in place (Gauss-Jordan, SPD, no pivoting)
-template <class Exec> DSIM_FN void dsim_fwd_mass(const DsimCtx& c, Exec& ex) {
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_mass(const Ctx& c, Exec& ex) {
     const int nd = c.d.nd;
     dsim_fwd_composite(c, ex);
     ex.run([&](int lane) {
@@ -293,19 +322,17 @@ template <class Exec> DSIM_FN void dsim_fwd_mass(const DsimCtx& c, Exec& ex) {
     }
 }
 
-template <class Exec> DSIM_FN void dsim_fwd_solve(const DsimCtx& c, Exec& ex) {
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_solve(const Ctx& c, Exec& ex) {
     const int nd = c.d.nd;
     ex.run([&](int lane) {
         for (int i = lane; i < nd; i += DSIM_NL) {
-            float acc = 0.f;
-            for (int j = 0; j < nd; ++j) acc += WF(hinv)[i * nd + j] * WF(tau)[j];
-            WF(qdd)[i] = acc;
+            WF(qdd)[i] = dsim_dot_n(WF(hinv) + i * nd, WF(tau), nd);
         }
     });
 }
 
 // semi-implicit Euler (sim.py:1505-1636); in place on q, qd
-template <class Exec> DSIM_FN void dsim_fwd_integrate(const DsimCtx& c, Exec& ex) {
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_integrate(const Ctx& c, Exec& ex) {
     ex.run([&](int lane) {
         const float h = c.h;
         for (int i = lane; i < c.d.L; i += DSIM_NL) {
@@ -339,7 +366,7 @@ template <class Exec> DSIM_FN void dsim_fwd_integrate(const DsimCtx& c, Exec& ex
 }
 
 // one substep on the LDS-resident state
-template <class Exec> DSIM_FN void dsim_fwd_substep(const DsimCtx& c, Exec& ex, bool update_mass) {
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_substep(const Ctx& c, Exec& ex, bool update_mass) {
     dsim_fwd_kinematics(c, ex);
     dsim_fwd_external(c, ex);
     dsim_fwd_tau(c, ex);
@@ -351,8 +378,8 @@ template <class Exec> DSIM_FN void dsim_fwd_substep(const DsimCtx& c, Exec& ex, 
 // ------------------------------------------------------------------------------------------------
 // one env.step(): `substeps` substeps with act / muscle activations held fixed (sim.py:2104-2116).
 // g_* are this environment's rows of the caller's tensors (global memory); ckpt may be null.
-template <class Exec>
-DSIM_FN void dsim_env_step_forward(const DsimCtx& c, Exec& ex, int substeps, int mm_freq, const float* g_q,
+template <class Ctx, class Exec>
+DSIM_FN void dsim_env_step_forward(const Ctx& c, Exec& ex, int substeps, int mm_freq, const float* g_q,
                                    const float* g_qd, const float* g_act, const float* g_mact, float* g_q_out,
                                    float* g_qd_out, float* g_ckpt) {
     const int nq = c.d.nq, nd = c.d.nd, M = c.d.M;
@@ -367,8 +394,8 @@ DSIM_FN void dsim_env_step_forward(const DsimCtx& c, Exec& ex, int substeps, int
     for (int s = 0; s < substeps; ++s) {
         if (g_ckpt) {
             float* ck = g_ckpt + (size_t)s * (nq + nd);
-            // no barrier needed after this phase's global stores, but run() keeps the structure uniform
-            ex.run([&](int lane) {
+            // global stores to a private row: no barrier, no wait -- they drain while the substep computes
+            ex.fire([&](int lane) {
                 for (int k = lane; k < nq; k += DSIM_NL) ck[k] = WF(q)[k];
                 for (int k = lane; k < nd; k += DSIM_NL) ck[nq + k] = WF(qd)[k];
             });
@@ -390,7 +417,7 @@ DSIM_FN void dsim_env_step_forward(const DsimCtx& c, Exec& ex, int substeps, int
 // Postconditions: aq/aqd = cotangents of the substep inputs; aact/amact/aH accumulated.
 
 // integrate^T, solve^T (matnn.h:310-336), tau^T
-template <class Exec> DSIM_FN void dsim_bwd_joint_space(const DsimCtx& c, Exec& ex) {
+template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c, Exec& ex) {
     const int nd = c.d.nd;
     ex.run([&](int lane) {
         const float h = c.h;
@@ -438,9 +465,7 @@ template <class Exec> DSIM_FN void dsim_bwd_joint_space(const DsimCtx& c, Exec& 
     });
     ex.run([&](int lane) {
         for (int i = lane; i < nd; i += DSIM_NL) {
-            float acc = 0.f;
-            for (int j = 0; j < nd; ++j) acc += WF(hinv)[i * nd + j] * WF(aqdd)[j];  // hinv is symmetric
-            WF(atau)[i] = acc;
+            WF(atau)[i] = dsim_dot_n(WF(hinv) + i * nd, WF(aqdd), nd);  // hinv is symmetric
         }
     });
     ex.run([&](int lane) {
@@ -478,15 +503,13 @@ template <class Exec> DSIM_FN void dsim_bwd_joint_space(const DsimCtx& c, Exec& 
     ex.run([&](int lane) {
         for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
             const int j = it / 6, k = it - 6 * j;
-            float acc = 0.f;
-            for (int e = CI(anc_start)[j]; e < CI(anc_start)[j + 1]; ++e) acc += WF(aftot)[6 * CI(anc_list)[e] + k];
-            WF(af)[it] = acc;
+            WF(af)[it] = dsim_gather_sum(WF(aftot), 6, k, CI(anc_list), CI(anc_start)[j], CI(anc_start)[j + 1], 0.f);
         }
     });
 }
 
 // contacts^T and muscles^T: per-item cotangents of (X_sc, v_s) / (X_sc, activation)
-template <class Exec> DSIM_FN void dsim_bwd_external(const DsimCtx& c, Exec& ex) {
+template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external(const Ctx& c, Exec& ex) {
     if (c.d.C == 0 && c.d.NS == 0) return;
     ex.run([&](int lane) {
         for (int k = lane; k < c.d.C; k += DSIM_NL) {
@@ -550,15 +573,17 @@ template <class Exec> DSIM_FN void dsim_bwd_external(const DsimCtx& c, Exec& ex)
         for (int s = lane; s < c.d.NS; s += DSIM_NL) {
             const int w = CI(seg_wp)[s];
             const int l0 = CI(mlinks)[w], l1 = CI(mlinks)[w + 1];
-            const float* mu_ = WF(mus) + 9 * s;
-            const v3 f = ld3(mu_), pos0 = ld3(mu_ + 3), pos1 = ld3(mu_ + 6);
+            const v3 pos0 = ld3(WF(xsc) + 7 * l0) + rotate(ldq(WF(xsc) + 7 * l0 + 3), ld3(CF(mpoints) + 3 * w));
+            const v3 pos1 = ld3(WF(xsc) + 7 * l1) + rotate(ldq(WF(xsc) + 7 * l1 + 3), ld3(CF(mpoints) + 3 * w + 3));
             const float act = WF(mact)[CI(seg_m)[s]];
+            const v3 d = pos1 - pos0;
+            const float l = sqrtf(dot(d, d));
+            v3 f = zero3();
+            if (l > 0.0f) f = d * (act / l);
             const sv6 A0 = ldsv(WF(af) + 6 * l0), A1 = ldsv(WF(af) + 6 * l1);
             const v3 a_f = cross(A1.w, pos1) + A1.v - cross(A0.w, pos0) - A0.v;
             v3 a_p0 = -cross(f, A0.w);
             v3 a_p1 = cross(f, A1.w);
-            const v3 d = pos1 - pos0;
-            const float l = sqrtf(dot(d, d));
             float a_act = 0.f;
             if (l > 0.0f) {
                 const v3 n = d * (1.0f / l);
@@ -568,7 +593,7 @@ template <class Exec> DSIM_FN void dsim_bwd_external(const DsimCtx& c, Exec& ex)
                 a_p1 += a_d;
                 a_p0 -= a_d;
             }
-            float* o = WF(amus) + 15 * s;
+            float* o = WF(mus) + 15 * s;  // the forward wrench rows are dead by now: same buffer
             st3(o, a_p0);
             stq(o + 3, rotate_adj_q(ldq(WF(xsc) + 7 * l0 + 3), ld3(CF(mpoints) + 3 * w), a_p0));
             st3(o + 7, a_p1);
@@ -579,7 +604,7 @@ template <class Exec> DSIM_FN void dsim_bwd_external(const DsimCtx& c, Exec& ex)
 }
 
 // mass matrix^T (update substeps): aH -> aS (added), ai10m
-template <class Exec> DSIM_FN void dsim_bwd_mass(const DsimCtx& c, Exec& ex) {
+template <class Ctx, class Exec> DSIM_FN void dsim_bwd_mass(const Ctx& c, Exec& ex) {
     const int nd = c.d.nd;
     ex.run([&](int lane) {
         for (int a = lane; a < nd; a += DSIM_NL) {
@@ -623,15 +648,13 @@ template <class Exec> DSIM_FN void dsim_bwd_mass(const DsimCtx& c, Exec& ex) {
     ex.run([&](int lane) {
         for (int it = lane; it < 10 * c.d.L; it += DSIM_NL) {
             const int i = it / 10, k = it - 10 * i;
-            float acc = 0.f;
-            for (int e = CI(anc_start)[i]; e < CI(anc_start)[i + 1]; ++e) acc += WF(aic10)[10 * CI(anc_list)[e] + k];
-            WF(ai10m)[it] = acc;
+            WF(ai10m)[it] = dsim_gather_sum(WF(aic10), 10, k, CI(anc_list), CI(anc_start)[i], CI(anc_start)[i + 1], 0.f);
         }
     });
 }
 
 // body level: f^T, velocity/acceleration recursions^T, joint motion^T, pose cotangents, FK^T
-template <class Exec> DSIM_FN void dsim_bwd_bodies(const DsimCtx& c, Exec& ex, bool update_mass) {
+template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec& ex, bool update_mass) {
     ex.run([&](int lane) {
         for (int i = lane; i < c.d.L; i += DSIM_NL) {
             const inertia10 I = ld_i10(WF(i10) + 10 * i);
@@ -662,7 +685,7 @@ template <class Exec> DSIM_FN void dsim_bwd_bodies(const DsimCtx& c, Exec& ex, b
             }
             for (int e = CI(ml_start)[i]; e < CI(ml_start)[i + 1]; ++e) {
                 const int code = CI(ml_list)[e];
-                const float* o = WF(amus) + 15 * (code >> 1) + 7 * (code & 1);
+                const float* o = WF(mus) + 15 * (code >> 1) + 7 * (code & 1);
                 xp += ld3(o);
                 xq += ldq(o + 3);
             }
@@ -672,16 +695,14 @@ template <class Exec> DSIM_FN void dsim_bwd_bodies(const DsimCtx& c, Exec& ex, b
         }
         for (int m = lane; m < c.d.M; m += DSIM_NL) {
             float acc = 0.f;
-            for (int s = CI(ms_start)[m]; s < CI(ms_start)[m + 1]; ++s) acc += WF(amus)[15 * s + 14];
+            for (int s = CI(ms_start)[m]; s < CI(ms_start)[m + 1]; ++s) acc += WF(mus)[15 * s + 14];
             WF(amact)[m] += acc;
         }
     });
     ex.run([&](int lane) {
         for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
             const int i = it / 6, k = it - 6 * i;
-            float acc = 0.f;
-            for (int e = CI(sub_start)[i]; e < CI(sub_start)[i + 1]; ++e) acc += WF(aa)[6 * CI(sub_list)[e] + k];
-            WF(aatot)[it] = acc;
+            WF(aatot)[it] = dsim_gather_sum(WF(aa), 6, k, CI(sub_list), CI(sub_start)[i], CI(sub_start)[i + 1], 0.f);
         }
     });
     ex.run([&](int lane) {
@@ -699,9 +720,7 @@ template <class Exec> DSIM_FN void dsim_bwd_bodies(const DsimCtx& c, Exec& ex, b
     ex.run([&](int lane) {
         for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
             const int i = it / 6, k = it - 6 * i;
-            float acc = 0.f;
-            for (int e = CI(sub_start)[i]; e < CI(sub_start)[i + 1]; ++e) acc += WF(av)[6 * CI(sub_list)[e] + k];
-            WF(avtot)[it] = acc;
+            WF(avtot)[it] = dsim_gather_sum(WF(av), 6, k, CI(sub_list), CI(sub_start)[i], CI(sub_start)[i + 1], 0.f);
         }
     });
     ex.run([&](int lane) {
@@ -832,7 +851,7 @@ template <class Exec> DSIM_FN void dsim_bwd_bodies(const DsimCtx& c, Exec& ex, b
     }
 }
 
-template <class Exec> DSIM_FN void dsim_bwd_substep(const DsimCtx& c, Exec& ex, bool update_mass) {
+template <class Ctx, class Exec> DSIM_FN void dsim_bwd_substep(const Ctx& c, Exec& ex, bool update_mass) {
     dsim_bwd_joint_space(c, ex);
     dsim_bwd_external(c, ex);
     if (update_mass) dsim_bwd_mass(c, ex);
@@ -840,8 +859,8 @@ template <class Exec> DSIM_FN void dsim_bwd_substep(const DsimCtx& c, Exec& ex, 
 }
 
 // Reverse sweep of one env.step().  g_ckpt is this environment's [substeps][nq+nd] checkpoint.
-template <class Exec>
-DSIM_FN void dsim_env_step_backward(const DsimCtx& c, Exec& ex, int substeps, int mm_freq, const float* g_ckpt,
+template <class Ctx, class Exec>
+DSIM_FN void dsim_env_step_backward(const Ctx& c, Exec& ex, int substeps, int mm_freq, const float* g_ckpt,
                                     const float* g_act, const float* g_mact, const float* g_gq_out,
                                     const float* g_gqd_out, float* g_gq_in, float* g_gqd_in, float* g_gact,
                                     float* g_gmact) {
@@ -928,8 +947,8 @@ struct DsimEnvSpec {
 };
 
 // actions -> LDS: ua (what the env stores as self.actions), act / mact
-template <class Exec>
-DSIM_FN void dsim_env_load_actions(const DsimCtx& c, Exec& ex, const DsimEnvSpec& sp, const float* g_actions) {
+template <class Ctx, class Exec>
+DSIM_FN void dsim_env_load_actions(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, const float* g_actions) {
     ex.run([&](int lane) {
         for (int k = lane; k < c.d.nd; k += DSIM_NL) WF(act)[k] = 0.f;
     });
@@ -948,8 +967,8 @@ DSIM_FN void dsim_env_load_actions(const DsimCtx& c, Exec& ex, const DsimEnvSpec
     });
 }
 
-template <class Exec>
-DSIM_FN void dsim_env_observe(const DsimCtx& c, Exec& ex, const DsimEnvSpec& sp, float* g_obs, float* g_rew) {
+template <class Ctx, class Exec>
+DSIM_FN void dsim_env_observe(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, float* g_obs, float* g_rew) {
     const int nq = c.d.nq, nd = c.d.nd;
     ex.run([&](int lane) {
         const float *q = WF(q), *qd = WF(qd);
@@ -1021,8 +1040,8 @@ DSIM_FN void dsim_env_observe(const DsimCtx& c, Exec& ex, const DsimEnvSpec& sp,
 }
 
 // obs/reward^T: adds into aqn/aqdn (cotangents of the step's output state) and writes gua (d/d stored action)
-template <class Exec>
-DSIM_FN void dsim_env_observe_adjoint(const DsimCtx& c, Exec& ex, const DsimEnvSpec& sp, const float* g_gobs,
+template <class Ctx, class Exec>
+DSIM_FN void dsim_env_observe_adjoint(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, const float* g_gobs,
                                       const float* g_grew) {
     const int nq = c.d.nq, nd = c.d.nd;
     // q/qd in LDS hold the step's OUTPUT state, ua the stored actions
@@ -1105,8 +1124,8 @@ DSIM_FN void dsim_env_observe_adjoint(const DsimCtx& c, Exec& ex, const DsimEnvS
 }
 
 // whole fused env.step(): actions -> sim -> (q', qd', obs, rew)
-template <class Exec>
-DSIM_FN void dsim_env_fused_forward(const DsimCtx& c, Exec& ex, const DsimEnvSpec& sp, int substeps, int mm_freq,
+template <class Ctx, class Exec>
+DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, int substeps, int mm_freq,
                                     const float* g_q, const float* g_qd, const float* g_actions, float* g_q_out,
                                     float* g_qd_out, float* g_obs, float* g_rew, float* g_ckpt) {
     const int nq = c.d.nq, nd = c.d.nd;
@@ -1118,14 +1137,14 @@ DSIM_FN void dsim_env_fused_forward(const DsimCtx& c, Exec& ex, const DsimEnvSpe
     for (int s = 0; s < substeps; ++s) {
         if (g_ckpt) {
             float* ck = g_ckpt + (size_t)s * (nq + nd);
-            ex.run([&](int lane) {
+            ex.fire([&](int lane) {
                 for (int k = lane; k < nq; k += DSIM_NL) ck[k] = WF(q)[k];
                 for (int k = lane; k < nd; k += DSIM_NL) ck[nq + k] = WF(qd)[k];
             });
         }
         dsim_fwd_substep(c, ex, (s % mm_freq) == 0);
     }
-    ex.run([&](int lane) {
+    ex.fire([&](int lane) {
         for (int k = lane; k < nq; k += DSIM_NL) g_q_out[k] = WF(q)[k];
         for (int k = lane; k < nd; k += DSIM_NL) g_qd_out[k] = WF(qd)[k];
     });
@@ -1133,8 +1152,8 @@ DSIM_FN void dsim_env_fused_forward(const DsimCtx& c, Exec& ex, const DsimEnvSpe
 }
 
 // state-only observation (reset / initialize_trajectory path): obs of (q, qd) with the given stored actions
-template <class Exec>
-DSIM_FN void dsim_env_observe_only(const DsimCtx& c, Exec& ex, const DsimEnvSpec& sp, const float* g_q, const float* g_qd,
+template <class Ctx, class Exec>
+DSIM_FN void dsim_env_observe_only(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, const float* g_q, const float* g_qd,
                                    const float* g_stored_actions, float* g_obs, float* g_rew) {
     ex.run([&](int lane) {
         for (int k = lane; k < c.d.nq; k += DSIM_NL) WF(q)[k] = g_q[k];
@@ -1145,8 +1164,8 @@ DSIM_FN void dsim_env_observe_only(const DsimCtx& c, Exec& ex, const DsimEnvSpec
 }
 
 // reverse of dsim_env_fused_forward; g_q_out/g_qd_out are the forward OUTPUT state (needed by obs^T)
-template <class Exec>
-DSIM_FN void dsim_env_fused_backward(const DsimCtx& c, Exec& ex, const DsimEnvSpec& sp, int substeps, int mm_freq,
+template <class Ctx, class Exec>
+DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, int substeps, int mm_freq,
                                      const float* g_ckpt, const float* g_actions, const float* g_q_out,
                                      const float* g_qd_out, const float* g_gq_out, const float* g_gqd_out,
                                      const float* g_gobs, const float* g_grew, float* g_gq_in, float* g_gqd_in,

@@ -5,16 +5,25 @@
 // row is loaded with one coalesced read per tensor, all `substeps` substeps run out of LDS, and only
 // (q, qd) [+ the per-substep checkpoint when gradients are wanted] go back to HBM.  N=1024
 // environments therefore put exactly one wave on each of the 1024 SIMDs of an MI355X; larger N
-// stacks waves per SIMD (LDS per workgroup: Ant 8.6 KB fwd / 15 KB bwd) and hides LDS/VALU latency.
+// stacks waves per SIMD and hides LDS/VALU latency.
+//
+// Every kernel exists in a GENERIC form (LDS offsets and model sizes are runtime values in SGPRs) and in
+// per-model SPECIALISED forms (dsim_static_layouts.hpp: offsets are instruction immediates, sizes are
+// compile-time loop bounds).  dsim_model_create picks a specialised form only if the layout it builds at
+// run time is bit-identical to the generated table; the first profile of the generic kernels showed that
+// >60 % of their instruction stream was SGPR spilling (v_readlane/v_writelane), address arithmetic and
+// moves caused by ~100 runtime offsets (profiles/r01_*), which is what the specialisation removes.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC dsim_hip.hip -o libdsim_hip.so
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include <new>
 #include <string>
 
 #define DSIM_FN __device__ __forceinline__
 #include "dsim_core.hpp"
+#include "dsim_static_layouts.hpp"
 
 namespace {
 
@@ -23,23 +32,32 @@ struct DevExec {
         f((int)threadIdx.x);
         __syncthreads();
     }
+    // phase that only writes global memory nobody in this launch reads back: no barrier, no vmcnt wait
+    template <class F> __device__ __forceinline__ void fire(F&& f) { f((int)threadIdx.x); }
 };
 
-struct KCommon {
-    DsimOff o;
-    DsimDims d;
+template <class O, class D> struct KCommonT {
+    O o;
+    D d;
     const uint32_t* cblob;
     float h;
     int substeps, mm_freq, n_envs;
 };
 
-__device__ __forceinline__ void load_constants(float* lds, const KCommon& k) {
+template <class O, class D> __device__ __forceinline__ DsimCtxT<O, D> start_env(float* lds, const KCommonT<O, D>& k) {
     uint32_t* l = reinterpret_cast<uint32_t*>(lds);
     for (int i = threadIdx.x; i < k.o.const_words; i += DSIM_NL) l[i] = k.cblob[i];
     __syncthreads();
+    DsimCtxT<O, D> c;
+    c.s = lds;
+    c.o = k.o;
+    c.d = k.d;
+    c.h = k.h;
+    return c;
 }
 
-__global__ __launch_bounds__(DSIM_NL) void dsim_fwd_kernel(KCommon k, const float* __restrict__ q_in,
+template <class O, class D>
+__global__ __launch_bounds__(DSIM_NL) void dsim_fwd_kernel(KCommonT<O, D> k, const float* __restrict__ q_in,
                                                            const float* __restrict__ qd_in,
                                                            const float* __restrict__ act,
                                                            const float* __restrict__ mact, float* q_out,
@@ -47,12 +65,7 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_fwd_kernel(KCommon k, const floa
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    load_constants(lds, k);
-    DsimCtx c;
-    c.s = lds;
-    c.o = k.o;
-    c.d = k.d;
-    c.h = k.h;
+    auto c = start_env(lds, k);
     DevExec ex;
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_env_step_forward(c, ex, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, act + e * nd,
@@ -60,7 +73,8 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_fwd_kernel(KCommon k, const floa
                           ckpt ? ckpt + (size_t)e * k.substeps * (nq + nd) : nullptr);
 }
 
-__global__ __launch_bounds__(DSIM_NL) void dsim_bwd_kernel(KCommon k, const float* __restrict__ ckpt,
+template <class O, class D>
+__global__ __launch_bounds__(DSIM_NL) void dsim_bwd_kernel(KCommonT<O, D> k, const float* __restrict__ ckpt,
                                                            const float* __restrict__ act,
                                                            const float* __restrict__ mact,
                                                            const float* __restrict__ gq_out,
@@ -69,12 +83,7 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_bwd_kernel(KCommon k, const floa
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    load_constants(lds, k);
-    DsimCtx c;
-    c.s = lds;
-    c.o = k.o;
-    c.d = k.d;
-    c.h = k.h;
+    auto c = start_env(lds, k);
     DevExec ex;
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_env_step_backward(c, ex, k.substeps, k.mm_freq, ckpt + (size_t)e * k.substeps * (nq + nd), act + e * nd,
@@ -82,24 +91,16 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_bwd_kernel(KCommon k, const floa
                            gqd_in + e * nd, gact ? gact + e * nd : nullptr, (gmact && M) ? gmact + e * M : nullptr);
 }
 
-__device__ __forceinline__ DsimCtx make_ctx(float* lds, const KCommon& k) {
-    DsimCtx c;
-    c.s = lds;
-    c.o = k.o;
-    c.d = k.d;
-    c.h = k.h;
-    return c;
-}
-
-__global__ __launch_bounds__(DSIM_NL) void dsim_env_fwd_kernel(KCommon k, DsimEnvSpec sp, const float* __restrict__ q_in,
+template <class O, class D>
+__global__ __launch_bounds__(DSIM_NL) void dsim_env_fwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp,
+                                                               const float* __restrict__ q_in,
                                                                const float* __restrict__ qd_in,
                                                                const float* __restrict__ actions, float* q_out,
                                                                float* qd_out, float* obs, float* rew, float* ckpt) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    load_constants(lds, k);
-    DsimCtx c = make_ctx(lds, k);
+    auto c = start_env(lds, k);
     DevExec ex;
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_forward(c, ex, sp, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, actions + (size_t)e * sp.n_act,
@@ -107,7 +108,9 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_env_fwd_kernel(KCommon k, DsimEn
                            ckpt ? ckpt + (size_t)e * k.substeps * (nq + nd) : nullptr);
 }
 
-__global__ __launch_bounds__(DSIM_NL) void dsim_env_bwd_kernel(KCommon k, DsimEnvSpec sp, const float* __restrict__ ckpt,
+template <class O, class D>
+__global__ __launch_bounds__(DSIM_NL) void dsim_env_bwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp,
+                                                               const float* __restrict__ ckpt,
                                                                const float* __restrict__ actions,
                                                                const float* __restrict__ q_out,
                                                                const float* __restrict__ qd_out,
@@ -119,8 +122,7 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_env_bwd_kernel(KCommon k, DsimEn
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    load_constants(lds, k);
-    DsimCtx c = make_ctx(lds, k);
+    auto c = start_env(lds, k);
     DevExec ex;
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_backward(c, ex, sp, k.substeps, k.mm_freq, ckpt + (size_t)e * k.substeps * (nq + nd),
@@ -129,18 +131,63 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_env_bwd_kernel(KCommon k, DsimEn
                             gactions + (size_t)e * sp.n_act);
 }
 
-__global__ __launch_bounds__(DSIM_NL) void dsim_env_obs_kernel(KCommon k, DsimEnvSpec sp, const float* __restrict__ q,
+template <class O, class D>
+__global__ __launch_bounds__(DSIM_NL) void dsim_env_obs_kernel(KCommonT<O, D> k, DsimEnvSpec sp,
+                                                               const float* __restrict__ q,
                                                                const float* __restrict__ qd,
                                                                const float* __restrict__ stored, float* obs,
                                                                float* rew) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    DsimCtx c = make_ctx(lds, k);
+    DsimCtxT<O, D> c;
+    c.s = lds;
+    c.o = k.o;
+    c.d = k.d;
+    c.h = k.h;
     DevExec ex;
     dsim_env_observe_only(c, ex, sp, q + (size_t)e * k.d.nq, qd + (size_t)e * k.d.nd, stored + (size_t)e * sp.n_act,
                           obs + (size_t)e * sp.n_obs, rew + e);
 }
+
+#ifdef DSIM_ENABLE_PHASE_TIMER
+// developer tool (tools/phase_timer.py): per-phase cycle stamps of workgroup 0; NOT compiled into the product library
+struct TimingExec {
+    long long* buf;
+    int idx, cap;
+    template <class F> __device__ __forceinline__ void run(F&& f) {
+        f((int)threadIdx.x);
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x == 0 && idx < cap) buf[idx] = clock64();
+        ++idx;
+    }
+    template <class F> __device__ __forceinline__ void fire(F&& f) { f((int)threadIdx.x); }
+};
+template <class O, class D>
+__global__ __launch_bounds__(DSIM_NL) void dsim_timer_kernel(KCommonT<O, D> k, DsimEnvSpec sp, int backward,
+                                                             const float* q_in, const float* qd_in, const float* actions,
+                                                             float* q_out, float* qd_out, float* obs, float* rew,
+                                                             float* ckpt, const float* gq_out, const float* gqd_out,
+                                                             const float* gobs, const float* grew, float* gq_in,
+                                                             float* gqd_in, float* gactions, long long* stamps, int cap) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int e = blockIdx.x;
+    if (e >= k.n_envs) return;
+    auto c = start_env(lds, k);
+    TimingExec ex{stamps, 1, cap};
+    if (blockIdx.x == 0 && threadIdx.x == 0) stamps[0] = clock64();
+    const size_t nq = k.d.nq, nd = k.d.nd;
+    float* ck = ckpt + (size_t)e * k.substeps * (nq + nd);
+    if (!backward)
+        dsim_env_fused_forward(c, ex, sp, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd,
+                               actions + (size_t)e * sp.n_act, q_out + e * nq, qd_out + e * nd,
+                               obs + (size_t)e * sp.n_obs, rew + e, ck);
+    else
+        dsim_env_fused_backward(c, ex, sp, k.substeps, k.mm_freq, ck, actions + (size_t)e * sp.n_act, q_out + e * nq,
+                                qd_out + e * nd, gq_out + e * nq, gqd_out + e * nd, gobs + (size_t)e * sp.n_obs, grew + e,
+                                gq_in + e * nq, gqd_in + e * nd, gactions + (size_t)e * sp.n_act);
+}
+#endif
 
 thread_local std::string g_err;
 
@@ -153,136 +200,77 @@ int hip_fail(hipError_t e, const char* what) {
     return DSIM_ERR_HIP;
 }
 
+// ---- kernel variants -------------------------------------------------------------------------------
+enum Variant {
+    V_GENERIC = 0,
+#define DSIM_ENUM(T) V_##T,
+    DSIM_STATIC_VARIANTS(DSIM_ENUM)
+#undef DSIM_ENUM
+};
+
+int match_variant(const DsimLayout& lay) {
+    if (getenv("DSIM_FORCE_GENERIC")) return V_GENERIC;
+    const size_t no = sizeof(DsimOff) / sizeof(int), nd = sizeof(DsimDims) / sizeof(int);
+#define DSIM_MATCH(T)                                                                                              \
+    if (sizeof(kDsimStatic##T) == (no + nd) * sizeof(int) && memcmp(kDsimStatic##T, &lay.o, no * sizeof(int)) == 0 && \
+        memcmp(kDsimStatic##T + no, &lay.d, nd * sizeof(int)) == 0)                                                 \
+        return V_##T;
+    DSIM_STATIC_VARIANTS(DSIM_MATCH)
+#undef DSIM_MATCH
+    return V_GENERIC;
+}
+
 }  // namespace
 
 struct dsim_model {
     DsimLayout lay;
     uint32_t* d_cblob = nullptr;
-    int max_lds_bytes = 0;
+    int variant = V_GENERIC;
 };
 
-extern "C" {
+namespace {
 
-const char* dsim_last_error(void) { return g_err.c_str(); }
-int dsim_version(void) { return 100; }
-
-int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
-    if (!desc || !out) return fail(DSIM_ERR_INVALID, "null argument");
-    dsim_model* m = new (std::nothrow) dsim_model();
-    if (!m) return fail(DSIM_ERR_INVALID, "out of host memory");
-    std::string err = dsim_build_layout(*desc, m->lay);
-    if (!err.empty()) {
-        delete m;
-        return fail(DSIM_ERR_INVALID, err);
+// calls f(offsets, dims) with the (static or runtime) layout types of the model's kernel variant
+template <class F> int dispatch(const dsim_model* m, F&& f) {
+    switch (m->variant) {
+#define DSIM_CASE(T) \
+    case V_##T:      \
+        return f(DsimOff##T{}, DsimDims##T{});
+        DSIM_STATIC_VARIANTS(DSIM_CASE)
+#undef DSIM_CASE
+        default:
+            return f(m->lay.o, m->lay.d);
     }
-    const int bytes = m->lay.o.total_words * 4;
-    if (bytes > 160 * 1024) {
-        delete m;
-        return fail(DSIM_ERR_LIMIT, "model needs more than 160 KiB of LDS per environment");
-    }
-    hipError_t e = hipMalloc(&m->d_cblob, sizeof(uint32_t) * m->lay.cblob.size());
-    if (e != hipSuccess) {
-        delete m;
-        return hip_fail(e, "hipMalloc(model constants)");
-    }
-    e = hipMemcpy(m->d_cblob, m->lay.cblob.data(), sizeof(uint32_t) * m->lay.cblob.size(), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        hipFree(m->d_cblob);
-        delete m;
-        return hip_fail(e, "hipMemcpy(model constants)");
-    }
-    if (bytes > 64 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsim_bwd_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsim_env_bwd_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e != hipSuccess) {
-            hipFree(m->d_cblob);
-            delete m;
-            return hip_fail(e, "hipFuncSetAttribute(bwd LDS)");
-        }
-    }
-    if (m->lay.o.fwd_words * 4 > 64 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsim_fwd_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, m->lay.o.fwd_words * 4);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsim_env_fwd_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, m->lay.o.fwd_words * 4);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsim_env_obs_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, m->lay.o.fwd_words * 4);
-        if (e != hipSuccess) {
-            hipFree(m->d_cblob);
-            delete m;
-            return hip_fail(e, "hipFuncSetAttribute(fwd LDS)");
-        }
-    }
-    *out = m;
-    return DSIM_OK;
 }
 
-int dsim_model_destroy(dsim_model* m) {
-    if (!m) return DSIM_OK;
-    if (m->d_cblob) hipFree(m->d_cblob);
-    delete m;
-    return DSIM_OK;
-}
-
-int64_t dsim_ckpt_floats(const dsim_model* m, int substeps) {
-    if (!m || substeps <= 0) return 0;
-    return (int64_t)substeps * (m->lay.d.nq + m->lay.d.nd);
-}
-
-static int make_common(const dsim_model* m, int n_envs, float dt, int substeps, int mm_freq, KCommon& k) {
-    if (!m) return fail(DSIM_ERR_INVALID, "null model");
-    if (n_envs <= 0) return fail(DSIM_ERR_INVALID, "n_envs must be positive");
-    if (substeps <= 0 || mm_freq <= 0) return fail(DSIM_ERR_INVALID, "substeps and mm_freq must be positive");
-    if (!(dt > 0.f)) return fail(DSIM_ERR_INVALID, "dt must be positive");
-    k.o = m->lay.o;
-    k.d = m->lay.d;
+template <class O, class D>
+KCommonT<O, D> make_k(const dsim_model* m, O o, D d, int n_envs, float dt, int substeps, int mm_freq) {
+    KCommonT<O, D> k;
+    k.o = o;
+    k.d = d;
     k.cblob = m->d_cblob;
     k.h = dt / float(substeps);
     k.substeps = substeps;
     k.mm_freq = mm_freq;
     k.n_envs = n_envs;
+    return k;
+}
+
+int check_common(const dsim_model* m, int n_envs, float dt, int substeps, int mm_freq) {
+    if (!m) return fail(DSIM_ERR_INVALID, "null model");
+    if (n_envs <= 0) return fail(DSIM_ERR_INVALID, "n_envs must be positive");
+    if (substeps <= 0 || mm_freq <= 0) return fail(DSIM_ERR_INVALID, "substeps and mm_freq must be positive");
+    if (!(dt > 0.f)) return fail(DSIM_ERR_INVALID, "dt must be positive");
     return DSIM_OK;
 }
 
-int dsim_step_forward(const dsim_model* m, int n_envs, const float* q_in, const float* qd_in, const float* act,
-                      const float* muscle_act, float dt, int substeps, int mm_freq, float* q_out, float* qd_out,
-                      float* ckpt, void* hip_stream) {
-    KCommon k;
-    int rc = make_common(m, n_envs, dt, substeps, mm_freq, k);
-    if (rc) return rc;
-    if (!q_in || !qd_in || !act || !q_out || !qd_out) return fail(DSIM_ERR_INVALID, "null state pointer");
-    if (k.d.M > 0 && !muscle_act) return fail(DSIM_ERR_INVALID, "model has muscles but muscle_act is null");
-    hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    hipLaunchKernelGGL(dsim_fwd_kernel, dim3(n_envs), dim3(DSIM_NL), (size_t)k.o.fwd_words * 4, st, k, q_in, qd_in, act,
-                       muscle_act, q_out, qd_out, ckpt);
+int launched(const char* what) {
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "launch dsim_fwd_kernel");
+    if (e != hipSuccess) return hip_fail(e, what);
     return DSIM_OK;
 }
 
-int dsim_step_backward(const dsim_model* m, int n_envs, const float* ckpt, const float* act, const float* muscle_act,
-                       float dt, int substeps, int mm_freq, const float* gq_out, const float* gqd_out, float* gq_in,
-                       float* gqd_in, float* gact, float* gmuscle_act, void* hip_stream) {
-    KCommon k;
-    int rc = make_common(m, n_envs, dt, substeps, mm_freq, k);
-    if (rc) return rc;
-    if (!ckpt || !act || !gq_out || !gqd_out || !gq_in || !gqd_in)
-        return fail(DSIM_ERR_INVALID, "null pointer (ckpt/act/grad)");
-    if (k.d.M > 0 && !muscle_act) return fail(DSIM_ERR_INVALID, "model has muscles but muscle_act is null");
-    hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    hipLaunchKernelGGL(dsim_bwd_kernel, dim3(n_envs), dim3(DSIM_NL), (size_t)k.o.total_words * 4, st, k, ckpt, act,
-                       muscle_act, gq_out, gqd_out, gq_in, gqd_in, gact, gmuscle_act);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "launch dsim_bwd_kernel");
-    return DSIM_OK;
-}
-
-static int make_spec(const dsim_model* m, const dsim_env_spec* e, DsimEnvSpec& sp) {
+int make_spec(const dsim_model* m, const dsim_env_spec* e, DsimEnvSpec& sp) {
     if (!e) return fail(DSIM_ERR_INVALID, "null env spec");
     const DsimDims& d = m->lay.d;
     if (e->kind != DSIM_ENV_LOCOMOTION && e->kind != DSIM_ENV_CARTPOLE) return fail(DSIM_ERR_INVALID, "unknown env kind");
@@ -312,30 +300,128 @@ static int make_spec(const dsim_model* m, const dsim_env_spec* e, DsimEnvSpec& s
     return DSIM_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+const char* dsim_last_error(void) { return g_err.c_str(); }
+int dsim_version(void) { return 101; }
+
+int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
+    if (!desc || !out) return fail(DSIM_ERR_INVALID, "null argument");
+    dsim_model* m = new (std::nothrow) dsim_model();
+    if (!m) return fail(DSIM_ERR_INVALID, "out of host memory");
+    std::string err = dsim_build_layout(*desc, m->lay);
+    if (!err.empty()) {
+        delete m;
+        return fail(DSIM_ERR_INVALID, err);
+    }
+    const int bytes = m->lay.o.total_words * 4, fbytes = m->lay.o.fwd_words * 4;
+    if (bytes > 160 * 1024) {
+        delete m;
+        return fail(DSIM_ERR_LIMIT, "model needs more than 160 KiB of LDS per environment");
+    }
+    m->variant = match_variant(m->lay);
+    hipError_t e = hipMalloc(&m->d_cblob, sizeof(uint32_t) * m->lay.cblob.size());
+    if (e == hipSuccess)
+        e = hipMemcpy(m->d_cblob, m->lay.cblob.data(), sizeof(uint32_t) * m->lay.cblob.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && (bytes > 64 * 1024 || fbytes > 64 * 1024)) {
+        // opt in to > 64 KiB of dynamic LDS for this model's kernel variant
+        dispatch(m, [&](auto o, auto d) {
+            using O = decltype(o);
+            using D = decltype(d);
+            const void* fns_bwd[] = {reinterpret_cast<const void*>(dsim_bwd_kernel<O, D>),
+                                     reinterpret_cast<const void*>(dsim_env_bwd_kernel<O, D>)};
+            const void* fns_fwd[] = {reinterpret_cast<const void*>(dsim_fwd_kernel<O, D>),
+                                     reinterpret_cast<const void*>(dsim_env_fwd_kernel<O, D>),
+                                     reinterpret_cast<const void*>(dsim_env_obs_kernel<O, D>)};
+            for (const void* fn : fns_bwd)
+                if (e == hipSuccess && bytes > 64 * 1024)
+                    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            for (const void* fn : fns_fwd)
+                if (e == hipSuccess && fbytes > 64 * 1024)
+                    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, fbytes);
+            return 0;
+        });
+    }
+    if (e != hipSuccess) {
+        if (m->d_cblob) (void)hipFree(m->d_cblob);
+        delete m;
+        return hip_fail(e, "dsim_model_create");
+    }
+    *out = m;
+    return DSIM_OK;
+}
+
+int dsim_model_destroy(dsim_model* m) {
+    if (!m) return DSIM_OK;
+    if (m->d_cblob) (void)hipFree(m->d_cblob);
+    delete m;
+    return DSIM_OK;
+}
+
+int64_t dsim_ckpt_floats(const dsim_model* m, int substeps) {
+    if (!m || substeps <= 0) return 0;
+    return (int64_t)substeps * (m->lay.d.nq + m->lay.d.nd);
+}
+
+int dsim_step_forward(const dsim_model* m, int n_envs, const float* q_in, const float* qd_in, const float* act,
+                      const float* muscle_act, float dt, int substeps, int mm_freq, float* q_out, float* qd_out,
+                      float* ckpt, void* hip_stream) {
+    int rc = check_common(m, n_envs, dt, substeps, mm_freq);
+    if (rc) return rc;
+    if (!q_in || !qd_in || !act || !q_out || !qd_out) return fail(DSIM_ERR_INVALID, "null state pointer");
+    if (m->lay.d.M > 0 && !muscle_act) return fail(DSIM_ERR_INVALID, "model has muscles but muscle_act is null");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    return dispatch(m, [&](auto o, auto d) {
+        auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
+        hipLaunchKernelGGL((dsim_fwd_kernel<decltype(o), decltype(d)>), dim3(n_envs), dim3(DSIM_NL),
+                           (size_t)m->lay.o.fwd_words * 4, st, k, q_in, qd_in, act, muscle_act, q_out, qd_out, ckpt);
+        return launched("launch dsim_fwd_kernel");
+    });
+}
+
+int dsim_step_backward(const dsim_model* m, int n_envs, const float* ckpt, const float* act, const float* muscle_act,
+                       float dt, int substeps, int mm_freq, const float* gq_out, const float* gqd_out, float* gq_in,
+                       float* gqd_in, float* gact, float* gmuscle_act, void* hip_stream) {
+    int rc = check_common(m, n_envs, dt, substeps, mm_freq);
+    if (rc) return rc;
+    if (!ckpt || !act || !gq_out || !gqd_out || !gq_in || !gqd_in)
+        return fail(DSIM_ERR_INVALID, "null pointer (ckpt/act/grad)");
+    if (m->lay.d.M > 0 && !muscle_act) return fail(DSIM_ERR_INVALID, "model has muscles but muscle_act is null");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    return dispatch(m, [&](auto o, auto d) {
+        auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
+        hipLaunchKernelGGL((dsim_bwd_kernel<decltype(o), decltype(d)>), dim3(n_envs), dim3(DSIM_NL),
+                           (size_t)m->lay.o.total_words * 4, st, k, ckpt, act, muscle_act, gq_out, gqd_out, gq_in, gqd_in,
+                           gact, gmuscle_act);
+        return launched("launch dsim_bwd_kernel");
+    });
+}
+
 int dsim_env_step_forward(const dsim_model* m, const dsim_env_spec* env, int n_envs, const float* q_in,
                           const float* qd_in, const float* actions, float dt, int substeps, int mm_freq, float* q_out,
                           float* qd_out, float* obs, float* rew, float* ckpt, void* hip_stream) {
-    KCommon k;
-    int rc = make_common(m, n_envs, dt, substeps, mm_freq, k);
+    int rc = check_common(m, n_envs, dt, substeps, mm_freq);
     if (rc) return rc;
     DsimEnvSpec sp;
     rc = make_spec(m, env, sp);
     if (rc) return rc;
     if (!q_in || !qd_in || !actions || !q_out || !qd_out || !obs || !rew) return fail(DSIM_ERR_INVALID, "null pointer");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    hipLaunchKernelGGL(dsim_env_fwd_kernel, dim3(n_envs), dim3(DSIM_NL), (size_t)k.o.fwd_words * 4, st, k, sp, q_in,
-                       qd_in, actions, q_out, qd_out, obs, rew, ckpt);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "launch dsim_env_fwd_kernel");
-    return DSIM_OK;
+    return dispatch(m, [&](auto o, auto d) {
+        auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
+        hipLaunchKernelGGL((dsim_env_fwd_kernel<decltype(o), decltype(d)>), dim3(n_envs), dim3(DSIM_NL),
+                           (size_t)m->lay.o.fwd_words * 4, st, k, sp, q_in, qd_in, actions, q_out, qd_out, obs, rew, ckpt);
+        return launched("launch dsim_env_fwd_kernel");
+    });
 }
 
 int dsim_env_step_backward(const dsim_model* m, const dsim_env_spec* env, int n_envs, const float* ckpt,
                            const float* actions, const float* q_out, const float* qd_out, float dt, int substeps,
                            int mm_freq, const float* gq_out, const float* gqd_out, const float* gobs, const float* grew,
                            float* gq_in, float* gqd_in, float* gactions, void* hip_stream) {
-    KCommon k;
-    int rc = make_common(m, n_envs, dt, substeps, mm_freq, k);
+    int rc = check_common(m, n_envs, dt, substeps, mm_freq);
     if (rc) return rc;
     DsimEnvSpec sp;
     rc = make_spec(m, env, sp);
@@ -343,28 +429,55 @@ int dsim_env_step_backward(const dsim_model* m, const dsim_env_spec* env, int n_
     if (!ckpt || !actions || !q_out || !qd_out || !gq_out || !gqd_out || !gobs || !grew || !gq_in || !gqd_in || !gactions)
         return fail(DSIM_ERR_INVALID, "null pointer");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    hipLaunchKernelGGL(dsim_env_bwd_kernel, dim3(n_envs), dim3(DSIM_NL), (size_t)k.o.total_words * 4, st, k, sp, ckpt,
-                       actions, q_out, qd_out, gq_out, gqd_out, gobs, grew, gq_in, gqd_in, gactions);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "launch dsim_env_bwd_kernel");
-    return DSIM_OK;
+    return dispatch(m, [&](auto o, auto d) {
+        auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
+        hipLaunchKernelGGL((dsim_env_bwd_kernel<decltype(o), decltype(d)>), dim3(n_envs), dim3(DSIM_NL),
+                           (size_t)m->lay.o.total_words * 4, st, k, sp, ckpt, actions, q_out, qd_out, gq_out, gqd_out, gobs,
+                           grew, gq_in, gqd_in, gactions);
+        return launched("launch dsim_env_bwd_kernel");
+    });
 }
 
 int dsim_env_observe(const dsim_model* m, const dsim_env_spec* env, int n_envs, const float* q, const float* qd,
                      const float* stored_actions, float* obs, float* rew, void* hip_stream) {
-    KCommon k;
-    int rc = make_common(m, n_envs, 1.0f, 1, 1, k);
+    int rc = check_common(m, n_envs, 1.0f, 1, 1);
     if (rc) return rc;
     DsimEnvSpec sp;
     rc = make_spec(m, env, sp);
     if (rc) return rc;
     if (!q || !qd || !stored_actions || !obs || !rew) return fail(DSIM_ERR_INVALID, "null pointer");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    hipLaunchKernelGGL(dsim_env_obs_kernel, dim3(n_envs), dim3(DSIM_NL), (size_t)k.o.fwd_words * 4, st, k, sp, q, qd,
-                       stored_actions, obs, rew);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "launch dsim_env_obs_kernel");
-    return DSIM_OK;
+    return dispatch(m, [&](auto o, auto d) {
+        auto k = make_k(m, o, d, n_envs, 1.0f, 1, 1);
+        hipLaunchKernelGGL((dsim_env_obs_kernel<decltype(o), decltype(d)>), dim3(n_envs), dim3(DSIM_NL),
+                           (size_t)m->lay.o.fwd_words * 4, st, k, sp, q, qd, stored_actions, obs, rew);
+        return launched("launch dsim_env_obs_kernel");
+    });
 }
+
+/* 0 = generic kernels, >0 = index of the specialised variant in use (diagnostics / tests) */
+int dsim_model_variant(const dsim_model* m) { return m ? m->variant : -1; }
+
+#ifdef DSIM_ENABLE_PHASE_TIMER
+int dsim_debug_phase_timer(const dsim_model* m, const dsim_env_spec* env, int n_envs, int backward, const float* q_in,
+                           const float* qd_in, const float* actions, float dt, int substeps, int mm_freq, float* q_out,
+                           float* qd_out, float* obs, float* rew, float* ckpt, const float* gq_out, const float* gqd_out,
+                           const float* gobs, const float* grew, float* gq_in, float* gqd_in, float* gactions,
+                           long long* stamps, int cap, void* hip_stream) {
+    int rc = check_common(m, n_envs, dt, substeps, mm_freq);
+    if (rc) return rc;
+    DsimEnvSpec sp;
+    rc = make_spec(m, env, sp);
+    if (rc) return rc;
+    return dispatch(m, [&](auto o, auto d) {
+        auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
+        hipLaunchKernelGGL((dsim_timer_kernel<decltype(o), decltype(d)>), dim3(n_envs), dim3(DSIM_NL),
+                           (size_t)m->lay.o.total_words * 4, static_cast<hipStream_t>(hip_stream), k, sp, backward, q_in,
+                           qd_in, actions, q_out, qd_out, obs, rew, ckpt, gq_out, gqd_out, gobs, grew, gq_in, gqd_in, gactions,
+                           stamps, cap);
+        return launched("launch dsim_timer_kernel");
+    });
+}
+#endif
 
 }  // extern "C"

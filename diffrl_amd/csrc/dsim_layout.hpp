@@ -25,6 +25,8 @@ struct DsimOff {
     int sub_start, sub_list;    // subtree of link i (self first, then descendants ascending)
     int child_start, child_list;
     int cb_start, cb_list;      // contacts of body i
+    int scb_start, scb_list;    // contacts of all bodies in subtree(i) (ascending contact index)
+    int sml_start, sml_list;    // muscle (segment*2+side) entries of all bodies in subtree(i)
     int rel;                    // [nd*nd] 0 unrelated, 1: link(b) in subtree(link(a)), 2: link(a) strictly below link(b)
     int cbody;
     int seg_wp, seg_m;          // active muscle segment -> first waypoint index / muscle index
@@ -161,6 +163,15 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     }
     std::vector<int> ml_start(L + 1, 0), ml_list;
     flatten(ml, ml_start, ml_list);
+    std::vector<std::vector<int>> scb(L), sml(L);
+    for (int i = 0; i < L; ++i)
+        for (int j : sub[i]) {
+            scb[i].insert(scb[i].end(), cb[j].begin(), cb[j].end());
+            sml[i].insert(sml[i].end(), ml[j].begin(), ml[j].end());
+        }
+    std::vector<int> scb_start(L + 1, 0), scb_list, sml_start(L + 1, 0), sml_list;
+    flatten(scb, scb_start, scb_list);
+    flatten(sml, sml_start, sml_list);
 
     DsimOff o;
     memset(&o, 0, sizeof(o));
@@ -191,6 +202,10 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.child_list = put_i(child_list.data(), child_list.size());
     o.cb_start = put_i(cb_start.data(), L + 1);
     o.cb_list = put_i(cb_list.data(), cb_list.size());
+    o.scb_start = put_i(scb_start.data(), L + 1);
+    o.scb_list = put_i(scb_list.data(), scb_list.size());
+    o.sml_start = put_i(sml_start.data(), L + 1);
+    o.sml_list = put_i(sml_list.data(), sml_list.size());
     o.rel = put_i(rel.data(), rel.size());
     o.cbody = put_i(m.contact_body, C);
     o.seg_wp = put_i(seg_wp.data(), NS);
@@ -240,14 +255,14 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.vj = take(6 * L); o.v = take(6 * L); o.a = take(6 * L); o.i10 = take(10 * L);
     o.f = take(6 * L); o.ftot = take(6 * L); o.cw = take(6 * C); o.tau = take(nd); o.qdd = take(nd);
     o.ic10 = take(10 * L); o.F = take(6 * nd); o.hinv = take(nd * nd); o.prow = take(nd); o.pcol = take(nd);
-    o.mus = take(9 * NS);
+    o.mus = take(15 * NS);  // forward: 12 floats/segment (signed wrenches); adjoint: 15 floats/segment (cotangents)
     o.fwd_words = cur;
     o.aq = take(nq); o.aqd = take(nd); o.aqn = take(nq); o.aqdn = take(nd); o.aact = take(nd); o.amact = take(M);
     o.aqdd = take(nd); o.atau = take(nd); o.aS = take(6 * nd); o.aftot = take(6 * L); o.af = take(6 * L);
     o.acx = take(13 * C); o.axsc = take(7 * L); o.axsj = take(7 * L); o.ac = take(3 * L);
     o.av = take(6 * L); o.aa = take(6 * L); o.aatot = take(6 * L); o.avtot = take(6 * L); o.avj = take(6 * L);
     o.ai10 = take(10 * L); o.ai10m = take(10 * L); o.aic10 = take(10 * L); o.aH = take(nd * nd);
-    o.topar = take(7 * L); o.amus = take(15 * NS); o.gua = take(M > nd ? M : nd);
+    o.topar = take(7 * L); o.amus = take(0); o.gua = take(M > nd ? M : nd);
     o.total_words = cur;
 
     out.o = o;

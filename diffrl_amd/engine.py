@@ -29,6 +29,7 @@ class Engine:
         with torch.cuda.device(self.device):
             capi.check(self._lib.dsim_model_create(C.byref(self._desc), C.byref(h)))
         self._h = h
+        self.variant = int(self._lib.dsim_model_variant(h))  # 0 = generic kernels, > 0 = specialised for this model
         self.n_q, self.n_qd, self.n_muscles = template.n_q, template.n_qd, template.n_muscles
 
     def __del__(self):

@@ -91,6 +91,9 @@ int dsim_version(void);
 /* Uploads the template to the current HIP device. */
 int dsim_model_create(const dsim_model_desc* desc, dsim_model** out);
 int dsim_model_destroy(dsim_model* m);
+/* 0: generic kernels (runtime layout); > 0: a per-model specialised kernel set is in use (layout matched a
+ * compile-time table exactly).  Same results either way. */
+int dsim_model_variant(const dsim_model* m);
 
 /* Floats per environment of the per-substep checkpoint the forward pass leaves for the adjoint:
  * substeps * (n_q + n_qd).  (The reference instead keeps all 14 State tensors of every substep

@@ -14,6 +14,7 @@ struct HostExec {
     template <class F> void run(F&& f) {
         for (int lane = 0; lane < DSIM_NL; ++lane) f(lane);
     }
+    template <class F> void fire(F&& f) { run(f); }
 };
 
 static void make_ctx(const DsimLayout& lay, std::vector<float>& lds, DsimCtx& c, float h) {

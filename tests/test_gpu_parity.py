@@ -146,3 +146,22 @@ def test_error_paths(dev):
         eng.forward(q, qd, torch.zeros_like(qd), None, 1 / 60, 0, 4, False)
     with pytest.raises(capi.DsimError):
         eng.forward(q.double(), qd, torch.zeros_like(qd), None, 1 / 60, 4, 4, False)
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_specialised_kernels_match_generic(env, dev, monkeypatch):
+    """the per-model specialised kernel set (compile-time layout) and the generic one agree"""
+    import os
+    from diffrl_amd.engine import Engine
+    t = template_from_golden(env)
+    g = golden(env + "_step")
+    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
+    spec_eng = Engine(t, dev)
+    assert spec_eng.variant > 0, "known model should select a specialised kernel set"
+    monkeypatch.setenv("DSIM_FORCE_GENERIC", "1")
+    gen_eng = Engine(t, dev)
+    assert gen_eng.variant == 0
+    a = _run(spec_eng, dev, g["q_in"], g["qd_in"], g["act_in"], g.get("muscle_act_in"), dt, S, mm, g["gq_out"], g["gqd_out"])
+    b = _run(gen_eng, dev, g["q_in"], g["qd_in"], g["act_in"], g.get("muscle_act_in"), dt, S, mm, g["gq_out"], g["gqd_out"])
+    for k in ("q", "qd", "gq", "gqd", "gact"):
+        assert relerr(a[k], b[k]) < 1e-5, k
