@@ -58,6 +58,38 @@ DSIM_FN float dsim_gather_sum(const float* data, int stride, int comp, const dsi
     for (; e < b1; ++e) acc += data[stride * list[e] + comp];
     return acc;
 }
+// sum_{j in [first, first+count)} data[stride*j + comp]: subtree / contact sums when the numbering is pre-order
+DSIM_FN float dsim_range_sum(const float* data, int stride, int comp, int first, int count, float acc) {
+    const float* p = data + stride * first + comp;
+    int e = 0;
+    for (; e + 4 <= count; e += 4) {
+        const float x0 = p[stride * e], x1 = p[stride * (e + 1)], x2 = p[stride * (e + 2)], x3 = p[stride * (e + 3)];
+        acc = (((acc + x0) + x1) + x2) + x3;
+    }
+    for (; e < count; ++e) acc += p[stride * e];
+    return acc;
+}
+struct __attribute__((aligned(16), may_alias)) dsim_i4 {
+    int x, y, z, w;
+};
+// packed per-link record (dsim_layout.hpp: linfo): two 16-byte LDS reads instead of a chain of dependent 4-byte reads
+struct DsimLinkInfo {
+    int parent, type, cs, ds, level, nsub, c0, nc;
+};
+template <class Ctx> DSIM_FN DsimLinkInfo dsim_link_info(const Ctx& c, int i) {
+    const dsim_i4* p = reinterpret_cast<const dsim_i4*>(reinterpret_cast<const dsim_int_a*>(c.s) + c.o.linfo + 8 * i);
+    const dsim_i4 a = p[0], b = p[1];
+    return DsimLinkInfo{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+}
+// subtree sum of a per-link array: contiguous range when the model is numbered in pre-order, CSR list otherwise
+template <class Ctx> DSIM_FN float dsim_subtree_sum(const Ctx& c, const float* data, int stride, int comp, int i) {
+    if (c.d.flags & DSIM_F_RANGES) {
+        const int n = reinterpret_cast<const dsim_int_a*>(c.s)[c.o.linfo + 8 * i + 5];
+        return dsim_range_sum(data, stride, comp, i, n, 0.f);
+    }
+    return dsim_gather_sum(data, stride, comp, CI(sub_list), CI(sub_start)[i], CI(sub_start)[i + 1], 0.f);
+}
+
 DSIM_FN float dsim_dot_n(const float* a, const float* b, int n) {
     float acc = 0.f;
     int j = 0;
@@ -78,15 +110,25 @@ DSIM_FN float dsim_dot_n(const float* a, const float* b, int n) {
 // ================================================================================================
 
 // FK + motion subspace + velocities + world inertia + body force, level by level.
+// constant parts of the work arrays (written once per launch): the motion subspace of a free joint is the identity
+template <class Ctx, class Exec> DSIM_FN void dsim_init_static(const Ctx& c, Exec& ex) {
+    ex.run([&](int lane) {
+        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+            const DsimLinkInfo li = dsim_link_info(c, i);
+            if (li.type == DSIM_JOINT_FREE)
+                for (int k = 0; k < 6; ++k)
+                    for (int r = 0; r < 6; ++r) WF(S)[6 * (li.ds + k) + r] = (k == r) ? 1.f : 0.f;
+        }
+    });
+}
+
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, Exec& ex) {
-    const dsim_int_a *jtype = CI(jtype), *parent = CI(parent), *qstart = CI(qstart), *qdstart = CI(qdstart),
-                     *lvl_start = CI(lvl_start), *lvl_links = CI(lvl_links);
     for (int lv = 0; lv < c.d.D; ++lv) {
-        const int b0 = lvl_start[lv], b1 = lvl_start[lv + 1];
         ex.run([&](int lane) {
-            for (int idx = b0 + lane; idx < b1; idx += DSIM_NL) {
-                const int i = lvl_links[idx], par = parent[i], type = jtype[i];
-                const int cs = qstart[i], ds = qdstart[i];
+            for (int i = lane; i < c.d.L; i += DSIM_NL) {
+                const DsimLinkInfo li = dsim_link_info(c, i);
+                if (li.level != lv) continue;
+                const int par = li.parent, type = li.type, cs = li.cs, ds = li.ds;
                 const float *q = WF(q), *qd = WF(qd);
                 v3 psp = zero3();
                 q4 rsp = mkq(0.f, 0.f, 0.f, 1.f);
@@ -132,9 +174,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
                 } else if (type == DSIM_JOINT_FREE) {
                     pc = rotate(rj, ld3(q + cs)) + pj;
                     rc = qmul(rj, ldq(q + cs + 3));
-                    for (int k = 0; k < 6; ++k)
-                        for (int r = 0; r < 6; ++r) S[6 * (ds + k) + r] = (k == r) ? 1.f : 0.f;
-                    vj = ldsv(qd + ds);
+                    vj = ldsv(qd + ds);  // S = identity, written once by dsim_init_static
                 }
                 st3(WF(xsc) + 7 * i, pc);
                 stq(WF(xsc) + 7 * i + 3, rc);
@@ -246,8 +286,15 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_tau(const Ctx& c, Exec& e
     ex.run([&](int lane) {
         for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
             const int i = it / 6, k = it - 6 * i;
-            float acc = dsim_gather_sum(WF(f), 6, k, CI(sub_list), CI(sub_start)[i], CI(sub_start)[i + 1], 0.f);
-            acc = dsim_gather_sum(WF(cw), 6, k, CI(scb_list), CI(scb_start)[i], CI(scb_start)[i + 1], acc);
+            float acc;
+            if (c.d.flags & DSIM_F_RANGES) {
+                const DsimLinkInfo li = dsim_link_info(c, i);
+                acc = dsim_range_sum(WF(f), 6, k, i, li.nsub, 0.f);
+                acc = dsim_range_sum(WF(cw), 6, k, li.c0, li.nc, acc);
+            } else {
+                acc = dsim_gather_sum(WF(f), 6, k, CI(sub_list), CI(sub_start)[i], CI(sub_start)[i + 1], 0.f);
+                acc = dsim_gather_sum(WF(cw), 6, k, CI(scb_list), CI(scb_start)[i], CI(scb_start)[i + 1], acc);
+            }
             WF(ftot)[it] = acc;
         }
     });
@@ -278,7 +325,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_composite(const Ctx& c, E
     ex.run([&](int lane) {
         for (int it = lane; it < 10 * c.d.L; it += DSIM_NL) {
             const int i = it / 10, k = it - 10 * i;
-            WF(ic10)[it] = dsim_gather_sum(WF(i10), 10, k, CI(sub_list), CI(sub_start)[i], CI(sub_start)[i + 1], 0.f);
+            WF(ic10)[it] = dsim_subtree_sum(c, WF(i10), 10, k, i);
         }
     });
     ex.run([&](int lane) {
@@ -383,6 +430,7 @@ DSIM_FN void dsim_env_step_forward(const Ctx& c, Exec& ex, int substeps, int mm_
                                    const float* g_qd, const float* g_act, const float* g_mact, float* g_q_out,
                                    float* g_qd_out, float* g_ckpt) {
     const int nq = c.d.nq, nd = c.d.nd, M = c.d.M;
+    dsim_init_static(c, ex);
     ex.run([&](int lane) {
         for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = g_q[k];
         for (int k = lane; k < nd; k += DSIM_NL) {
@@ -492,18 +540,26 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
             }
         }
     });
-    ex.run([&](int lane) {
-        for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
-            const int i = it / 6, k = it - 6 * i;
-            float acc = 0.f;
-            for (int d = CI(qdstart)[i]; d < CI(qdstart)[i + 1]; ++d) acc -= WF(S)[6 * d + k] * WF(atau)[d];
-            WF(aftot)[it] = acc;
-        }
-    });
+    // af[j] = sum over ancestors-or-self i of aftot[i], aftot[i] = -sum_{d in dofs(i)} S_d atau_d  (one phase: each
+    // (link, component) item walks its ancestor list; the per-joint partial sums are recomputed instead of exchanged)
     ex.run([&](int lane) {
         for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
             const int j = it / 6, k = it - 6 * j;
-            WF(af)[it] = dsim_gather_sum(WF(aftot), 6, k, CI(anc_list), CI(anc_start)[j], CI(anc_start)[j + 1], 0.f);
+            float acc = 0.f;
+            const dsim_int_a* lst = CI(adof_list);
+            int e = CI(adof_start)[j];
+            const int e1 = CI(adof_start)[j + 1];
+            for (; e + 4 <= e1; e += 4) {
+                const int d0 = lst[e], d1 = lst[e + 1], d2 = lst[e + 2], d3 = lst[e + 3];
+                const float s0 = WF(S)[6 * d0 + k], s1 = WF(S)[6 * d1 + k], s2 = WF(S)[6 * d2 + k], s3 = WF(S)[6 * d3 + k];
+                const float t0 = WF(atau)[d0], t1 = WF(atau)[d1], t2 = WF(atau)[d2], t3 = WF(atau)[d3];
+                acc -= s0 * t0;
+                acc -= s1 * t1;
+                acc -= s2 * t2;
+                acc -= s3 * t3;
+            }
+            for (; e < e1; ++e) acc -= WF(S)[6 * lst[e] + k] * WF(atau)[lst[e]];
+            WF(af)[it] = acc;
         }
     });
 }
@@ -673,25 +729,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             for (int k = 0; k < 10; ++k) WF(ai10)[10 * i + k] = g[k];
             stsv(WF(aa) + 6 * i, inertia_mul(I, r));
             st3(WF(ac) + 3 * i, cross(r.w, ld3(CF(grav)) * I.m));
-            // gather contact / muscle cotangents of this body
-            v3 xp = zero3();
-            q4 xq = mkq(0.f, 0.f, 0.f, 0.f);
-            for (int e = CI(cb_start)[i]; e < CI(cb_start)[i + 1]; ++e) {
-                const float* o = WF(acx) + 13 * CI(cb_list)[e];
-                xp += ld3(o);
-                xq += ldq(o + 3);
-                a_v.w += ld3(o + 7);
-                a_v.v += ld3(o + 10);
-            }
-            for (int e = CI(ml_start)[i]; e < CI(ml_start)[i + 1]; ++e) {
-                const int code = CI(ml_list)[e];
-                const float* o = WF(mus) + 15 * (code >> 1) + 7 * (code & 1);
-                xp += ld3(o);
-                xq += ldq(o + 3);
-            }
-            st3(WF(axsc) + 7 * i, xp);
-            stq(WF(axsc) + 7 * i + 3, xq);
-            stsv(WF(av) + 6 * i, a_v);
+            stsv(WF(av) + 6 * i, a_v);  // contact cotangents are added by the item-parallel gather below
         }
         for (int m = lane; m < c.d.M; m += DSIM_NL) {
             float acc = 0.f;
@@ -702,13 +740,24 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
     ex.run([&](int lane) {
         for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
             const int i = it / 6, k = it - 6 * i;
-            WF(aatot)[it] = dsim_gather_sum(WF(aa), 6, k, CI(sub_list), CI(sub_start)[i], CI(sub_start)[i + 1], 0.f);
+            WF(aatot)[it] = dsim_subtree_sum(c, WF(aa), 6, k, i);
+        }
+        // per-body gather of the contact (13 floats: X_sc 7, v_s 6) and muscle (7 floats: X_sc) cotangents
+        for (int it = lane; it < 13 * c.d.L; it += DSIM_NL) {
+            const int i = it / 13, r = it - 13 * i;
+            float acc = dsim_gather_sum(WF(acx), 13, r, CI(cb_list), CI(cb_start)[i], CI(cb_start)[i + 1], 0.f);
+            if (r < 7)
+                for (int e = CI(ml_start)[i]; e < CI(ml_start)[i + 1]; ++e) {
+                    const int code = CI(ml_list)[e];
+                    acc += WF(mus)[15 * (code >> 1) + 7 * (code & 1) + r];
+                }
+            WF(agx)[it] = acc;
         }
     });
     ex.run([&](int lane) {
         for (int i = lane; i < c.d.L; i += DSIM_NL) {
             const sv6 v = ldsv(WF(v) + 6 * i), vj = ldsv(WF(vj) + 6 * i), A = ldsv(WF(aatot) + 6 * i);
-            sv6 a_v = ldsv(WF(av) + 6 * i), a_vj;
+            sv6 a_v = ldsv(WF(av) + 6 * i) + ldsv(WF(agx) + 13 * i + 7), a_vj;
             a_v.w += cross(vj.w, A.w) + cross(vj.v, A.v);
             a_v.v += cross(vj.w, A.v);
             a_vj.w = cross(A.w, v.w) + cross(A.v, v.v);
@@ -720,7 +769,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
     ex.run([&](int lane) {
         for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
             const int i = it / 6, k = it - 6 * i;
-            WF(avtot)[it] = dsim_gather_sum(WF(av), 6, k, CI(sub_list), CI(sub_start)[i], CI(sub_start)[i + 1], 0.f);
+            WF(avtot)[it] = dsim_subtree_sum(c, WF(av), 6, k, i);
         }
     });
     ex.run([&](int lane) {
@@ -769,8 +818,8 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
                 a_rc += rotate_adj_q(rc, ey_, c1);
                 a_rc += rotate_adj_q(rc, ez_, c2);
             }
-            add3(WF(axsc) + 7 * i, a_c);
-            addq(WF(axsc) + 7 * i + 3, a_rc);
+            st3(WF(axsc) + 7 * i, ld3(WF(agx) + 13 * i) + a_c);
+            stq(WF(axsc) + 7 * i + 3, ldq(WF(agx) + 13 * i + 3) + a_rc);
             const v3 pj = ld3(WF(xsj) + 7 * i);
             const q4 rj = ldq(WF(xsj) + 7 * i + 3);
             v3 a_pj = zero3();
@@ -795,10 +844,11 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
     });
     // FK^T, leaves to root
     for (int lv = c.d.D - 1; lv >= 0; --lv) {
-        const int b0 = CI(lvl_start)[lv], b1 = CI(lvl_start)[lv + 1];
         ex.run([&](int lane) {
-            for (int idx = b0 + lane; idx < b1; idx += DSIM_NL) {
-                const int i = CI(lvl_links)[idx], par = CI(parent)[i], type = CI(jtype)[i], cs = CI(qstart)[i];
+            for (int i = lane; i < c.d.L; i += DSIM_NL) {
+                const DsimLinkInfo li = dsim_link_info(c, i);
+                if (li.level != lv) continue;
+                const int par = li.parent, type = li.type, cs = li.cs;
                 v3 a_pc = ld3(WF(axsc) + 7 * i);
                 q4 a_rc = ldq(WF(axsc) + 7 * i + 3);
                 for (int e = CI(child_start)[i]; e < CI(child_start)[i + 1]; ++e) {
@@ -865,6 +915,7 @@ DSIM_FN void dsim_env_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
                                     const float* g_gqd_out, float* g_gq_in, float* g_gqd_in, float* g_gact,
                                     float* g_gmact) {
     const int nq = c.d.nq, nd = c.d.nd, M = c.d.M;
+    dsim_init_static(c, ex);
     ex.run([&](int lane) {
         for (int k = lane; k < nq; k += DSIM_NL) WF(aqn)[k] = g_gq_out[k];
         for (int k = lane; k < nd; k += DSIM_NL) {
@@ -1129,6 +1180,7 @@ DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& s
                                     const float* g_q, const float* g_qd, const float* g_actions, float* g_q_out,
                                     float* g_qd_out, float* g_obs, float* g_rew, float* g_ckpt) {
     const int nq = c.d.nq, nd = c.d.nd;
+    dsim_init_static(c, ex);
     ex.run([&](int lane) {
         for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = g_q[k];
         for (int k = lane; k < nd; k += DSIM_NL) WF(qd)[k] = g_qd[k];
@@ -1171,6 +1223,7 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
                                      const float* g_gobs, const float* g_grew, float* g_gq_in, float* g_gqd_in,
                                      float* g_gactions) {
     const int nq = c.d.nq, nd = c.d.nd, M = c.d.M;
+    dsim_init_static(c, ex);
     ex.run([&](int lane) {
         for (int k = lane; k < nq; k += DSIM_NL) {
             WF(q)[k] = g_q_out[k];

@@ -16,12 +16,16 @@
 
 struct DsimDims {
     int L, nq, nd, C, M, W, NS, D;  // links, coords, dofs, contacts, muscles, waypoints, active muscle segments, tree levels
+    int flags;                      // DSIM_F_*
 };
+#define DSIM_F_RANGES 1  // subtree(i) == links [i, i+n_i) and its contacts == one contiguous contact range (pre-order numbering)
 
 struct DsimOff {
     // ---- constant block: ints
     int jtype, parent, qstart, qdstart, lvl_start, lvl_links, dof_link;
+    int linfo;                  // [L][8] packed per-link record: parent, type, q start, qd start, level, subtree size, first subtree contact, subtree contact count
     int anc_start, anc_list;    // ancestors-or-self of link i, root first
+    int adof_start, adof_list;  // dofs of all ancestors-or-self of link i
     int sub_start, sub_list;    // subtree of link i (self first, then descendants ascending)
     int child_start, child_list;
     int cb_start, cb_list;      // contacts of body i
@@ -42,7 +46,7 @@ struct DsimOff {
     int fwd_words;
     // ---- adjoint work arrays (floats)
     int aq, aqd, aqn, aqdn, aact, amact, aqdd, atau, aS, aftot, af, acx, axsc, axsj, ac, av, aa, aatot, avtot, avj,
-        ai10, ai10m, aic10, aH, topar, amus, gua;
+        ai10, ai10m, aic10, aH, topar, amus, gua, agx;
     int total_words;
 };
 
@@ -126,6 +130,12 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
         start[v.size()] = (int)list.size();
     };
     flatten(anc, anc_start, anc_list);
+    std::vector<std::vector<int>> adof(L);
+    for (int i = 0; i < L; ++i)
+        for (int j : anc[i])
+            for (int d = m.joint_qd_start[j]; d < m.joint_qd_start[j + 1]; ++d) adof[i].push_back(d);
+    std::vector<int> adof_start(L + 1, 0), adof_list;
+    flatten(adof, adof_start, adof_list);
     flatten(sub, sub_start, sub_list);
     flatten(child, child_start, child_list);
     std::vector<std::vector<int>> cb(L);
@@ -194,8 +204,31 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.lvl_start = put_i(lvl_start.data(), D + 1);
     o.lvl_links = put_i(lvl_links.data(), L);
     o.dof_link = put_i(dof_link.data(), nd);
+    // packed per-link record (16-byte aligned so that it is two ds_read_b128) + the range fast-path check
+    bool ranges = true;
+    std::vector<int> linfo(8 * L, 0);
+    for (int i = 0; i < L; ++i) {
+        const int ns = (int)sub[i].size();
+        for (int k = 0; k < ns; ++k)
+            if (sub[i][k] != i + k) ranges = false;
+        const int nc = (int)scb[i].size();
+        for (int k = 0; k + 1 < nc; ++k)
+            if (scb[i][k + 1] != scb[i][k] + 1) ranges = false;
+        linfo[8 * i + 0] = m.joint_parent[i];
+        linfo[8 * i + 1] = m.joint_type[i];
+        linfo[8 * i + 2] = m.joint_q_start[i];
+        linfo[8 * i + 3] = m.joint_qd_start[i];
+        linfo[8 * i + 4] = level[i];
+        linfo[8 * i + 5] = ns;
+        linfo[8 * i + 6] = nc ? scb[i][0] : 0;
+        linfo[8 * i + 7] = nc;
+    }
+    while (blob.size() % 4) blob.push_back(0);
+    o.linfo = put_i(linfo.data(), linfo.size());
     o.anc_start = put_i(anc_start.data(), L + 1);
     o.anc_list = put_i(anc_list.data(), anc_list.size());
+    o.adof_start = put_i(adof_start.data(), L + 1);
+    o.adof_list = put_i(adof_list.data(), adof_list.size());
     o.sub_start = put_i(sub_start.data(), L + 1);
     o.sub_list = put_i(sub_list.data(), sub_list.size());
     o.child_start = put_i(child_start.data(), L + 1);
@@ -262,10 +295,10 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.acx = take(13 * C); o.axsc = take(7 * L); o.axsj = take(7 * L); o.ac = take(3 * L);
     o.av = take(6 * L); o.aa = take(6 * L); o.aatot = take(6 * L); o.avtot = take(6 * L); o.avj = take(6 * L);
     o.ai10 = take(10 * L); o.ai10m = take(10 * L); o.aic10 = take(10 * L); o.aH = take(nd * nd);
-    o.topar = take(7 * L); o.amus = take(0); o.gua = take(M > nd ? M : nd);
+    o.topar = take(7 * L); o.amus = take(0); o.gua = take(M > nd ? M : nd); o.agx = take(13 * L);
     o.total_words = cur;
 
     out.o = o;
-    out.d = DsimDims{L, nq, nd, C, M, W, NS, D};
+    out.d = DsimDims{L, nq, nd, C, M, W, NS, D, ranges ? DSIM_F_RANGES : 0};
     return "";
 }
