@@ -286,15 +286,27 @@ class ModelBuilder:
 
 class State:
     """Time-varying state (reference: dflex/dflex/model.py:50-130).  Only the tensors that cross the
-    DFlexEnv boundary exist; the derived per-substep tensors of the reference live in LDS."""
+    DFlexEnv boundary exist; the derived per-substep tensors of the reference live in LDS.
+    `joint_act` is allocated (zeros) on first access: the fused env path never touches it."""
 
-    def __init__(self):
+    def __init__(self, act_like=None):
         self.joint_q = None
         self.joint_qd = None
-        self.joint_act = None
+        self._joint_act = None
+        self._act_like = act_like
+
+    @property
+    def joint_act(self):
+        if self._joint_act is None and self._act_like is not None:
+            self._joint_act = torch.zeros_like(self._act_like)
+        return self._joint_act
+
+    @joint_act.setter
+    def joint_act(self, value):
+        self._joint_act = value
 
     def flatten(self):
-        return [t for t in (self.joint_q, self.joint_qd, self.joint_act) if torch.is_tensor(t)]
+        return [t for t in (self.joint_q, self.joint_qd, self._joint_act) if torch.is_tensor(t)]
 
 
 def ground_contacts(shape_info):
@@ -346,8 +358,11 @@ class Model:
         self.muscle_params = np.array(muscle_params, dtype=np.float32).reshape(-1, 5)
         self.shape_count = len(shape_info["body"]) * n_art
         self.particle_count = 0
-        self.ground = True
-        self.gravity = torch.tensor((0.0, -9.8, 0.0), dtype=torch.float32, device=self.device)
+        self._engine = None
+        self._engine_key = None
+        self._ground = True
+        self._gravity_host = (0.0, -9.8, 0.0)
+        self._gravity = torch.tensor(self._gravity_host, dtype=torch.float32, device=self.device)
         self.joint_q = torch.tensor(q0.reshape(-1), dtype=torch.float32, device=self.device)
         self.joint_qd = torch.tensor(qd0.reshape(-1), dtype=torch.float32, device=self.device)
         self.joint_target = torch.tensor(np.tile(np.asarray(tdict["joint_target"], np.float32), n_art),
@@ -355,14 +370,32 @@ class Model:
         self.muscle_activation = torch.zeros(self.muscle_count, dtype=torch.float32, device=self.device)
         self.contact_count = 0
         self._contacts = None
+
+    # ground / gravity are part of the device-side model: setting them invalidates the engine (no per-step
+    # device->host reads are needed to notice a change)
+    @property
+    def ground(self):
+        return self._ground
+
+    @ground.setter
+    def ground(self, value):
+        self._ground = bool(value)
         self._engine = None
-        self._engine_key = None
+
+    @property
+    def gravity(self):
+        return self._gravity
+
+    @gravity.setter
+    def gravity(self, value):
+        self._gravity_host = tuple(float(x) for x in (value.detach().cpu().tolist() if torch.is_tensor(value) else value))
+        self._gravity = torch.tensor(self._gravity_host, dtype=torch.float32, device=self.device)
+        self._engine = None
 
     def state(self):
-        s = State()
+        s = State(act_like=self.joint_qd)
         s.joint_q = self.joint_q.clone()
         s.joint_qd = self.joint_qd.clone()
-        s.joint_act = torch.zeros_like(self.joint_qd)
         return s
 
     def collide(self, state=None):
@@ -382,18 +415,13 @@ class Model:
         else:
             d.update(contact_body=np.zeros(0, np.int32), contact_point=np.zeros((0, 3)), contact_dist=np.zeros(0),
                      contact_material=np.zeros((0, 4)))
-        g = self.gravity.detach().cpu().numpy() if torch.is_tensor(self.gravity) else np.asarray(self.gravity)
-        return ArticulationTemplate(gravity=g, **d)
+        return ArticulationTemplate(gravity=np.asarray(self._gravity_host, dtype=np.float32), **d)
 
     def engine(self):
         """Device-side model handle; rebuilt if ground / gravity / contacts changed since the last step."""
-        g = tuple(float(x) for x in (self.gravity.detach().cpu().tolist() if torch.is_tensor(self.gravity)
-                                     else self.gravity))
-        key = (bool(self.ground), g, self.contact_count)
-        if self._engine is None or self._engine_key != key:
+        if self._engine is None:
             from ..engine import Engine
             self._engine = Engine(self.template(), self.device)
-            self._engine_key = key
         return self._engine
 
     def flatten(self):

@@ -144,9 +144,8 @@ class DFlexEnv:
         else:
             q, qd, obs, rew = EnvStep.apply(eng, spec, float(self.sim_dt), self.sim_substeps, self.MM_caching_frequency,
                                             self.state.joint_q, self.state.joint_qd, actions)
-        st = df.State()
+        st = df.State(act_like=self.model.joint_qd)
         st.joint_q, st.joint_qd = q, qd
-        st.joint_act = torch.zeros_like(self.model.joint_qd)
         self.state = st
         if spec.obs_actions:
             self.actions = obs[:, self.num_observations - self.num_actions:]

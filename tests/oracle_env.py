@@ -43,10 +43,9 @@ def make_cpu_env(name, n, template):
     class OracleIntegrator:
         def forward(self, model, state, dt_, substeps, mm_freq):
             assert substeps == S and mm_freq == mm
-            st = State()
+            st = State(act_like=model.joint_qd)
             mact = model.muscle_activation if model.muscle_count else None
             st.joint_q, st.joint_qd = OracleStep.apply(state.joint_q, state.joint_qd, state.joint_act, mact)
-            st.joint_act = torch.zeros_like(model.joint_qd)
             return st
 
     e.integrator = OracleIntegrator()
