@@ -144,7 +144,7 @@ def main():
         achieved = bwd_bytes / t_bwd / 1e9
         traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
         try:
-            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
+            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_final_pmc.json"))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
             if a.env == "ant" and n == 1024 and pmc.get("kernel") in ("dsim_bwd_kernel", "dsim_env_bwd_kernel"):
                 traffic = pmc["traffic_bytes_per_launch"]
