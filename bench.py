@@ -20,18 +20,18 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-ALG_BYTES = {"ant": 748, "humanoid": 1424, "snu": 2884, "cartpole": 104}  # per env-step fwd+adjoint, SURVEY.md 8(d)
+ALG_BYTES = {"ant": 748, "humanoid": 1424, "snu": 2884, "cartpole": 104, "hopper": 300, "cheetah": 444}  # per env-step fwd+adjoint, SURVEY.md 8(d)
 HBM_PEAK_GBS = 8000.0
-MM_FREQ = {"ant": 16, "humanoid": 48, "snu": 8, "cartpole": 4}  # examples/cfg/shac/*.yaml
+MM_FREQ = {"ant": 16, "humanoid": 48, "snu": 8, "cartpole": 4, "hopper": 16, "cheetah": 16}  # examples/cfg/shac/*.yaml
 
 
 def make_env(name, n, device):
     from diffrl_amd import envs
     cls = {"ant": envs.AntEnv, "humanoid": envs.HumanoidEnv, "snu": envs.SNUHumanoidEnv,
-           "cartpole": envs.CartPoleSwingUpEnv}[name]
+           "cartpole": envs.CartPoleSwingUpEnv, "hopper": envs.HopperEnv, "cheetah": envs.CheetahEnv}[name]
     kw = dict(num_envs=n, device=device, render=False, seed=0, episode_length=100000, no_grad=False,
               stochastic_init=False, MM_caching_frequency=MM_FREQ[name])
-    if name in ("ant", "cartpole"):
+    if name in ("ant", "cartpole", "hopper", "cheetah"):
         kw["early_termination"] = False
     return cls(**kw)
 

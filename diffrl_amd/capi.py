@@ -43,8 +43,8 @@ class EnvSpec(C.Structure):
     ]
 
 
-ENV_LOCOMOTION, ENV_CARTPOLE = 1, 2
-REW_ANT, REW_HUMANOID, REW_SNU, REW_CARTPOLE = 0, 1, 2, 3
+ENV_LOCOMOTION, ENV_CARTPOLE, ENV_PLANAR = 1, 2, 3
+REW_ANT, REW_HUMANOID, REW_SNU, REW_CARTPOLE, REW_HOPPER, REW_CHEETAH = 0, 1, 2, 3, 4, 5
 
 
 def make_env_spec(kind, rew_kind, n_act, n_obs, act_scale_ptr, act_offset=0, act_muscle=False, obs_actions=False,

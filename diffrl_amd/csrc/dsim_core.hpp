@@ -979,10 +979,13 @@ DSIM_FN void dsim_env_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
 // ================================================================================================
 #define DSIM_ENV_LOCOMOTION 1   // free-floating root: [h, quat, lin vel, ang vel, joint q, joint qd*s, up, heading, (actions)]
 #define DSIM_ENV_CARTPOLE 2     // [x, xdot, sin th, cos th, thdot]
+#define DSIM_ENV_PLANAR 3       // planar root (slide x, slide z, hinge y): [q[1:], qd]  (hopper, half-cheetah)
 #define DSIM_REW_ANT 0
 #define DSIM_REW_HUMANOID 1
 #define DSIM_REW_SNU 2
 #define DSIM_REW_CARTPOLE 3
+#define DSIM_REW_HOPPER 4
+#define DSIM_REW_CHEETAH 5
 
 struct DsimEnvSpec {
     int kind, rew_kind;
@@ -1053,6 +1056,9 @@ DSIM_FN void dsim_env_observe(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, flo
                 o[3] = cosf(q[1]);
                 o[4] = qd[1];
             }
+        } else if (sp.kind == DSIM_ENV_PLANAR) {
+            for (int k = lane; k < nq - 1; k += DSIM_NL) o[k] = q[1 + k];
+            for (int k = lane; k < nd; k += DSIM_NL) o[nq - 1 + k] = qd[k];
         }
     });
     ex.run([&](int lane) {
@@ -1084,6 +1090,18 @@ DSIM_FN void dsim_env_observe(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, flo
                 const float a = WF(ua)[0];
                 r = -th * th * sp.pen[0] - o[4] * o[4] * sp.pen[1] - o[0] * o[0] * sp.pen[2] - o[1] * o[1] * sp.pen[3] -
                     a * a * sp.act_pen;
+            } else if (sp.kind == DSIM_ENV_PLANAR) {
+                float pen = 0.f;
+                for (int k = 0; k < sp.n_act; ++k) pen += WF(ua)[k] * WF(ua)[k];
+                r = o[nq - 1] + pen * sp.act_pen;  // progress = qd[0]
+                if (sp.rew_kind == DSIM_REW_HOPPER) {
+                    // envs/hopper.py:279-288: clipped / shaped height term + upright term (pen[0] = termination angle)
+                    float hr = o[0] - (sp.term_h + sp.term_tol);
+                    hr = hr < -1.0f ? -1.0f : (hr > 0.3f ? 0.3f : hr);
+                    if (hr < 0.0f) hr = -200.0f * hr * hr;
+                    if (hr > 0.0f) hr = sp.h_scale * hr;
+                    r += hr + (1.0f - o[1] * o[1] / (sp.pen[0] * sp.pen[0]));
+                }
             }
             g_rew[0] = r;
         }
@@ -1161,6 +1179,23 @@ DSIM_FN void dsim_env_observe_adjoint(const Ctx& c, Exec& ex, const DsimEnvSpec&
                 add3(WF(aqdn), g_w);
                 add3(WF(aqdn) + 3, g_lv);
             }
+        } else if (sp.kind == DSIM_ENV_PLANAR) {
+            for (int k = lane; k < nq - 1; k += DSIM_NL) {
+                float g = go[k];
+                if (sp.rew_kind == DSIM_REW_HOPPER) {
+                    if (k == 0) {
+                        const float d = q[1] - (sp.term_h + sp.term_tol);
+                        float dh = 0.f;
+                        if (d >= -1.0f && d <= 0.3f) dh = d < 0.0f ? -400.0f * d : (d > 0.0f ? sp.h_scale : 1.0f);
+                        g += gr * dh;
+                    } else if (k == 1) {
+                        g += gr * (-2.0f * q[2] / (sp.pen[0] * sp.pen[0]));
+                    }
+                }
+                WF(aqn)[1 + k] += g;
+            }
+            for (int k = lane; k < nd; k += DSIM_NL) WF(aqdn)[k] += go[nq - 1 + k] + (k == 0 ? gr : 0.f);
+            for (int k = lane; k < sp.n_act; k += DSIM_NL) WF(gua)[k] = gr * sp.act_pen * 2.0f * WF(ua)[k];
         } else if (sp.kind == DSIM_ENV_CARTPOLE) {
             if (lane == 0) {
                 const float th = atan2f(sinf(q[1]), cosf(q[1]));

@@ -273,7 +273,8 @@ int launched(const char* what) {
 int make_spec(const dsim_model* m, const dsim_env_spec* e, DsimEnvSpec& sp) {
     if (!e) return fail(DSIM_ERR_INVALID, "null env spec");
     const DsimDims& d = m->lay.d;
-    if (e->kind != DSIM_ENV_LOCOMOTION && e->kind != DSIM_ENV_CARTPOLE) return fail(DSIM_ERR_INVALID, "unknown env kind");
+    if (e->kind != DSIM_ENV_LOCOMOTION && e->kind != DSIM_ENV_CARTPOLE && e->kind != DSIM_ENV_PLANAR)
+        return fail(DSIM_ERR_INVALID, "unknown env kind");
     if (e->n_act <= 0 || e->n_act > (d.M > d.nd ? d.M : d.nd)) return fail(DSIM_ERR_INVALID, "n_act out of range");
     if (!e->act_scale) return fail(DSIM_ERR_INVALID, "null act_scale");
     if (e->act_muscle) {
@@ -286,6 +287,9 @@ int make_spec(const dsim_model* m, const dsim_env_spec* e, DsimEnvSpec& sp) {
         if (d.nq < 7 || d.nd < 6 || m->lay.cblob[m->lay.o.jtype] != DSIM_JOINT_FREE)
             return fail(DSIM_ERR_INVALID, "locomotion observations need a free-floating root joint");
         expect = 13 + (d.nq - 7) + (d.nd - 6) + (e->obs_actions ? e->n_act : 0);
+    } else if (e->kind == DSIM_ENV_PLANAR) {
+        if (d.nq != d.nd || d.nq < 3) return fail(DSIM_ERR_INVALID, "planar observations need a 3-dof planar root");
+        expect = d.nq - 1 + d.nd;
     } else {
         if (d.nq != 2 || d.nd != 2) return fail(DSIM_ERR_INVALID, "cartpole observations need 2 coordinates");
         expect = 5;

@@ -4,4 +4,5 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from diffrl_amd.envs import *  # noqa: F401,F403,E402
-from diffrl_amd.envs import AntEnv, CartPoleSwingUpEnv, DFlexEnv, HumanoidEnv, SNUHumanoidEnv  # noqa: F401,E402
+from diffrl_amd.envs import (AntEnv, CartPoleSwingUpEnv, CheetahEnv, DFlexEnv, HopperEnv, HumanoidEnv,  # noqa: F401,E402
+                             SNUHumanoidEnv)

@@ -130,10 +130,13 @@ int dsim_step_backward(const dsim_model* m, int n_envs,
  * step kernels, adjoint included, so that one env.step() is ONE launch forward and ONE backward. */
 #define DSIM_ENV_LOCOMOTION 1 /* free root: [h, quat(4), lin vel(3), ang vel(3), q[7:], s*qd[6:], up, heading, (actions)] */
 #define DSIM_ENV_CARTPOLE 2   /* [x, xdot, sin th, cos th, thdot] */
+#define DSIM_ENV_PLANAR 3     /* planar root (hopper, half-cheetah; envs/hopper.py:273, cheetah.py:254): [q[1:], qd] */
 #define DSIM_REW_ANT 0
 #define DSIM_REW_HUMANOID 1
 #define DSIM_REW_SNU 2
 #define DSIM_REW_CARTPOLE 3
+#define DSIM_REW_HOPPER 4     /* cartpole_penalties[0] carries the termination angle */
+#define DSIM_REW_CHEETAH 5
 
 typedef struct dsim_env_spec {
     int32_t kind, rew_kind;

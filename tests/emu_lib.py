@@ -102,6 +102,15 @@ def env_spec_for(env_name, t):
         sc = np.full(1, 1000.0, np.float32)
         return capi.make_env_spec(capi.ENV_CARTPOLE, capi.REW_CARTPOLE, 1, 5, sc.ctypes.data, action_penalty=0.0,
                                   cartpole_penalties=(1.0, 0.1, 0.05, 0.1)), sc
+    if env_name in ("hopper", "cheetah"):
+        na = 3 if env_name == "hopper" else 6
+        sc = np.full(na, 200.0, np.float32)
+        if env_name == "hopper":
+            return capi.make_env_spec(capi.ENV_PLANAR, capi.REW_HOPPER, 3, 11, sc.ctypes.data, act_offset=3,
+                                      action_penalty=-0.1, termination_height=-0.45, termination_tolerance=0.15,
+                                      height_rew_scale=1.0, cartpole_penalties=(math.pi / 6.0, 0.0, 0.0, 0.0)), sc
+        return capi.make_env_spec(capi.ENV_PLANAR, capi.REW_CHEETAH, 6, 17, sc.ctypes.data, act_offset=3,
+                                  action_penalty=-0.1), sc
     if env_name == "ant":
         sr, h, tgt = U.quat_from_axis_angle((1.0, 0.0, 0.0), -math.pi * 0.5), 0.75, 10000.0
         sc = np.full(8, 200.0, np.float32)

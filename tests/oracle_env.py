@@ -9,16 +9,16 @@ from diffrl_amd import envs
 from diffrl_amd.dflex.model import State
 from oracle_lib import oracle_backward, oracle_forward
 
-SUBSTEPS = {"cartpole": 4, "ant": 16, "humanoid": 48, "snu": 48}
-MM = {"cartpole": 4, "ant": 16, "humanoid": 48, "snu": 8}
+SUBSTEPS = {"cartpole": 4, "ant": 16, "humanoid": 48, "snu": 48, "hopper": 16, "cheetah": 16}
+MM = {"cartpole": 4, "ant": 16, "humanoid": 48, "snu": 8, "hopper": 16, "cheetah": 16}
 CLS = {"cartpole": envs.CartPoleSwingUpEnv, "ant": envs.AntEnv, "humanoid": envs.HumanoidEnv,
-       "snu": envs.SNUHumanoidEnv}
+       "snu": envs.SNUHumanoidEnv, "hopper": envs.HopperEnv, "cheetah": envs.CheetahEnv}
 
 
 def make_cpu_env(name, n, template):
     kw = dict(num_envs=n, device="cpu", render=False, seed=0, episode_length=1000, no_grad=False,
               stochastic_init=False, MM_caching_frequency=MM[name])
-    if name in ("cartpole", "ant"):
+    if name in ("cartpole", "ant", "hopper", "cheetah"):
         kw["early_termination"] = False
     e = CLS[name](**kw)
     e.fused = False

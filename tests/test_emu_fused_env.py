@@ -6,10 +6,10 @@ import pytest
 from emu_lib import emu_env_backward, emu_env_forward, env_spec_for
 from oracle_lib import golden, relerr, template_from_golden
 
-SUBSTEPS = {"cartpole": 4, "ant": 16, "humanoid": 48, "snu": 48}
+SUBSTEPS = {"cartpole": 4, "ant": 16, "humanoid": 48, "snu": 48, "hopper": 16, "cheetah": 16}
 
 
-@pytest.mark.parametrize("env", ["cartpole", "ant", "humanoid", "snu"])
+@pytest.mark.parametrize("env", ["cartpole", "ant", "humanoid", "snu", "hopper", "cheetah"])
 def test_fused_rollout_vs_reference(env):
     t = template_from_golden(env)
     g = golden(env + "_rollout")

@@ -8,7 +8,7 @@ import pytest
 from emu_lib import emu_backward, emu_forward, layout
 from oracle_lib import golden, oracle_backward, project_tangent, relerr, template_from_golden
 
-ENVS = ["cartpole", "ant", "humanoid", "snu"]
+ENVS = ["cartpole", "ant", "humanoid", "snu", "hopper", "cheetah"]
 
 
 @pytest.mark.parametrize("env", ENVS)

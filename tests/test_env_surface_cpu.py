@@ -7,7 +7,7 @@ from oracle_env import rollout_grad
 from oracle_lib import golden, relerr, template_from_golden
 
 
-@pytest.mark.parametrize("env", ["cartpole", "ant", "humanoid", "snu"])
+@pytest.mark.parametrize("env", ["cartpole", "ant", "humanoid", "snu", "hopper", "cheetah"])
 def test_torch_env_surface_plus_oracle_vs_reference_rollout(env):
     t = template_from_golden(env)
     g = golden(env + "_rollout")

@@ -9,17 +9,17 @@ import torch
 from oracle_lib import golden, relerr
 
 pytestmark = pytest.mark.gpu
-CASES = ["cartpole", "ant", "humanoid", "snu"]
+CASES = ["cartpole", "ant", "humanoid", "snu", "hopper", "cheetah"]
 
 
 def _make(env, n, no_grad=False):
     from diffrl_amd import envs
     cls = {"cartpole": envs.CartPoleSwingUpEnv, "ant": envs.AntEnv, "humanoid": envs.HumanoidEnv,
-           "snu": envs.SNUHumanoidEnv}[env]
-    mm = {"cartpole": 4, "ant": 16, "humanoid": 48, "snu": 8}[env]
+           "snu": envs.SNUHumanoidEnv, "hopper": envs.HopperEnv, "cheetah": envs.CheetahEnv}[env]
+    mm = {"cartpole": 4, "ant": 16, "humanoid": 48, "snu": 8, "hopper": 16, "cheetah": 16}[env]
     kw = dict(num_envs=n, device="cuda:0", render=False, seed=0, episode_length=1000, no_grad=no_grad,
               stochastic_init=False, MM_caching_frequency=mm)
-    if env in ("cartpole", "ant"):
+    if env in ("cartpole", "ant", "hopper", "cheetah"):
         kw["early_termination"] = False
     return cls(**kw)
 

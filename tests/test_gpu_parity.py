@@ -8,7 +8,7 @@ import torch
 from oracle_lib import golden, oracle_backward, oracle_forward, project_tangent, relerr, template_from_golden
 
 pytestmark = pytest.mark.gpu
-ENVS = ["cartpole", "ant", "humanoid", "snu"]
+ENVS = ["cartpole", "ant", "humanoid", "snu", "hopper", "cheetah"]
 
 
 @pytest.fixture(scope="module")

@@ -11,7 +11,7 @@ from diffrl_amd import envs
 from oracle_lib import golden
 
 CASES = [("ant", envs.AntEnv), ("humanoid", envs.HumanoidEnv), ("snu", envs.SNUHumanoidEnv),
-         ("cartpole", envs.CartPoleSwingUpEnv)]
+         ("cartpole", envs.CartPoleSwingUpEnv), ("hopper", envs.HopperEnv), ("cheetah", envs.CheetahEnv)]
 FIELDS = ["joint_type", "joint_parent", "joint_q_start", "joint_qd_start", "joint_X_pj", "joint_X_cm", "joint_axis",
           "body_I_m", "joint_armature", "joint_target", "joint_target_ke", "joint_target_kd", "joint_limit_lower",
           "joint_limit_upper", "joint_limit_ke", "joint_limit_kd", "contact_body", "contact_point", "contact_dist",
@@ -36,7 +36,7 @@ def _check(env, t, exact):
 @pytest.mark.parametrize("env,cls", CASES)
 def test_compiled_asset_matches_reference_model(env, cls, monkeypatch):
     monkeypatch.setattr(de, "find_asset", lambda name: None)  # force the .npz path (what the GPU box uses)
-    for mod in (envs.ant, envs.humanoid, envs.snu_humanoid, envs.cartpole_swing_up):
+    for mod in (envs.ant, envs.humanoid, envs.snu_humanoid, envs.cartpole_swing_up, envs.planar):
         monkeypatch.setattr(mod, "find_asset", lambda name: None)
     e = cls(num_envs=3, device="cpu", no_grad=True)
     _check(env, e.model.template(), exact=True)
@@ -45,7 +45,8 @@ def test_compiled_asset_matches_reference_model(env, cls, monkeypatch):
 
 @pytest.mark.parametrize("env,cls", CASES)
 def test_loader_matches_reference_model(env, cls):
-    probe = {"ant": "ant.xml", "humanoid": "humanoid.xml", "snu": "snu/human.xml", "cartpole": "cartpole.urdf"}[env]
+    probe = {"ant": "ant.xml", "humanoid": "humanoid.xml", "snu": "snu/human.xml", "cartpole": "cartpole.urdf",
+             "hopper": "hopper.xml", "cheetah": "half_cheetah.xml"}[env]
     if de.find_asset(probe) is None:
         pytest.skip("original asset files not available here")
     e = cls(num_envs=2, device="cpu", no_grad=True)

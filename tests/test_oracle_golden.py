@@ -5,7 +5,7 @@ import pytest
 
 from oracle_lib import golden, oracle_backward, oracle_forward, template_from_golden
 
-ENVS = ["cartpole", "ant", "humanoid", "snu"]
+ENVS = ["cartpole", "ant", "humanoid", "snu", "hopper", "cheetah"]
 
 
 def relerr(a, b):

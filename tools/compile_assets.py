@@ -11,7 +11,8 @@ from diffrl_amd.envs.dflex_env import ASSET_DIR, find_asset  # noqa: E402
 
 if __name__ == "__main__":
     jobs = [("ant", envs.AntEnv, "ant.xml"), ("humanoid", envs.HumanoidEnv, "humanoid.xml"),
-            ("cartpole", envs.CartPoleSwingUpEnv, "cartpole.urdf"), ("snu_humanoid", envs.SNUHumanoidEnv, "snu/human.xml")]
+            ("cartpole", envs.CartPoleSwingUpEnv, "cartpole.urdf"), ("snu_humanoid", envs.SNUHumanoidEnv, "snu/human.xml"),
+            ("hopper", envs.HopperEnv, "hopper.xml"), ("half_cheetah", envs.CheetahEnv, "half_cheetah.xml")]
     for name, cls, probe in jobs:
         assert find_asset(probe) is not None, "original asset %s not found (set DIFFRL_ASSETS)" % probe
         b = cls.make_builder()
