@@ -123,6 +123,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_init_static(const Ctx& c, Exe
 }
 
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, Exec& ex) {
+    ex.mark(1);
     for (int lv = 0; lv < c.d.D; ++lv) {
         ex.run([&](int lane) {
             for (int i = lane; i < c.d.L; i += DSIM_NL) {
@@ -224,6 +225,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
 
 // ground contacts (sim.py:1137-1206) and muscle segments (sim.py:1209-1242): per-item wrenches
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Exec& ex) {
+    ex.mark(2);
     if (c.d.C == 0 && c.d.NS == 0) return;
     ex.run([&](int lane) {
         for (int k = lane; k < c.d.C; k += DSIM_NL) {
@@ -282,6 +284,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Ex
 
 // joint-space forces (sim.py:1421-1502, 1792-1842)
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_tau(const Ctx& c, Exec& ex) {
+    ex.mark(3);
     // f_tot[i] = sum over subtree(i) of (inverse-dynamics force [+ muscle wrenches, gathered per body]) + contact wrenches
     ex.run([&](int lane) {
         for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
@@ -321,6 +324,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_tau(const Ctx& c, Exec& e
 
 // composite inertias Ic[i] = sum over subtree(i), F_b = Ic[link(b)] S_b
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_composite(const Ctx& c, Exec& ex) {
+    ex.mark(4);
     const int nd = c.d.nd;
     ex.run([&](int lane) {
         for (int it = lane; it < 10 * c.d.L; it += DSIM_NL) {
@@ -370,6 +374,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_mass(const Ctx& c, Exec& 
 }
 
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_solve(const Ctx& c, Exec& ex) {
+    ex.mark(5);
     const int nd = c.d.nd;
     ex.run([&](int lane) {
         for (int i = lane; i < nd; i += DSIM_NL) {
@@ -380,6 +385,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_solve(const Ctx& c, Exec&
 
 // semi-implicit Euler (sim.py:1505-1636); in place on q, qd
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_integrate(const Ctx& c, Exec& ex) {
+    ex.mark(6);
     ex.run([&](int lane) {
         const float h = c.h;
         for (int i = lane; i < c.d.L; i += DSIM_NL) {
@@ -466,6 +472,7 @@ DSIM_FN void dsim_env_step_forward(const Ctx& c, Exec& ex, int substeps, int mm_
 
 // integrate^T, solve^T (matnn.h:310-336), tau^T
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c, Exec& ex) {
+    ex.mark(7);
     const int nd = c.d.nd;
     ex.run([&](int lane) {
         const float h = c.h;
@@ -566,6 +573,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
 
 // contacts^T and muscles^T: per-item cotangents of (X_sc, v_s) / (X_sc, activation)
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external(const Ctx& c, Exec& ex) {
+    ex.mark(8);
     if (c.d.C == 0 && c.d.NS == 0) return;
     ex.run([&](int lane) {
         for (int k = lane; k < c.d.C; k += DSIM_NL) {
@@ -661,6 +669,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external(const Ctx& c, Ex
 
 // mass matrix^T (update substeps): aH -> aS (added), ai10m
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_mass(const Ctx& c, Exec& ex) {
+    ex.mark(9);
     const int nd = c.d.nd;
     ex.run([&](int lane) {
         for (int a = lane; a < nd; a += DSIM_NL) {
@@ -679,38 +688,43 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_mass(const Ctx& c, Exec& 
             add3(o, acc.w);
             add3(o + 3, acc.v);
         }
-        for (int j = lane; j < c.d.L; j += DSIM_NL) {
+        // cotangent of the composite inertia of link(b), one partial per dof b (upper lanes run concurrently with the
+        // aS loop above): pairs {a, b} whose deeper link is link(b); same-link pairs are counted once (a <= b)
+        for (int t = lane; t < nd + 32; t += DSIM_NL) {
+            const int b = t - 32;
+            if (b < 0) continue;
             float g[10];
             for (int k = 0; k < 10; ++k) g[k] = 0.f;
-            for (int b = CI(qdstart)[j]; b < CI(qdstart)[j + 1]; ++b) {
-                const sv6 Sb = ldsv(WF(S) + 6 * b);
-                for (int a = 0; a < nd; ++a) {
-                    const int la = CI(dof_link)[a];
-                    float w;
-                    if (la == j) {
-                        if (a > b) continue;
-                        w = (a == b) ? WF(aH)[a * nd + a] : WF(aH)[a * nd + b] + WF(aH)[b * nd + a];
-                    } else if (CI(rel)[a * nd + b] == 1) {
-                        w = WF(aH)[a * nd + b] + WF(aH)[b * nd + a];
-                    } else {
-                        continue;
-                    }
-                    inertia_bilinear_adj(g, ldsv(WF(S) + 6 * a), Sb, w);
+            const int j = CI(dof_link)[b];
+            const sv6 Sb = ldsv(WF(S) + 6 * b);
+            for (int a = 0; a < nd; ++a) {
+                const int la = CI(dof_link)[a];
+                float w;
+                if (la == j) {
+                    if (a > b) continue;
+                    w = (a == b) ? WF(aH)[a * nd + a] : WF(aH)[a * nd + b] + WF(aH)[b * nd + a];
+                } else if (CI(rel)[a * nd + b] == 1) {
+                    w = WF(aH)[a * nd + b] + WF(aH)[b * nd + a];
+                } else {
+                    continue;
                 }
+                inertia_bilinear_adj(g, ldsv(WF(S) + 6 * a), Sb, w);
             }
-            for (int k = 0; k < 10; ++k) WF(aic10)[10 * j + k] = g[k];
+            for (int k = 0; k < 10; ++k) WF(aic10)[10 * b + k] = g[k];
         }
     });
+    // ai10m[i] = sum over the dofs b of all ancestors-or-self of link i
     ex.run([&](int lane) {
         for (int it = lane; it < 10 * c.d.L; it += DSIM_NL) {
             const int i = it / 10, k = it - 10 * i;
-            WF(ai10m)[it] = dsim_gather_sum(WF(aic10), 10, k, CI(anc_list), CI(anc_start)[i], CI(anc_start)[i + 1], 0.f);
+            WF(ai10m)[it] = dsim_gather_sum(WF(aic10), 10, k, CI(adof_list), CI(adof_start)[i], CI(adof_start)[i + 1], 0.f);
         }
     });
 }
 
 // body level: f^T, velocity/acceleration recursions^T, joint motion^T, pose cotangents, FK^T
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec& ex, bool update_mass) {
+    ex.mark(10);
     ex.run([&](int lane) {
         for (int i = lane; i < c.d.L; i += DSIM_NL) {
             const inertia10 I = ld_i10(WF(i10) + 10 * i);
@@ -745,7 +759,11 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
         // per-body gather of the contact (13 floats: X_sc 7, v_s 6) and muscle (7 floats: X_sc) cotangents
         for (int it = lane; it < 13 * c.d.L; it += DSIM_NL) {
             const int i = it / 13, r = it - 13 * i;
-            float acc = dsim_gather_sum(WF(acx), 13, r, CI(cb_list), CI(cb_start)[i], CI(cb_start)[i + 1], 0.f);
+            float acc;
+            if (c.d.flags & DSIM_F_RANGES)  // pre-order numbering: a body's own contacts are one contiguous range
+                acc = dsim_range_sum(WF(acx), 13, r, CI(cb_start)[i], CI(cb_start)[i + 1] - CI(cb_start)[i], 0.f);
+            else
+                acc = dsim_gather_sum(WF(acx), 13, r, CI(cb_list), CI(cb_start)[i], CI(cb_start)[i + 1], 0.f);
             if (r < 7)
                 for (int e = CI(ml_start)[i]; e < CI(ml_start)[i + 1]; ++e) {
                     const int code = CI(ml_list)[e];

@@ -34,6 +34,7 @@ struct DevExec {
     }
     // phase that only writes global memory nobody in this launch reads back: no barrier, no vmcnt wait
     template <class F> __device__ __forceinline__ void fire(F&& f) { f((int)threadIdx.x); }
+    __device__ __forceinline__ void mark(int) {}
 };
 
 template <class O, class D> struct KCommonT {
@@ -155,10 +156,16 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_env_obs_kernel(KCommonT<O, D> k,
 struct TimingExec {
     long long* buf;
     int idx, cap;
+    int tag = 0;
+    __device__ __forceinline__ void mark(int t) { tag = t * 100; }
     template <class F> __device__ __forceinline__ void run(F&& f) {
         f((int)threadIdx.x);
         __syncthreads();
-        if (blockIdx.x == 0 && threadIdx.x == 0 && idx < cap) buf[idx] = clock64();
+        if (blockIdx.x == 0 && threadIdx.x == 0 && idx < cap) {
+            buf[idx] = clock64();
+            buf[cap + idx] = tag;
+        }
+        ++tag;
         ++idx;
     }
     template <class F> __device__ __forceinline__ void fire(F&& f) { f((int)threadIdx.x); }

@@ -294,7 +294,7 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.aqdd = take(nd); o.atau = take(nd); o.aS = take(6 * nd); o.aftot = take(6 * L); o.af = take(6 * L);
     o.acx = take(13 * C); o.axsc = take(7 * L); o.axsj = take(7 * L); o.ac = take(3 * L);
     o.av = take(6 * L); o.aa = take(6 * L); o.aatot = take(6 * L); o.avtot = take(6 * L); o.avj = take(6 * L);
-    o.ai10 = take(10 * L); o.ai10m = take(10 * L); o.aic10 = take(10 * L); o.aH = take(nd * nd);
+    o.ai10 = take(10 * L); o.ai10m = take(10 * L); o.aic10 = take(10 * (nd > L ? nd : L)); o.aH = take(nd * nd);
     o.topar = take(7 * L); o.amus = take(0); o.gua = take(M > nd ? M : nd); o.agx = take(13 * L);
     o.total_words = cur;
 

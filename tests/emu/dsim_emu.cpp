@@ -15,6 +15,7 @@ struct HostExec {
         for (int lane = 0; lane < DSIM_NL; ++lane) f(lane);
     }
     template <class F> void fire(F&& f) { run(f); }
+    void mark(int) {}
 };
 
 static void make_ctx(const DsimLayout& lay, std::vector<float>& lds, DsimCtx& c, float h) {

@@ -42,7 +42,7 @@ gqi, gqdi, ga = torch.empty_like(q), torch.empty_like(qd), torch.empty_like(a)
 cap = 4096
 p = lambda x: C.c_void_p(x.data_ptr())
 for backward in (0, 1):
-    stamps = torch.zeros(cap, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(2 * cap, dtype=torch.int64, device=dev)
     for _ in range(2):
         rc = L.dsim_debug_phase_timer(h, C.byref(spec), N, backward, p(q), p(qd), p(a), C.c_float(dt), S, mm, p(qo), p(qdo),
                                       p(obs), p(rew), p(ck), p(gq), p(gqd), p(go), p(gr), p(gqi), p(gqdi), p(ga), p(stamps),
@@ -50,7 +50,19 @@ for backward in (0, 1):
         assert rc == 0, L.dsim_last_error()
         torch.cuda.synchronize()
     st = stamps.cpu().numpy()
-    n = int((st != 0).sum())
+    n = int((st[:cap] != 0).sum())
     d = np.diff(st[:n])
+    tags = st[cap + 1:cap + n]
     print("==", env, "N", N, "backward" if backward else "forward", "phases", n - 1, "total cycles", int(st[n - 1] - st[0]))
     print(" ".join(str(int(x)) for x in d))
+    import collections
+    agg = collections.OrderedDict()
+    for t, x in zip(tags.tolist(), d.tolist()):
+        agg.setdefault(t, []).append(x)
+    names = {0: "io", 1: "fwd_kin", 2: "fwd_ext", 3: "fwd_tau", 4: "fwd_mass", 5: "fwd_solve", 6: "fwd_integ", 7: "bwd_joint",
+             8: "bwd_ext", 9: "bwd_mass", 10: "bwd_bodies"}
+    tot = collections.Counter()
+    for t, xs in agg.items():
+        tot[names.get(t // 100, "?")] += sum(xs)
+        print("  %-10s phase %2d: n=%3d mean %6.0f cycles" % (names.get(t // 100, "?"), t % 100, len(xs), sum(xs) / len(xs)))
+    print("  totals:", dict(tot))
