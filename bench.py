@@ -71,24 +71,16 @@ def time_backward_kernel(env, name, n, H, reps, device):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
-def cpu_baseline(name, budget_s=15.0):
-    """scalar CPU oracle (oracle/dsim_oracle.cpp, a port of the reference's CPU path) on a bounded sample"""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_lib import golden, oracle_backward, template_from_golden
-    t = template_from_golden(name)
-    g = golden(name + "_step")
-    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
-    args = (g["q_in"], g["qd_in"], g["act_in"], g.get("muscle_act_in"), dt, S, mm, g["gq_out"], g["gqd_out"])
-    oracle_backward(t, *args)  # warm up
-    n = g["q_in"].shape[0]
-    done, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        oracle_backward(t, *args)
-        done += n
-    el = time.perf_counter() - t0
-    return {"value": done / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d %s env-steps (fwd + taped adjoint, %d substeps each) in %.1f s on 1 of %d host cores"
-                      % (done, name, S, el, os.cpu_count())}
+def cpu_baseline(name, budget_s=12.0):
+    """scalar CPU oracle (oracle/dsim_oracle.cpp, a port of the reference's CPU path) on a bounded sample, one process
+    per host core (up to 32); run as a subprocess so that nothing GPU-related is forked"""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), name, str(budget_s)],
+                         capture_output=True, text=True, timeout=300)
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if not line:
+        return {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": "failed: " + out.stderr[-200:]}
+    return json.loads(line[-1])
 
 
 def main():

@@ -124,29 +124,28 @@ template <class Ctx, class Exec> DSIM_FN void dsim_init_static(const Ctx& c, Exe
 
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, Exec& ex) {
     ex.mark(1);
-    for (int lv = 0; lv < c.d.D; ++lv) {
-        ex.run([&](int lane) {
-            for (int i = lane; i < c.d.L; i += DSIM_NL) {
-                const DsimLinkInfo li = dsim_link_info(c, i);
-                if (li.level != lv) continue;
-                const int par = li.parent, type = li.type, cs = li.cs, ds = li.ds;
-                const float *q = WF(q), *qd = WF(qd);
-                v3 psp = zero3();
-                q4 rsp = mkq(0.f, 0.f, 0.f, 1.f);
-                sv6 vpar = zerosv(), apar = zerosv();
-                if (par >= 0) {
-                    psp = ld3(WF(xsc) + 7 * par);
-                    rsp = ldq(WF(xsc) + 7 * par + 3);
-                    vpar = ldsv(WF(v) + 6 * par);
-                    apar = ldsv(WF(a) + 6 * par);
-                }
-                const v3 ppj = ld3(CF(xpj) + 7 * i);
-                const q4 rpj = ldq(CF(xpj) + 7 * i + 3);
+    // "Flat" forward kinematics: every link's lane walks its own ancestor chain from the root and recomputes the
+    // joint transforms / twists on the way, instead of one barrier-separated phase per tree level.  A phase costs
+    // ~2k cycles whatever it computes (LDS round trips of a single wavefront) and most lanes idle anyway, so the
+    // redundant arithmetic (depth x ~250 instructions) is cheaper than depth x phases; results are identical to the
+    // level-synchronous form (same operations in the same order along each chain).
+    ex.run([&](int lane) {
+        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+            const float *q = WF(q), *qd = WF(qd);
+            v3 psp = zero3();
+            q4 rsp = mkq(0.f, 0.f, 0.f, 1.f);
+            sv6 v = zerosv(), a = zerosv();
+            const int e0 = CI(anc_start)[i], e1 = CI(anc_start)[i + 1];
+            for (int e = e0; e < e1; ++e) {
+                const int j = CI(anc_list)[e];
+                const DsimLinkInfo li = dsim_link_info(c, j);
+                const int type = li.type, cs = li.cs, ds = li.ds;
+                const bool own = (e == e1 - 1);  // j == i: this lane owns the outputs of link i
+                const v3 ppj = ld3(CF(xpj) + 7 * j);
+                const q4 rpj = ldq(CF(xpj) + 7 * j + 3);
                 const v3 pj = rotate(rsp, ppj) + psp;
                 const q4 rj = qmul(rsp, rpj);
-                st3(WF(xsj) + 7 * i, pj);
-                stq(WF(xsj) + 7 * i + 3, rj);
-                const v3 axis = ld3(CF(axis) + 3 * i);
+                const v3 axis = ld3(CF(axis) + 3 * j);
                 v3 pc = pj;
                 q4 rc = rj;
                 sv6 vj = zerosv();
@@ -155,21 +154,21 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
                     const v3 u = rotate(rj, axis);
                     pc = pj + u * q[cs];
                     const sv6 s = mksv(zero3(), u);
-                    stsv(S + 6 * ds, s);
+                    if (own) stsv(S + 6 * ds, s);
                     vj = s * qd[ds];
                 } else if (type == DSIM_JOINT_REVOLUTE) {
                     rc = qmul(rj, quat_axis_angle(axis, q[cs]));
                     const v3 w = rotate(rj, axis);
                     const sv6 s = mksv(w, cross(pj, w));
-                    stsv(S + 6 * ds, s);
+                    if (own) stsv(S + 6 * ds, s);
                     vj = s * qd[ds];
                 } else if (type == DSIM_JOINT_BALL) {
                     rc = qmul(rj, ldq(q + cs));
                     for (int k = 0; k < 3; ++k) {
-                        const v3 e = mk3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f);
-                        const v3 w = rotate(rj, e);
+                        const v3 ek = mk3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f);
+                        const v3 w = rotate(rj, ek);
                         const sv6 s = mksv(w, cross(pj, w));
-                        stsv(S + 6 * (ds + k), s);
+                        if (own) stsv(S + 6 * (ds + k), s);
                         vj += s * qd[ds + k];
                     }
                 } else if (type == DSIM_JOINT_FREE) {
@@ -177,22 +176,23 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
                     rc = qmul(rj, ldq(q + cs + 3));
                     vj = ldsv(qd + ds);  // S = identity, written once by dsim_init_static
                 }
-                st3(WF(xsc) + 7 * i, pc);
-                stq(WF(xsc) + 7 * i + 3, rc);
-                const sv6 v = vpar + vj;
-                const sv6 a = apar + scross(v, vj);
-                stsv(WF(vj) + 6 * i, vj);
-                stsv(WF(v) + 6 * i, v);
-                stsv(WF(a) + 6 * i, a);
+                v = v + vj;
+                a = a + scross(v, vj);
+                if (own) {
+                    st3(WF(xsj) + 7 * i, pj);
+                    stq(WF(xsj) + 7 * i + 3, rj);
+                    st3(WF(xsc) + 7 * i, pc);
+                    stq(WF(xsc) + 7 * i + 3, rc);
+                    stsv(WF(vj) + 6 * i, vj);
+                    stsv(WF(v) + 6 * i, v);
+                    stsv(WF(a) + 6 * i, a);
+                }
+                psp = pc;
+                rsp = rc;
             }
-        });
-    }
-    // everything that does not feed the next tree level runs ONCE for all links: COM, world inertia, body force
-    ex.run([&](int lane) {
-        for (int i = lane; i < c.d.L; i += DSIM_NL) {
-            const v3 pc = ld3(WF(xsc) + 7 * i);
-            const q4 rc = ldq(WF(xsc) + 7 * i + 3);
-            const sv6 v = ldsv(WF(v) + 6 * i), a = ldsv(WF(a) + 6 * i);
+            // same lane, same phase: COM, world inertia and body force of link i from the values still in registers
+            const v3 pc = psp;
+            const q4 rc = rsp;
             const v3 cm = rotate(rc, ld3(CF(com) + 3 * i)) + pc;
             st3(WF(pm) + 3 * i, cm);
             // world-frame inertia about the origin: Theta = R Ic R^T, A = Theta + m(c.c 1 - c c^T), h = m c
@@ -432,7 +432,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_substep(const Ctx& c, Exe
 // one env.step(): `substeps` substeps with act / muscle activations held fixed (sim.py:2104-2116).
 // g_* are this environment's rows of the caller's tensors (global memory); ckpt may be null.
 template <class Ctx, class Exec>
-DSIM_FN void dsim_env_step_forward(const Ctx& c, Exec& ex, int substeps, int mm_freq, const float* g_q,
+DSIM_FN void dsim_sim_step_forward(const Ctx& c, Exec& ex, int substeps, int mm_freq, const float* g_q,
                                    const float* g_qd, const float* g_act, const float* g_mact, float* g_q_out,
                                    float* g_qd_out, float* g_ckpt) {
     const int nq = c.d.nq, nd = c.d.nd, M = c.d.M;
@@ -547,8 +547,8 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
             }
         }
     });
-    // af[j] = sum over ancestors-or-self i of aftot[i], aftot[i] = -sum_{d in dofs(i)} S_d atau_d  (one phase: each
-    // (link, component) item walks its ancestor list; the per-joint partial sums are recomputed instead of exchanged)
+    // cotangent of body_f_s[j]: f_tot of every ancestor-or-self i of j contains f[j] and tau_d = -S_d . f_tot[link(d)], so
+    // af[j] = -sum over the dofs d of all ancestors-or-self of j of S_d atau_d (one phase, batched over the dof list)
     ex.run([&](int lane) {
         for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
             const int j = it / 6, k = it - 6 * j;
@@ -928,7 +928,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_substep(const Ctx& c, Exe
 
 // Reverse sweep of one env.step().  g_ckpt is this environment's [substeps][nq+nd] checkpoint.
 template <class Ctx, class Exec>
-DSIM_FN void dsim_env_step_backward(const Ctx& c, Exec& ex, int substeps, int mm_freq, const float* g_ckpt,
+DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm_freq, const float* g_ckpt,
                                     const float* g_act, const float* g_mact, const float* g_gq_out,
                                     const float* g_gqd_out, float* g_gq_in, float* g_gqd_in, float* g_gact,
                                     float* g_gmact) {

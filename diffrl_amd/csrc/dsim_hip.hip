@@ -69,7 +69,7 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_fwd_kernel(KCommonT<O, D> k, con
     auto c = start_env(lds, k);
     DevExec ex;
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
-    dsim_env_step_forward(c, ex, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, act + e * nd,
+    dsim_sim_step_forward(c, ex, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, act + e * nd,
                           M ? mact + e * M : nullptr, q_out + e * nq, qd_out + e * nd,
                           ckpt ? ckpt + (size_t)e * k.substeps * (nq + nd) : nullptr);
 }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_bwd_kernel(KCommonT<O, D> k, con
     auto c = start_env(lds, k);
     DevExec ex;
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
-    dsim_env_step_backward(c, ex, k.substeps, k.mm_freq, ckpt + (size_t)e * k.substeps * (nq + nd), act + e * nd,
+    dsim_sim_step_backward(c, ex, k.substeps, k.mm_freq, ckpt + (size_t)e * k.substeps * (nq + nd), act + e * nd,
                            M ? mact + e * M : nullptr, gq_out + e * nq, gqd_out + e * nd, gq_in + e * nq,
                            gqd_in + e * nd, gact ? gact + e * nd : nullptr, (gmact && M) ? gmact + e * M : nullptr);
 }

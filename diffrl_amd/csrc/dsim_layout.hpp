@@ -22,7 +22,7 @@ struct DsimDims {
 
 struct DsimOff {
     // ---- constant block: ints
-    int jtype, parent, qstart, qdstart, lvl_start, lvl_links, dof_link;
+    int jtype, parent, qstart, qdstart, dof_link;
     int linfo;                  // [L][8] packed per-link record: parent, type, q start, qd start, level, subtree size, first subtree contact, subtree contact count
     int anc_start, anc_list;    // ancestors-or-self of link i, root first
     int adof_start, adof_list;  // dofs of all ancestors-or-self of link i
@@ -30,7 +30,6 @@ struct DsimOff {
     int child_start, child_list;
     int cb_start, cb_list;      // contacts of body i
     int scb_start, scb_list;    // contacts of all bodies in subtree(i) (ascending contact index)
-    int sml_start, sml_list;    // muscle (segment*2+side) entries of all bodies in subtree(i)
     int rel;                    // [nd*nd] 0 unrelated, 1: link(b) in subtree(link(a)), 2: link(a) strictly below link(b)
     int cbody;
     int seg_wp, seg_m;          // active muscle segment -> first waypoint index / muscle index
@@ -45,8 +44,8 @@ struct DsimOff {
     int q, qd, act, mact, ua, obs, xsj, xsc, pm, S, vj, v, a, i10, f, ftot, cw, tau, qdd, ic10, F, hinv, prow, pcol, mus;
     int fwd_words;
     // ---- adjoint work arrays (floats)
-    int aq, aqd, aqn, aqdn, aact, amact, aqdd, atau, aS, aftot, af, acx, axsc, axsj, ac, av, aa, aatot, avtot, avj,
-        ai10, ai10m, aic10, aH, topar, amus, gua, agx;
+    int aq, aqd, aqn, aqdn, aact, amact, aqdd, atau, aS, af, acx, axsc, axsj, ac, av, aa, aatot, avtot, avj,
+        ai10, ai10m, aic10, aH, topar, gua, agx;
     int total_words;
 };
 
@@ -106,13 +105,6 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     if (M > 0 && (m.muscle_start[0] != 0 || m.muscle_start[M] != W)) return "muscle_start must span the waypoints";
 
     // ---- tree tables
-    std::vector<int> lvl_start(D + 1, 0), lvl_links;
-    for (int lv = 0; lv < D; ++lv) {
-        lvl_start[lv] = (int)lvl_links.size();
-        for (int i = 0; i < L; ++i)
-            if (level[i] == lv) lvl_links.push_back(i);
-    }
-    lvl_start[D] = (int)lvl_links.size();
     std::vector<int> anc_start(L + 1, 0), anc_list, sub_start(L + 1, 0), sub_list, child_start(L + 1, 0), child_list;
     std::vector<std::vector<int>> anc(L), sub(L), child(L);
     for (int i = 0; i < L; ++i) {
@@ -173,15 +165,11 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     }
     std::vector<int> ml_start(L + 1, 0), ml_list;
     flatten(ml, ml_start, ml_list);
-    std::vector<std::vector<int>> scb(L), sml(L);
+    std::vector<std::vector<int>> scb(L);
     for (int i = 0; i < L; ++i)
-        for (int j : sub[i]) {
-            scb[i].insert(scb[i].end(), cb[j].begin(), cb[j].end());
-            sml[i].insert(sml[i].end(), ml[j].begin(), ml[j].end());
-        }
-    std::vector<int> scb_start(L + 1, 0), scb_list, sml_start(L + 1, 0), sml_list;
+        for (int j : sub[i]) scb[i].insert(scb[i].end(), cb[j].begin(), cb[j].end());
+    std::vector<int> scb_start(L + 1, 0), scb_list;
     flatten(scb, scb_start, scb_list);
-    flatten(sml, sml_start, sml_list);
 
     DsimOff o;
     memset(&o, 0, sizeof(o));
@@ -201,8 +189,6 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.parent = put_i(m.joint_parent, L);
     o.qstart = put_i(m.joint_q_start, L + 1);
     o.qdstart = put_i(m.joint_qd_start, L + 1);
-    o.lvl_start = put_i(lvl_start.data(), D + 1);
-    o.lvl_links = put_i(lvl_links.data(), L);
     o.dof_link = put_i(dof_link.data(), nd);
     // packed per-link record (16-byte aligned so that it is two ds_read_b128) + the range fast-path check
     bool ranges = true;
@@ -237,8 +223,6 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.cb_list = put_i(cb_list.data(), cb_list.size());
     o.scb_start = put_i(scb_start.data(), L + 1);
     o.scb_list = put_i(scb_list.data(), scb_list.size());
-    o.sml_start = put_i(sml_start.data(), L + 1);
-    o.sml_list = put_i(sml_list.data(), sml_list.size());
     o.rel = put_i(rel.data(), rel.size());
     o.cbody = put_i(m.contact_body, C);
     o.seg_wp = put_i(seg_wp.data(), NS);
@@ -291,11 +275,11 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.mus = take(15 * NS);  // forward: 12 floats/segment (signed wrenches); adjoint: 15 floats/segment (cotangents)
     o.fwd_words = cur;
     o.aq = take(nq); o.aqd = take(nd); o.aqn = take(nq); o.aqdn = take(nd); o.aact = take(nd); o.amact = take(M);
-    o.aqdd = take(nd); o.atau = take(nd); o.aS = take(6 * nd); o.aftot = take(6 * L); o.af = take(6 * L);
+    o.aqdd = take(nd); o.atau = take(nd); o.aS = take(6 * nd); o.af = take(6 * L);
     o.acx = take(13 * C); o.axsc = take(7 * L); o.axsj = take(7 * L); o.ac = take(3 * L);
     o.av = take(6 * L); o.aa = take(6 * L); o.aatot = take(6 * L); o.avtot = take(6 * L); o.avj = take(6 * L);
     o.ai10 = take(10 * L); o.ai10m = take(10 * L); o.aic10 = take(10 * (nd > L ? nd : L)); o.aH = take(nd * nd);
-    o.topar = take(7 * L); o.amus = take(0); o.gua = take(M > nd ? M : nd); o.agx = take(13 * L);
+    o.topar = take(7 * L); o.gua = take(M > nd ? M : nd); o.agx = take(13 * L);
     o.total_words = cur;
 
     out.o = o;

@@ -73,7 +73,7 @@ int dsim_emu_step_forward(const dsim_model_desc* m, int n_envs, const float* q_i
         std::vector<float> lds;
         DsimCtx c;
         make_ctx(lay, lds, c, dt / float(substeps));
-        dsim_env_step_forward(c, ex, substeps, mm_freq, q_in + (size_t)e * nq, qd_in + (size_t)e * nd,
+        dsim_sim_step_forward(c, ex, substeps, mm_freq, q_in + (size_t)e * nq, qd_in + (size_t)e * nd,
                               act + (size_t)e * nd, M ? mact + (size_t)e * M : nullptr, q_out + (size_t)e * nq,
                               qd_out + (size_t)e * nd, ckpt ? ckpt + (size_t)e * substeps * (nq + nd) : nullptr);
     }
@@ -92,7 +92,7 @@ extern "C" int dsim_emu_step_backward(const dsim_model_desc* m, int n_envs, cons
         std::vector<float> lds;
         DsimCtx c;
         make_ctx(lay, lds, c, dt / float(substeps));
-        dsim_env_step_backward(c, ex, substeps, mm_freq, ckpt + (size_t)e * substeps * (nq + nd), act + (size_t)e * nd,
+        dsim_sim_step_backward(c, ex, substeps, mm_freq, ckpt + (size_t)e * substeps * (nq + nd), act + (size_t)e * nd,
                                M ? mact + (size_t)e * M : nullptr, gq_out + (size_t)e * nq, gqd_out + (size_t)e * nd,
                                gq_in + (size_t)e * nq, gqd_in + (size_t)e * nd, gact ? gact + (size_t)e * nd : nullptr,
                                (gmact && M) ? gmact + (size_t)e * M : nullptr);

@@ -127,3 +127,28 @@ def test_shac_style_usage():
     assert all(torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0 for p in actor.parameters())
     e.clear_grad()
     assert not e.state.joint_q.requires_grad
+
+
+@pytest.mark.parametrize("env,H,iters", [("cartpole", 16, 25), ("ant", 8, 15)])
+def test_gradients_are_useful(env, H, iters):
+    """first-order optimisation of an open-loop action sequence through the fused step improves the return"""
+    e = _make(env, 32)
+    dev = torch.device("cuda:0")
+    acts = torch.zeros((H, 32, e.num_actions), device=dev, requires_grad=True)
+    opt = torch.optim.Adam([acts], lr=0.05)
+    q0, qd0 = e.get_state()
+    losses = []
+    for it in range(iters):
+        e.clear_grad()
+        e.reset_with_state(q0, qd0)
+        e.initialize_trajectory()
+        loss = 0.0
+        for t in range(H):
+            obs, rew, done, _ = e.step(torch.tanh(acts[t]))
+            loss = loss - rew.mean()
+        opt.zero_grad()
+        loss.backward()
+        assert torch.isfinite(acts.grad).all()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0] - 1e-3, losses
