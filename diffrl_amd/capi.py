@@ -119,6 +119,8 @@ def lib():
     L.dsim_model_variant.restype = C.c_int
     L.dsim_ckpt_floats.argtypes = [vp, C.c_int]
     L.dsim_ckpt_floats.restype = C.c_int64
+    L.dsim_ckpt_floats_mm.argtypes = [vp, C.c_int, C.c_int]
+    L.dsim_ckpt_floats_mm.restype = C.c_int64
     L.dsim_step_forward.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp]
     L.dsim_step_backward.argtypes = [vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp,
                                      vp]
@@ -140,6 +142,6 @@ def check(rc):
 
 
 EXPORTS = ("dsim_last_error", "dsim_version", "dsim_model_create", "dsim_model_destroy", "dsim_model_variant",
-           "dsim_ckpt_floats",
+           "dsim_ckpt_floats", "dsim_ckpt_floats_mm",
            "dsim_step_forward", "dsim_step_backward", "dsim_env_step_forward", "dsim_env_step_backward",
            "dsim_env_observe")

@@ -418,13 +418,32 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_integrate(const Ctx& c, E
     });
 }
 
-// one substep on the LDS-resident state
-template <class Ctx, class Exec> DSIM_FN void dsim_fwd_substep(const Ctx& c, Exec& ex, bool update_mass) {
+// ---- checkpoint = what the adjoint launch needs from the forward launch, kept in HBM instead of recomputed ----
+// per environment: [substeps][save_words] saved blocks (q, qd, X_sj, X_sc, COM, S, v_j, v, a, inertias, f_tot, qdd of the
+// substep) followed by [groups][hinv_words] inverses of the mass matrix (one per refresh).  288 GB of HBM are otherwise
+// idle on this path (Ant: 37 KB per env-step), and reading the block back costs ~1.5k cycles against ~10k to recompute it.
+DSIM_FN int dsim_hinv_words_d(int nd) { return (nd * nd + 3) & ~3; }
+template <class Ctx> DSIM_FN float* dsim_ckpt_hinv(const Ctx& c, float* g_ckpt, int substeps, int group) {
+    return g_ckpt + (size_t)substeps * c.o.save_words + (size_t)group * dsim_hinv_words_d(c.d.nd);
+}
+
+// one substep on the LDS-resident state; g_row / g_hinv: where to stream the saved block / the fresh inverse (or null)
+template <class Ctx, class Exec>
+DSIM_FN void dsim_fwd_substep(const Ctx& c, Exec& ex, bool update_mass, float* g_row = nullptr, float* g_hinv = nullptr) {
     dsim_fwd_kinematics(c, ex);
     dsim_fwd_external(c, ex);
     dsim_fwd_tau(c, ex);
     if (update_mass) dsim_fwd_mass(c, ex);
     dsim_fwd_solve(c, ex);
+    if (g_row) {
+        // global stores to this environment's private rows: no barrier, no wait -- they drain while the step goes on
+        ex.fire([&](int lane) {
+            const float* src = WF(q);
+            for (int k = lane; k < c.o.save_words; k += DSIM_NL) g_row[k] = src[k];
+            if (update_mass && g_hinv)
+                for (int k = lane; k < c.d.nd * c.d.nd; k += DSIM_NL) g_hinv[k] = WF(hinv)[k];
+        });
+    }
     dsim_fwd_integrate(c, ex);
 }
 
@@ -445,17 +464,9 @@ DSIM_FN void dsim_sim_step_forward(const Ctx& c, Exec& ex, int substeps, int mm_
         }
         for (int k = lane; k < M; k += DSIM_NL) WF(mact)[k] = g_mact[k];
     });
-    for (int s = 0; s < substeps; ++s) {
-        if (g_ckpt) {
-            float* ck = g_ckpt + (size_t)s * (nq + nd);
-            // global stores to a private row: no barrier, no wait -- they drain while the substep computes
-            ex.fire([&](int lane) {
-                for (int k = lane; k < nq; k += DSIM_NL) ck[k] = WF(q)[k];
-                for (int k = lane; k < nd; k += DSIM_NL) ck[nq + k] = WF(qd)[k];
-            });
-        }
-        dsim_fwd_substep(c, ex, (s % mm_freq) == 0);
-    }
+    for (int s = 0; s < substeps; ++s)
+        dsim_fwd_substep(c, ex, (s % mm_freq) == 0, g_ckpt ? g_ckpt + (size_t)s * c.o.save_words : nullptr,
+                         g_ckpt ? dsim_ckpt_hinv(c, g_ckpt, substeps, s / mm_freq) : nullptr);
     ex.run([&](int lane) {
         for (int k = lane; k < nq; k += DSIM_NL) g_q_out[k] = WF(q)[k];
         for (int k = lane; k < nd; k += DSIM_NL) g_qd_out[k] = WF(qd)[k];
@@ -949,28 +960,20 @@ DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
     const int groups = (substeps + mm_freq - 1) / mm_freq;
     for (int g = groups - 1; g >= 0; --g) {
         const int s0 = g * mm_freq, s1 = (s0 + mm_freq < substeps) ? s0 + mm_freq : substeps;
-        // the factor this group of substeps used: rebuild it from the state at s0
-        {
-            const float* ck = g_ckpt + (size_t)s0 * (nq + nd);
-            ex.run([&](int lane) {
-                for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = ck[k];
-                for (int k = lane; k < nd; k += DSIM_NL) WF(qd)[k] = ck[nq + k];
-                for (int k = lane; k < nd * nd; k += DSIM_NL) WF(aH)[k] = 0.f;
-            });
-            dsim_fwd_kinematics(c, ex);
-            dsim_fwd_mass(c, ex);
-        }
         for (int s = s1 - 1; s >= s0; --s) {
-            const float* ck = g_ckpt + (size_t)s * (nq + nd);
+            // forward intermediates of substep s (and, entering a group, the inverse its substeps used) from HBM
+            const float* row = g_ckpt + (size_t)s * c.o.save_words;
+            const float* hv = (s == s1 - 1) ? dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, g) : nullptr;
             ex.run([&](int lane) {
-                for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = ck[k];
-                for (int k = lane; k < nd; k += DSIM_NL) WF(qd)[k] = ck[nq + k];
+                float* dst = WF(q);
+                for (int k = lane; k < c.o.save_words; k += DSIM_NL) dst[k] = row[k];
+                if (hv)
+                    for (int k = lane; k < nd * nd; k += DSIM_NL) {
+                        WF(hinv)[k] = hv[k];
+                        WF(aH)[k] = 0.f;
+                    }
             });
-            dsim_fwd_kinematics(c, ex);
-            dsim_fwd_external(c, ex);
-            dsim_fwd_tau(c, ex);
             if (s == s0) dsim_fwd_composite(c, ex);
-            dsim_fwd_solve(c, ex);
             dsim_bwd_substep(c, ex, s == s0);
             ex.run([&](int lane) {
                 for (int k = lane; k < nq; k += DSIM_NL) WF(aqn)[k] = WF(aq)[k];
@@ -1239,16 +1242,9 @@ DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& s
         for (int k = lane; k < nd; k += DSIM_NL) WF(qd)[k] = g_qd[k];
     });
     dsim_env_load_actions(c, ex, sp, g_actions);
-    for (int s = 0; s < substeps; ++s) {
-        if (g_ckpt) {
-            float* ck = g_ckpt + (size_t)s * (nq + nd);
-            ex.fire([&](int lane) {
-                for (int k = lane; k < nq; k += DSIM_NL) ck[k] = WF(q)[k];
-                for (int k = lane; k < nd; k += DSIM_NL) ck[nq + k] = WF(qd)[k];
-            });
-        }
-        dsim_fwd_substep(c, ex, (s % mm_freq) == 0);
-    }
+    for (int s = 0; s < substeps; ++s)
+        dsim_fwd_substep(c, ex, (s % mm_freq) == 0, g_ckpt ? g_ckpt + (size_t)s * c.o.save_words : nullptr,
+                         g_ckpt ? dsim_ckpt_hinv(c, g_ckpt, substeps, s / mm_freq) : nullptr);
     ex.fire([&](int lane) {
         for (int k = lane; k < nq; k += DSIM_NL) g_q_out[k] = WF(q)[k];
         for (int k = lane; k < nd; k += DSIM_NL) g_qd_out[k] = WF(qd)[k];
@@ -1294,27 +1290,20 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
     const int groups = (substeps + mm_freq - 1) / mm_freq;
     for (int g = groups - 1; g >= 0; --g) {
         const int s0 = g * mm_freq, s1 = (s0 + mm_freq < substeps) ? s0 + mm_freq : substeps;
-        {
-            const float* ck = g_ckpt + (size_t)s0 * (nq + nd);
-            ex.run([&](int lane) {
-                for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = ck[k];
-                for (int k = lane; k < nd; k += DSIM_NL) WF(qd)[k] = ck[nq + k];
-                for (int k = lane; k < nd * nd; k += DSIM_NL) WF(aH)[k] = 0.f;
-            });
-            dsim_fwd_kinematics(c, ex);
-            dsim_fwd_mass(c, ex);
-        }
         for (int s = s1 - 1; s >= s0; --s) {
-            const float* ck = g_ckpt + (size_t)s * (nq + nd);
+            // forward intermediates of substep s (and, entering a group, the inverse its substeps used) from HBM
+            const float* row = g_ckpt + (size_t)s * c.o.save_words;
+            const float* hv = (s == s1 - 1) ? dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, g) : nullptr;
             ex.run([&](int lane) {
-                for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = ck[k];
-                for (int k = lane; k < nd; k += DSIM_NL) WF(qd)[k] = ck[nq + k];
+                float* dst = WF(q);
+                for (int k = lane; k < c.o.save_words; k += DSIM_NL) dst[k] = row[k];
+                if (hv)
+                    for (int k = lane; k < nd * nd; k += DSIM_NL) {
+                        WF(hinv)[k] = hv[k];
+                        WF(aH)[k] = 0.f;
+                    }
             });
-            dsim_fwd_kinematics(c, ex);
-            dsim_fwd_external(c, ex);
-            dsim_fwd_tau(c, ex);
             if (s == s0) dsim_fwd_composite(c, ex);
-            dsim_fwd_solve(c, ex);
             dsim_bwd_substep(c, ex, s == s0);
             ex.run([&](int lane) {
                 for (int k = lane; k < nq; k += DSIM_NL) WF(aqn)[k] = WF(aq)[k];

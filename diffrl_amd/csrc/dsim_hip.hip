@@ -43,6 +43,7 @@ template <class O, class D> struct KCommonT {
     const uint32_t* cblob;
     float h;
     int substeps, mm_freq, n_envs;
+    long long ckpt_stride;  // floats per environment (dsim_ckpt_words)
 };
 
 template <class O, class D> __device__ __forceinline__ DsimCtxT<O, D> start_env(float* lds, const KCommonT<O, D>& k) {
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_fwd_kernel(KCommonT<O, D> k, con
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_sim_step_forward(c, ex, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, act + e * nd,
                           M ? mact + e * M : nullptr, q_out + e * nq, qd_out + e * nd,
-                          ckpt ? ckpt + (size_t)e * k.substeps * (nq + nd) : nullptr);
+                          ckpt ? ckpt + (size_t)e * k.ckpt_stride : nullptr);
 }
 
 template <class O, class D>
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_bwd_kernel(KCommonT<O, D> k, con
     auto c = start_env(lds, k);
     DevExec ex;
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
-    dsim_sim_step_backward(c, ex, k.substeps, k.mm_freq, ckpt + (size_t)e * k.substeps * (nq + nd), act + e * nd,
+    dsim_sim_step_backward(c, ex, k.substeps, k.mm_freq, ckpt + (size_t)e * k.ckpt_stride, act + e * nd,
                            M ? mact + e * M : nullptr, gq_out + e * nq, gqd_out + e * nd, gq_in + e * nq,
                            gqd_in + e * nd, gact ? gact + e * nd : nullptr, (gmact && M) ? gmact + e * M : nullptr);
 }
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_env_fwd_kernel(KCommonT<O, D> k,
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_forward(c, ex, sp, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, actions + (size_t)e * sp.n_act,
                            q_out + e * nq, qd_out + e * nd, obs + (size_t)e * sp.n_obs, rew + e,
-                           ckpt ? ckpt + (size_t)e * k.substeps * (nq + nd) : nullptr);
+                           ckpt ? ckpt + (size_t)e * k.ckpt_stride : nullptr);
 }
 
 template <class O, class D>
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_env_bwd_kernel(KCommonT<O, D> k,
     auto c = start_env(lds, k);
     DevExec ex;
     const size_t nq = k.d.nq, nd = k.d.nd;
-    dsim_env_fused_backward(c, ex, sp, k.substeps, k.mm_freq, ckpt + (size_t)e * k.substeps * (nq + nd),
+    dsim_env_fused_backward(c, ex, sp, k.substeps, k.mm_freq, ckpt + (size_t)e * k.ckpt_stride,
                             actions + (size_t)e * sp.n_act, q_out + e * nq, qd_out + e * nd, gq_out + e * nq,
                             gqd_out + e * nd, gobs + (size_t)e * sp.n_obs, grew + e, gq_in + e * nq, gqd_in + e * nd,
                             gactions + (size_t)e * sp.n_act);
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_timer_kernel(KCommonT<O, D> k, D
     TimingExec ex{stamps, 1, cap};
     if (blockIdx.x == 0 && threadIdx.x == 0) stamps[0] = clock64();
     const size_t nq = k.d.nq, nd = k.d.nd;
-    float* ck = ckpt + (size_t)e * k.substeps * (nq + nd);
+    float* ck = ckpt + (size_t)e * k.ckpt_stride;
     if (!backward)
         dsim_env_fused_forward(c, ex, sp, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd,
                                actions + (size_t)e * sp.n_act, q_out + e * nq, qd_out + e * nd,
@@ -260,6 +261,7 @@ KCommonT<O, D> make_k(const dsim_model* m, O o, D d, int n_envs, float dt, int s
     k.substeps = substeps;
     k.mm_freq = mm_freq;
     k.n_envs = n_envs;
+    k.ckpt_stride = dsim_ckpt_words(m->lay.o.save_words, m->lay.d.nd, substeps, mm_freq);
     return k;
 }
 
@@ -371,10 +373,12 @@ int dsim_model_destroy(dsim_model* m) {
     return DSIM_OK;
 }
 
-int64_t dsim_ckpt_floats(const dsim_model* m, int substeps) {
-    if (!m || substeps <= 0) return 0;
-    return (int64_t)substeps * (m->lay.d.nq + m->lay.d.nd);
+int64_t dsim_ckpt_floats_mm(const dsim_model* m, int substeps, int mm_freq) {
+    if (!m || substeps <= 0 || mm_freq <= 0) return 0;
+    return (int64_t)dsim_ckpt_words(m->lay.o.save_words, m->lay.d.nd, substeps, mm_freq);
 }
+
+int64_t dsim_ckpt_floats(const dsim_model* m, int substeps) { return dsim_ckpt_floats_mm(m, substeps, 1); }
 
 int dsim_step_forward(const dsim_model* m, int n_envs, const float* q_in, const float* qd_in, const float* act,
                       const float* muscle_act, float dt, int substeps, int mm_freq, float* q_out, float* qd_out,

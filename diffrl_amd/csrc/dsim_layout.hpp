@@ -42,12 +42,20 @@ struct DsimOff {
     int const_words;
     // ---- forward work arrays (floats)
     int q, qd, act, mact, ua, obs, xsj, xsc, pm, S, vj, v, a, i10, f, ftot, cw, tau, qdd, ic10, F, hinv, prow, pcol, mus;
+    int save_words;             // length of the saved block that starts at q (see dsim_build_layout)
     int fwd_words;
     // ---- adjoint work arrays (floats)
     int aq, aqd, aqn, aqdn, aact, amact, aqdd, atau, aS, af, acx, axsc, axsj, ac, av, aa, aatot, avtot, avj,
         ai10, ai10m, aic10, aH, topar, gua, agx;
     int total_words;
 };
+
+// checkpoint geometry (floats per environment): one saved block per substep + one H^-1 per mass-matrix group
+inline int dsim_hinv_words(int nd) { return (nd * nd + 3) & ~3; }
+inline long long dsim_ckpt_words(int save_words, int nd, int substeps, int mm_freq) {
+    const int groups = (substeps + mm_freq - 1) / mm_freq;
+    return (long long)substeps * save_words + (long long)groups * dsim_hinv_words(nd);
+}
 
 struct DsimLayout {
     DsimDims d;
@@ -266,11 +274,17 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
         cur += (n + 3) & ~3;
         return off;
     };
-    o.q = take(nq); o.qd = take(nd); o.act = take(nd); o.mact = take(M);
-    o.ua = take(M > nd ? M : nd); o.obs = take(16 + nq + nd + (M > nd ? M : nd));
+    // "saved block": everything the adjoint of a substep reads from its forward pass, contiguous so that the
+    // forward launch can stream it to HBM with one linear copy per substep and the adjoint launch can read it back
+    // instead of recomputing it (the checkpoint row of a substep IS this block; it starts with q, qd)
+    o.q = take(nq); o.qd = take(nd);
     o.xsj = take(7 * L); o.xsc = take(7 * L); o.pm = take(3 * L); o.S = take(6 * nd);
     o.vj = take(6 * L); o.v = take(6 * L); o.a = take(6 * L); o.i10 = take(10 * L);
-    o.f = take(6 * L); o.ftot = take(6 * L); o.cw = take(6 * C); o.tau = take(nd); o.qdd = take(nd);
+    o.ftot = take(6 * L); o.qdd = take(nd);
+    o.save_words = cur - o.q;
+    o.act = take(nd); o.mact = take(M);
+    o.ua = take(M > nd ? M : nd); o.obs = take(16 + nq + nd + (M > nd ? M : nd));
+    o.f = take(6 * L); o.cw = take(6 * C); o.tau = take(nd);
     o.ic10 = take(10 * L); o.F = take(6 * nd); o.hinv = take(nd * nd); o.prow = take(nd); o.pcol = take(nd);
     o.mus = take(15 * NS);  // forward: 12 floats/segment (signed wrenches); adjoint: 15 floats/segment (cotangents)
     o.fwd_words = cur;

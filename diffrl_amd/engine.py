@@ -40,6 +40,11 @@ class Engine:
         except Exception:
             pass
 
+    def _alloc_ckpt(self, n, substeps, mm_freq):
+        """[n][dsim_ckpt_floats_mm]: per substep the saved forward block (starts with q, qd), then the H^-1 per group"""
+        words = int(self._lib.dsim_ckpt_floats_mm(self._h, substeps, mm_freq))
+        return torch.empty((n, words), dtype=torch.float32, device=self.device)
+
     def _check(self, t, cols, name):
         if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
             raise capi.DsimError("%s must be a contiguous float32 tensor on %s" % (name, self.device))
@@ -61,7 +66,7 @@ class Engine:
         qd_out = torch.empty_like(qd)
         ckpt = None
         if need_ckpt:
-            ckpt = torch.empty((n, substeps, self.n_q + self.n_qd), dtype=torch.float32, device=self.device)
+            ckpt = self._alloc_ckpt(n, substeps, mm_freq)
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             capi.check(self._lib.dsim_step_forward(self._h, n, _ptr(q), _ptr(qd), _ptr(act),
@@ -97,7 +102,7 @@ class Engine:
         q_out, qd_out = torch.empty_like(q), torch.empty_like(qd)
         obs = torch.empty((n, spec.n_obs), dtype=torch.float32, device=self.device)
         rew = torch.empty(n, dtype=torch.float32, device=self.device)
-        ckpt = torch.empty((n, substeps, self.n_q + self.n_qd), dtype=torch.float32, device=self.device) if need_ckpt else None
+        ckpt = self._alloc_ckpt(n, substeps, mm_freq) if need_ckpt else None
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             capi.check(self._lib.dsim_env_step_forward(self._h, C.byref(spec), n, _ptr(q), _ptr(qd), _ptr(actions),

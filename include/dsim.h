@@ -95,15 +95,19 @@ int dsim_model_destroy(dsim_model* m);
  * compile-time table exactly).  Same results either way. */
 int dsim_model_variant(const dsim_model* m);
 
-/* Floats per environment of the per-substep checkpoint the forward pass leaves for the adjoint:
- * substeps * (n_q + n_qd).  (The reference instead keeps all 14 State tensors of every substep
- * alive on its Tape, sim.py:2111 / model.py:338-392.) */
+/* Floats per environment of the checkpoint the forward launch leaves in HBM for the adjoint launch: per
+ * substep one "saved block" (q, qd and the forward intermediates the adjoint reads: transforms, motion
+ * subspace, twists, inertias, subtree forces, accelerations) plus one inverse mass matrix per refresh.
+ * (The reference keeps all 14 State tensors of every substep alive on its Tape, sim.py:2111 /
+ * model.py:338-392.)  dsim_ckpt_floats() is the upper bound over mm_freq (mm_freq = 1). */
+int64_t dsim_ckpt_floats_mm(const dsim_model* m, int substeps, int mm_freq);
 int64_t dsim_ckpt_floats(const dsim_model* m, int substeps);
 
 /* One env.step() worth of simulation for N environments: `substeps` semi-implicit substeps of
  * dt/substeps with joint_act / muscle_act held fixed; mass matrix + Cholesky factor refreshed on
  * substeps i with i % mm_freq == 0 (sim.py:2113).
- *   ckpt: [N][substeps][n_q+n_qd] or NULL (no-grad fast path == dflex.config.no_grad, sim.py:2201)
+ *   ckpt: [N][dsim_ckpt_floats_mm(m, substeps, mm_freq)] or NULL (no-grad fast path == dflex.config.no_grad,
+ *   sim.py:2201); every row starts with the (q, qd) entering its substep
  *   muscle_act may be NULL when n_muscles == 0.  q_out/qd_out may alias q_in/qd_in. */
 int dsim_step_forward(const dsim_model* m, int n_envs,
                       const float* q_in, const float* qd_in, const float* act, const float* muscle_act,

@@ -75,7 +75,7 @@ int dsim_emu_step_forward(const dsim_model_desc* m, int n_envs, const float* q_i
         make_ctx(lay, lds, c, dt / float(substeps));
         dsim_sim_step_forward(c, ex, substeps, mm_freq, q_in + (size_t)e * nq, qd_in + (size_t)e * nd,
                               act + (size_t)e * nd, M ? mact + (size_t)e * M : nullptr, q_out + (size_t)e * nq,
-                              qd_out + (size_t)e * nd, ckpt ? ckpt + (size_t)e * substeps * (nq + nd) : nullptr);
+                              qd_out + (size_t)e * nd, ckpt ? ckpt + (size_t)e * dsim_ckpt_words(lay.o.save_words, nd, substeps, mm_freq) : nullptr);
     }
     return 0;
 }
@@ -92,7 +92,7 @@ extern "C" int dsim_emu_step_backward(const dsim_model_desc* m, int n_envs, cons
         std::vector<float> lds;
         DsimCtx c;
         make_ctx(lay, lds, c, dt / float(substeps));
-        dsim_sim_step_backward(c, ex, substeps, mm_freq, ckpt + (size_t)e * substeps * (nq + nd), act + (size_t)e * nd,
+        dsim_sim_step_backward(c, ex, substeps, mm_freq, ckpt + (size_t)e * dsim_ckpt_words(lay.o.save_words, nd, substeps, mm_freq), act + (size_t)e * nd,
                                M ? mact + (size_t)e * M : nullptr, gq_out + (size_t)e * nq, gqd_out + (size_t)e * nd,
                                gq_in + (size_t)e * nq, gqd_in + (size_t)e * nd, gact ? gact + (size_t)e * nd : nullptr,
                                (gmact && M) ? gmact + (size_t)e * M : nullptr);
@@ -126,7 +126,7 @@ extern "C" int dsim_emu_env_forward(const dsim_model_desc* m, const dsim_env_spe
         make_ctx(lay, lds, c, dt / float(substeps));
         dsim_env_fused_forward(c, ex, sp, substeps, mm_freq, q_in + (size_t)e * nq, qd_in + (size_t)e * nd,
                                actions + (size_t)e * sp.n_act, q_out + (size_t)e * nq, qd_out + (size_t)e * nd,
-                               obs + (size_t)e * sp.n_obs, rew + e, ckpt ? ckpt + (size_t)e * substeps * (nq + nd) : nullptr);
+                               obs + (size_t)e * sp.n_obs, rew + e, ckpt ? ckpt + (size_t)e * dsim_ckpt_words(lay.o.save_words, nd, substeps, mm_freq) : nullptr);
     }
     return 0;
 }
@@ -144,10 +144,16 @@ extern "C" int dsim_emu_env_backward(const dsim_model_desc* m, const dsim_env_sp
         std::vector<float> lds;
         DsimCtx c;
         make_ctx(lay, lds, c, dt / float(substeps));
-        dsim_env_fused_backward(c, ex, sp, substeps, mm_freq, ckpt + (size_t)e * substeps * (nq + nd),
+        dsim_env_fused_backward(c, ex, sp, substeps, mm_freq, ckpt + (size_t)e * dsim_ckpt_words(lay.o.save_words, nd, substeps, mm_freq),
                                 actions + (size_t)e * sp.n_act, q_out + (size_t)e * nq, qd_out + (size_t)e * nd,
                                 gq_out + (size_t)e * nq, gqd_out + (size_t)e * nd, gobs + (size_t)e * sp.n_obs, grew + e,
                                 gq_in + (size_t)e * nq, gqd_in + (size_t)e * nd, gactions + (size_t)e * sp.n_act);
     }
     return 0;
+}
+
+extern "C" long long dsim_emu_ckpt_floats(const dsim_model_desc* m, int substeps, int mm_freq) {
+    DsimLayout lay;
+    if (!dsim_build_layout(*m, lay).empty()) return -1;
+    return dsim_ckpt_words(lay.o.save_words, lay.d.nd, substeps, mm_freq);
 }

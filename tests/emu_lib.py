@@ -65,13 +65,20 @@ def substep_image(t, q, qd, act, mact, h):
     return img, off, dims
 
 
+def ckpt_floats(t, substeps, mm_freq):
+    desc, keep = make_desc(t)
+    fn = emu().dsim_emu_ckpt_floats
+    fn.restype = C.c_longlong
+    return int(fn(C.byref(desc), C.c_int(substeps), C.c_int(mm_freq)))
+
+
 def emu_forward(t, q, qd, act, mact, dt, substeps, mm_freq, want_ckpt=False):
     desc, keep = make_desc(t)
     N = q.shape[0]
     q, qd, act = _c(q), _c(qd), _c(act)
     mact = _c(mact) if mact is not None else np.zeros((N, 0), np.float32)
     qo, qdo = np.zeros_like(q), np.zeros_like(qd)
-    ck = np.zeros((N, substeps, t.n_q + t.n_qd), np.float32) if want_ckpt else None
+    ck = np.zeros((N, ckpt_floats(t, substeps, mm_freq)), np.float32) if want_ckpt else None
     rc = emu().dsim_emu_step_forward(C.byref(desc), C.c_int(N), _p(q), _p(qd), _p(act), _p(mact), C.c_float(dt),
                                      C.c_int(substeps), C.c_int(mm_freq), _p(qo), _p(qdo), _p(ck))
     assert rc == 0
@@ -140,7 +147,7 @@ def emu_env_forward(t, spec, q, qd, actions, dt, substeps, mm_freq):
     q, qd, actions = _c(q), _c(qd), _c(actions)
     qo, qdo = np.zeros_like(q), np.zeros_like(qd)
     obs, rew = np.zeros((N, spec.n_obs), np.float32), np.zeros(N, np.float32)
-    ck = np.zeros((N, substeps, t.n_q + t.n_qd), np.float32)
+    ck = np.zeros((N, ckpt_floats(t, substeps, mm_freq)), np.float32)
     rc = emu().dsim_emu_env_forward(C.byref(desc), C.byref(spec), C.c_int(N), _p(q), _p(qd), _p(actions), C.c_float(dt),
                                     C.c_int(substeps), C.c_int(mm_freq), _p(qo), _p(qdo), _p(obs), _p(rew), _p(ck))
     assert rc == 0

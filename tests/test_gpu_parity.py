@@ -49,7 +49,7 @@ def test_step_vs_reference_golden(env, dev):
     r = _run(eng, dev, g["q_in"], g["qd_in"], g["act_in"], g.get("muscle_act_in"), dt, S, mm, g["gq_out"], g["gqd_out"])
     assert relerr(r["q"], g["q_out"]) < 1e-4
     assert relerr(r["qd"], g["qd_out"]) < 1e-4
-    assert np.array_equal(r["ckpt"][:, 0, :t.n_q], g["q_in"])  # first checkpoint is the input state, bit-exact
+    assert np.array_equal(r["ckpt"][:, :t.n_q], g["q_in"])  # every checkpoint row starts with the substep's input q
     assert relerr(project_tangent(t, g["q_in"], r["gq"]), project_tangent(t, g["q_in"], g["gq_in"])) < 1e-3
     assert relerr(r["gqd"], g["gqd_in"]) < 1e-3
     if "gact_in" in g:
@@ -99,7 +99,8 @@ def test_determinism_and_inplace(dev):
     a = torch.tensor(np.tile(g["act_in"], (100, 1)), device=dev).reshape(-1)
     r1 = eng.forward(q, qd, a, None, dt, S, mm, True)
     r2 = eng.forward(q, qd, a, None, dt, S, mm, True)
-    assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1]) and torch.equal(r1[2], r2[2])
+    assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
+    assert torch.equal(r1[2][:, :t.n_q], r2[2][:, :t.n_q])  # (rows also carry alignment padding that is never read)
     gq = torch.randn_like(q)
     gqd = torch.randn_like(qd)
     b1 = eng.backward(r1[2], a, None, dt, S, mm, gq, gqd)
