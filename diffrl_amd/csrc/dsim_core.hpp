@@ -961,18 +961,20 @@ DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
     for (int g = groups - 1; g >= 0; --g) {
         const int s0 = g * mm_freq, s1 = (s0 + mm_freq < substeps) ? s0 + mm_freq : substeps;
         for (int s = s1 - 1; s >= s0; --s) {
-            // forward intermediates of substep s (and, entering a group, the inverse its substeps used) from HBM
-            const float* row = g_ckpt + (size_t)s * c.o.save_words;
+            // forward intermediates of substep s (and, entering a group, the inverse its substeps used) from HBM.
+            // The row was requested one substep earlier (ex.prefetch keeps it in flight in registers while the
+            // previous adjoint substep computes), so this phase only moves registers to LDS.
             const float* hv = (s == s1 - 1) ? dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, g) : nullptr;
+            if (s == substeps - 1) ex.prefetch(g_ckpt + (size_t)s * c.o.save_words, c.o.save_words);
             ex.run([&](int lane) {
-                float* dst = WF(q);
-                for (int k = lane; k < c.o.save_words; k += DSIM_NL) dst[k] = row[k];
+                ex.commit(WF(q), c.o.save_words, lane);
                 if (hv)
                     for (int k = lane; k < nd * nd; k += DSIM_NL) {
                         WF(hinv)[k] = hv[k];
                         WF(aH)[k] = 0.f;
                     }
             });
+            if (s > 0) ex.prefetch(g_ckpt + (size_t)(s - 1) * c.o.save_words, c.o.save_words);
             if (s == s0) dsim_fwd_composite(c, ex);
             dsim_bwd_substep(c, ex, s == s0);
             ex.run([&](int lane) {
@@ -1291,18 +1293,20 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
     for (int g = groups - 1; g >= 0; --g) {
         const int s0 = g * mm_freq, s1 = (s0 + mm_freq < substeps) ? s0 + mm_freq : substeps;
         for (int s = s1 - 1; s >= s0; --s) {
-            // forward intermediates of substep s (and, entering a group, the inverse its substeps used) from HBM
-            const float* row = g_ckpt + (size_t)s * c.o.save_words;
+            // forward intermediates of substep s (and, entering a group, the inverse its substeps used) from HBM.
+            // The row was requested one substep earlier (ex.prefetch keeps it in flight in registers while the
+            // previous adjoint substep computes), so this phase only moves registers to LDS.
             const float* hv = (s == s1 - 1) ? dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, g) : nullptr;
+            if (s == substeps - 1) ex.prefetch(g_ckpt + (size_t)s * c.o.save_words, c.o.save_words);
             ex.run([&](int lane) {
-                float* dst = WF(q);
-                for (int k = lane; k < c.o.save_words; k += DSIM_NL) dst[k] = row[k];
+                ex.commit(WF(q), c.o.save_words, lane);
                 if (hv)
                     for (int k = lane; k < nd * nd; k += DSIM_NL) {
                         WF(hinv)[k] = hv[k];
                         WF(aH)[k] = 0.f;
                     }
             });
+            if (s > 0) ex.prefetch(g_ckpt + (size_t)(s - 1) * c.o.save_words, c.o.save_words);
             if (s == s0) dsim_fwd_composite(c, ex);
             dsim_bwd_substep(c, ex, s == s0);
             ex.run([&](int lane) {

@@ -27,14 +27,47 @@
 
 namespace {
 
+// The workgroup IS one wavefront (64 threads, enforced at launch): a phase boundary needs no s_barrier, only
+// (a) the compiler must not move / cache LDS accesses across it and (b) this wave's LDS operations must have
+// completed -- DS instructions of one wave execute in order, `s_waitcnt lgkmcnt(0)` + a memory clobber is the whole
+// synchronisation.  Unlike __syncthreads() this does NOT wait for outstanding global loads / stores (vmcnt), which is
+// what lets checkpoint traffic overlap with compute.
+__device__ __forceinline__ void dsim_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+#define DSIM_PF 24  // prefetch registers per lane: rows up to 1536 floats (Humanoid: 1421)
+
 struct DevExec {
     template <class F> __device__ __forceinline__ void run(F&& f) {
         f((int)threadIdx.x);
-        __syncthreads();
+        dsim_wave_sync();
     }
     // phase that only writes global memory nobody in this launch reads back: no barrier, no vmcnt wait
     template <class F> __device__ __forceinline__ void fire(F&& f) { f((int)threadIdx.x); }
     __device__ __forceinline__ void mark(int) {}
+    // software prefetch of one checkpoint row: global loads are issued here and stay in flight (registers) until
+    // commit() stores them to LDS one adjoint substep later; rows longer than 64*DSIM_PF lanes*regs are read at commit
+    float pf[DSIM_PF];
+    const float* pf_src;
+    __device__ __forceinline__ void prefetch(const float* row, int words) {
+        pf_src = row;
+        if (words > DSIM_NL * DSIM_PF) return;
+#pragma unroll
+        for (int r = 0; r < DSIM_PF; ++r) {
+            const int k = (int)threadIdx.x + DSIM_NL * r;
+            if (k < words) pf[r] = row[k];
+        }
+    }
+    __device__ __forceinline__ void commit(float* dst, int words, int lane) {
+        if (words > DSIM_NL * DSIM_PF) {
+            for (int k = lane; k < words; k += DSIM_NL) dst[k] = pf_src[k];
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < DSIM_PF; ++r) {
+            const int k = lane + DSIM_NL * r;
+            if (k < words) dst[k] = pf[r];
+        }
+    }
 };
 
 template <class O, class D> struct KCommonT {
@@ -49,7 +82,7 @@ template <class O, class D> struct KCommonT {
 template <class O, class D> __device__ __forceinline__ DsimCtxT<O, D> start_env(float* lds, const KCommonT<O, D>& k) {
     uint32_t* l = reinterpret_cast<uint32_t*>(lds);
     for (int i = threadIdx.x; i < k.o.const_words; i += DSIM_NL) l[i] = k.cblob[i];
-    __syncthreads();
+    dsim_wave_sync();
     DsimCtxT<O, D> c;
     c.s = lds;
     c.o = k.o;
@@ -170,6 +203,11 @@ struct TimingExec {
         ++idx;
     }
     template <class F> __device__ __forceinline__ void fire(F&& f) { f((int)threadIdx.x); }
+    const float* pf_src;
+    __device__ __forceinline__ void prefetch(const float* row, int) { pf_src = row; }
+    __device__ __forceinline__ void commit(float* dst, int words, int lane) {
+        for (int k = lane; k < words; k += DSIM_NL) dst[k] = pf_src[k];
+    }
 };
 template <class O, class D>
 __global__ __launch_bounds__(DSIM_NL) void dsim_timer_kernel(KCommonT<O, D> k, DsimEnvSpec sp, int backward,

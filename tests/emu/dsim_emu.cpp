@@ -16,6 +16,11 @@ struct HostExec {
     }
     template <class F> void fire(F&& f) { run(f); }
     void mark(int) {}
+    const float* pf_src = nullptr;
+    void prefetch(const float* row, int) { pf_src = row; }
+    void commit(float* dst, int words, int lane) {
+        for (int k = lane; k < words; k += DSIM_NL) dst[k] = pf_src[k];
+    }
 };
 
 static void make_ctx(const DsimLayout& lay, std::vector<float>& lds, DsimCtx& c, float h) {
