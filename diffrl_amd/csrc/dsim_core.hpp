@@ -733,6 +733,51 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_mass(const Ctx& c, Exec& 
     });
 }
 
+// FK^T of one link: cotangent (a_pc, a_rc) of its X_sc plus axsj (cotangent of X_sj from the motion subspace) ->
+// joint coordinates (added into aq) and the cotangent handed to the parent's X_sc (topar[i]).  a_pj0 / a_rj0: axsj.
+template <class Ctx>
+DSIM_FN void dsim_fk_adjoint_link(const Ctx& c, int i, const DsimLinkInfo& li, v3 a_pc, q4 a_rc, v3 a_pj0, q4 a_rj0) {
+    const int par = li.parent, type = li.type, cs = li.cs;
+    const q4 rj = ldq(WF(xsj) + 7 * i + 3);
+    v3 a_pj = a_pj0 + a_pc;
+    q4 a_rj = a_rj0;
+    const v3 axis = ld3(CF(axis) + 3 * i);
+    const float* q = WF(q);
+    float* aq = WF(aq);
+    if (type == DSIM_JOINT_PRISMATIC) {
+        // pc = pj + rotate(rj, axis) q ; rc = rj
+        const v3 u = rotate(rj, axis);
+        aq[cs] += dot(u, a_pc);
+        a_rj += rotate_adj_q(rj, axis, a_pc * q[cs]);
+        a_rj += a_rc;
+    } else if (type == DSIM_JOINT_REVOLUTE) {
+        const q4 rjc = quat_axis_angle(axis, q[cs]);
+        aq[cs] += quat_axis_angle_adj(axis, q[cs], qmul_adj_b(rj, a_rc));
+        a_rj += qmul_adj_a(rjc, a_rc);
+    } else if (type == DSIM_JOINT_BALL) {
+        const q4 rjc = ldq(q + cs);
+        addq(aq + cs, qmul_adj_b(rj, a_rc));
+        a_rj += qmul_adj_a(rjc, a_rc);
+    } else if (type == DSIM_JOINT_FREE) {
+        const v3 pjc = ld3(q + cs);
+        const q4 rjc = ldq(q + cs + 3);
+        add3(aq + cs, rotate_inv(rj, a_pc));
+        addq(aq + cs + 3, qmul_adj_b(rj, a_rc));
+        a_rj += rotate_adj_q(rj, pjc, a_pc);
+        a_rj += qmul_adj_a(rjc, a_rc);
+    } else {
+        a_rj += a_rc;
+    }
+    if (par >= 0) {
+        const q4 rsp = ldq(WF(xsc) + 7 * par + 3);
+        const v3 ppj = ld3(CF(xpj) + 7 * i);
+        const q4 rpj = ldq(CF(xpj) + 7 * i + 3);
+        float* o = WF(topar) + 7 * i;
+        st3(o, a_pj);
+        stq(o + 3, rotate_adj_q(rsp, ppj, a_pj) + qmul_adj_a(rpj, a_rj));
+    }
+}
+
 // body level: f^T, velocity/acceleration recursions^T, joint motion^T, pose cotangents, FK^T
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec& ex, bool update_mass) {
     ex.mark(10);
@@ -867,64 +912,32 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
                     a_rj += rotate_adj_q(rj, ax, sw - cross(pj, sv_));
                 }
             }
-            st3(WF(axsj) + 7 * i, a_pj);
-            stq(WF(axsj) + 7 * i + 3, a_rj);
+            if (CI(child_start)[i] == CI(child_start)[i + 1]) {
+                // leaf: nothing will be added to its X_sc cotangent, finish its FK^T here (saves a tree-level phase)
+                dsim_fk_adjoint_link(c, i, dsim_link_info(c, i), ld3(WF(agx) + 13 * i) + a_c, ldq(WF(agx) + 13 * i + 3) + a_rc,
+                                     a_pj, a_rj);
+            } else {
+                st3(WF(axsj) + 7 * i, a_pj);
+                stq(WF(axsj) + 7 * i + 3, a_rj);
+            }
         }
     });
-    // FK^T, leaves to root
-    for (int lv = c.d.D - 1; lv >= 0; --lv) {
+    // FK^T, leaves to root.  Leaf links were already finished inside the pose phase above (their X_sc cotangent has
+    // no contribution from children), so only the levels that contain interior links need a phase: d.Dinner of them.
+    for (int lv = c.d.Dinner - 1; lv >= 0; --lv) {
         ex.run([&](int lane) {
             for (int i = lane; i < c.d.L; i += DSIM_NL) {
                 const DsimLinkInfo li = dsim_link_info(c, i);
-                if (li.level != lv) continue;
-                const int par = li.parent, type = li.type, cs = li.cs;
+                const int ch0 = CI(child_start)[i], ch1 = CI(child_start)[i + 1];
+                if (li.level != lv || ch0 == ch1) continue;
                 v3 a_pc = ld3(WF(axsc) + 7 * i);
                 q4 a_rc = ldq(WF(axsc) + 7 * i + 3);
-                for (int e = CI(child_start)[i]; e < CI(child_start)[i + 1]; ++e) {
+                for (int e = ch0; e < ch1; ++e) {
                     const float* o = WF(topar) + 7 * CI(child_list)[e];
                     a_pc += ld3(o);
                     a_rc += ldq(o + 3);
                 }
-                const v3 pj = ld3(WF(xsj) + 7 * i);
-                const q4 rj = ldq(WF(xsj) + 7 * i + 3);
-                v3 a_pj = ld3(WF(axsj) + 7 * i) + a_pc;
-                q4 a_rj = ldq(WF(axsj) + 7 * i + 3);
-                const v3 axis = ld3(CF(axis) + 3 * i);
-                const float* q = WF(q);
-                float* aq = WF(aq);
-                if (type == DSIM_JOINT_PRISMATIC) {
-                    // pc = pj + rotate(rj, axis) q ; rc = rj
-                    const v3 u = rotate(rj, axis);
-                    aq[cs] += dot(u, a_pc);
-                    a_rj += rotate_adj_q(rj, axis, a_pc * q[cs]);
-                    a_rj += a_rc;
-                } else if (type == DSIM_JOINT_REVOLUTE) {
-                    const q4 rjc = quat_axis_angle(axis, q[cs]);
-                    aq[cs] += quat_axis_angle_adj(axis, q[cs], qmul_adj_b(rj, a_rc));
-                    a_rj += qmul_adj_a(rjc, a_rc);
-                } else if (type == DSIM_JOINT_BALL) {
-                    const q4 rjc = ldq(q + cs);
-                    addq(aq + cs, qmul_adj_b(rj, a_rc));
-                    a_rj += qmul_adj_a(rjc, a_rc);
-                } else if (type == DSIM_JOINT_FREE) {
-                    const v3 pjc = ld3(q + cs);
-                    const q4 rjc = ldq(q + cs + 3);
-                    add3(aq + cs, rotate_inv(rj, a_pc));
-                    addq(aq + cs + 3, qmul_adj_b(rj, a_rc));
-                    a_rj += rotate_adj_q(rj, pjc, a_pc);
-                    a_rj += qmul_adj_a(rjc, a_rc);
-                } else {
-                    a_rj += a_rc;
-                }
-                (void)pj;
-                if (par >= 0) {
-                    const q4 rsp = ldq(WF(xsc) + 7 * par + 3);
-                    const v3 ppj = ld3(CF(xpj) + 7 * i);
-                    const q4 rpj = ldq(CF(xpj) + 7 * i + 3);
-                    float* o = WF(topar) + 7 * i;
-                    st3(o, a_pj);
-                    stq(o + 3, rotate_adj_q(rsp, ppj, a_pj) + qmul_adj_a(rpj, a_rj));
-                }
+                dsim_fk_adjoint_link(c, i, li, a_pc, a_rc, ld3(WF(axsj) + 7 * i), ldq(WF(axsj) + 7 * i + 3));
             }
         });
     }

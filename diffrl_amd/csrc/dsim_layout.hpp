@@ -17,6 +17,7 @@
 struct DsimDims {
     int L, nq, nd, C, M, W, NS, D;  // links, coords, dofs, contacts, muscles, waypoints, active muscle segments, tree levels
     int flags;                      // DSIM_F_*
+    int Dinner;                     // number of tree levels that contain links with children
 };
 #define DSIM_F_RANGES 1  // subtree(i) == links [i, i+n_i) and its contacts == one contiguous contact range (pre-order numbering)
 
@@ -297,6 +298,9 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.total_words = cur;
 
     out.o = o;
-    out.d = DsimDims{L, nq, nd, C, M, W, NS, D, ranges ? DSIM_F_RANGES : 0};
+    int Dinner = 0;
+    for (int i = 0; i < L; ++i)
+        if (!child[i].empty() && level[i] + 1 > Dinner) Dinner = level[i] + 1;
+    out.d = DsimDims{L, nq, nd, C, M, W, NS, D, ranges ? DSIM_F_RANGES : 0, Dinner};
     return "";
 }

@@ -51,7 +51,7 @@ def layout(t):
     dims = np.zeros(12, np.int32)
     n = emu().dsim_emu_layout(C.byref(desc), _p(off), C.c_int(off.size), _p(dims))
     assert n == len(names), (n, len(names))
-    return dict(zip(names, off[:n].tolist())), dict(zip("L nq nd C M W NS D flags".split(), dims.tolist()))
+    return dict(zip(names, off[:n].tolist())), dict(zip("L nq nd C M W NS D flags Dinner".split(), dims.tolist()))
 
 
 def substep_image(t, q, qd, act, mact, h):

@@ -36,7 +36,9 @@ qd = torch.tensor(np.tile(g["qd_in"], (reps, 1))[:N], device=dev).reshape(-1)
 a = torch.zeros((N, spec.n_act), device=dev)
 qo, qdo = torch.empty_like(q), torch.empty_like(qd)
 obs, rew = torch.empty((N, spec.n_obs), device=dev), torch.empty(N, device=dev)
-ck = torch.empty((N, S, t.n_q + t.n_qd), device=dev)
+L.dsim_ckpt_floats_mm.restype = C.c_int64
+L.dsim_ckpt_floats_mm.argtypes = [C.c_void_p, C.c_int, C.c_int]
+ck = torch.empty((N, int(L.dsim_ckpt_floats_mm(h, S, mm))), device=dev)
 gq, gqd, go, gr = torch.randn_like(q), torch.randn_like(qd), torch.randn_like(obs), torch.randn_like(rew)
 gqi, gqdi, ga = torch.empty_like(q), torch.empty_like(qd), torch.empty_like(a)
 cap = 4096
