@@ -1,0 +1,129 @@
+"""CPU-only edge cases: model validation in the C-ABI library (runs before any HIP call, so it works without a
+GPU), layout limits, ragged / degenerate articulations through the oracle and the lane-serial phase harness."""
+import copy
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from diffrl_amd import capi
+from diffrl_amd import dflex as df
+from emu_lib import emu_backward, emu_forward, layout
+from oracle_lib import golden, oracle_backward, oracle_forward, project_tangent, relerr, template_from_golden
+
+
+def _create(t):
+    lib = capi.lib()
+    desc, keep = capi.make_desc(t)
+    h = C.c_void_p()
+    rc = lib.dsim_model_create(C.byref(desc), C.byref(h))
+    return rc, lib.dsim_last_error().decode(), h
+
+
+def test_rejects_non_block_diagonal_inertia():
+    t = template_from_golden("ant")
+    t.body_I_m = t.body_I_m.copy()
+    t.body_I_m[2, 0, 4] = 0.1
+    rc, msg, _ = _create(t)
+    assert rc == -1 and "block diagonal" in msg
+
+
+def test_rejects_child_before_parent_and_bad_counts():
+    t = template_from_golden("cartpole")
+    t.joint_parent = t.joint_parent.copy()
+    t.joint_parent[1] = 2
+    rc, msg, _ = _create(t)
+    assert rc == -1 and "parent" in msg
+    t = template_from_golden("cartpole")
+    t.joint_type = t.joint_type.copy()
+    t.joint_type[1] = 4  # claims a free joint but has 1 coordinate
+    rc, msg, _ = _create(t)
+    assert rc == -1 and "type" in msg
+
+
+def test_rejects_rotated_com_frame_and_out_of_range_contact():
+    t = template_from_golden("ant")
+    t.joint_X_cm = t.joint_X_cm.copy()
+    t.joint_X_cm[1, 3:7] = (0.0, 0.7071068, 0.0, 0.7071068)
+    rc, msg, _ = _create(t)
+    assert rc == -1 and "joint_X_cm" in msg
+    t = template_from_golden("ant")
+    t.contact_body = t.contact_body.copy()
+    t.contact_body[0] = 99
+    t.validate = lambda: None
+    rc, msg, _ = _create(t)
+    assert rc == -1 and "contact_body" in msg
+
+
+def test_null_arguments():
+    lib = capi.lib()
+    assert lib.dsim_model_create(None, None) == -1
+    assert lib.dsim_model_destroy(None) == 0
+    assert lib.dsim_ckpt_floats(None, 4) == 0
+
+
+def _chain(n_links, with_shapes=True, floating=False):
+    """user-built articulation through the ModelBuilder API: a revolute chain hanging under gravity"""
+    b = df.sim.ModelBuilder()
+    b.add_articulation()
+    parent = -1
+    for i in range(n_links):
+        kind = df.JOINT_FREE if (floating and i == 0) else df.JOINT_REVOLUTE
+        link = b.add_link(parent, df.transform((0.0 if i == 0 else 0.4, 0.0, 0.0), df.quat_identity()), (0.0, 0.0, 1.0),
+                          kind, stiffness=1.0, damping=0.2, limit_lower=-1.0, limit_upper=1.0, armature=0.02)
+        if with_shapes or i == n_links - 1:
+            b.add_shape_capsule(link, pos=(0.2, 0.0, 0.0), radius=0.05, half_width=0.2, ke=1e4, kd=1e3, kf=1e3, mu=0.5)
+        parent = link
+    if floating:
+        b.joint_q[0:3] = [0.0, 0.3, 0.0]
+    m = b.finalize("cpu")
+    m.ground = True
+    m.gravity = (0.0, -9.81, 0.0)
+    m.collide()
+    return m.template()
+
+
+@pytest.mark.parametrize("n_links,shapes,floating", [(1, True, False), (5, False, False), (4, True, True)])
+def test_user_built_chain_emulated_kernels_vs_oracle(n_links, shapes, floating):
+    """single link, mass-less intermediate links (ragged mass distribution), floating chain in contact"""
+    t = _chain(n_links, shapes, floating)
+    off, dims = layout(t)
+    assert dims["L"] == n_links
+    rng = np.random.default_rng(n_links)
+    n = 3
+    q = np.tile(t.joint_q0, (n, 1)) + rng.normal(0, 0.2, (n, t.n_q)).astype(np.float32)
+    if floating:
+        q[:, 3:7] /= np.linalg.norm(q[:, 3:7], axis=1, keepdims=True)
+    qd = rng.normal(0, 0.5, (n, t.n_qd)).astype(np.float32)
+    act = rng.normal(0, 1.0, (n, t.n_qd)).astype(np.float32)
+    gq, gqd = rng.normal(0, 1, q.shape).astype(np.float32), rng.normal(0, 1, qd.shape).astype(np.float32)
+    for S, mm in [(1, 1), (5, 2), (3, 7)]:     # mm_freq larger than / not dividing the substep count
+        dt = S / 960.0                          # substep length of the shipped environments (1/60 / 16)
+        o = oracle_backward(t, q, qd, act, None, dt, S, mm, gq, gqd)
+        qo, qdo, ck = emu_forward(t, q, qd, act, None, dt, S, mm, want_ckpt=True)
+        r = emu_backward(t, ck, act, None, dt, S, mm, gq, gqd)
+        # mass-less intermediate links make H nearly singular (only the armature regularises it): the reference's
+        # Cholesky + substitution and the explicit inverse used here are both at the fp32 noise floor of that system
+        tol = 2e-5 if shapes else 5e-4
+        assert relerr(qo, o["q_out"]) < tol and relerr(qdo, o["qd_out"]) < 10 * tol
+        gtol = 1e-3 if shapes else 2e-2
+        assert relerr(project_tangent(t, q, r["gq"]), project_tangent(t, q, o["gq"])) < gtol
+        assert relerr(r["gqd"], o["gqd"]) < gtol and relerr(r["gact"], o["gact"]) < gtol
+
+
+def test_degenerate_inputs_stay_finite():
+    """zero velocities / zero actions / resting contact with exactly zero tangential velocity: the reference's
+    zero-gradient rules for normalize / length at 0 (vec3.h:204-222) keep everything finite"""
+    t = template_from_golden("ant")
+    g = golden("ant_step")
+    q = g["q_in"][8:10].copy()
+    qd = np.zeros((2, t.n_qd), np.float32)
+    act = np.zeros((2, t.n_qd), np.float32)
+    S, mm, dt = 16, 16, 1 / 60
+    qo, qdo, ck = emu_forward(t, q, qd, act, None, dt, S, mm, want_ckpt=True)
+    r = emu_backward(t, ck, act, None, dt, S, mm, np.ones_like(q), np.ones_like(qd))
+    o = oracle_backward(t, q, qd, act, None, dt, S, mm, np.ones_like(q), np.ones_like(qd))
+    for a in (qo, qdo, r["gq"], r["gqd"], r["gact"]):
+        assert np.isfinite(a).all()
+    assert relerr(qo, o["q_out"]) < 2e-5
+    assert relerr(r["gact"], o["gact"]) < 1e-3

@@ -1,0 +1,85 @@
+"""-m gpu: edge cases through the real kernels -- user-built articulations (no specialised kernel set: the
+generic runtime-layout kernels run), N = 1, a large non-power-of-two N, actions outside the clip range."""
+import numpy as np
+import pytest
+import torch
+
+from oracle_lib import golden, oracle_backward, project_tangent, relerr, template_from_golden
+from test_edge_cases_cpu import _chain
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run(eng, t, q, qd, act, dt, S, mm, gq, gqd):
+    dev = torch.device(DEV)
+    T = lambda a: torch.tensor(a, device=dev).reshape(-1)  # noqa: E731
+    qo, qdo, ck = eng.forward(T(q), T(qd), T(act), None, dt, S, mm, True)
+    r = eng.backward(ck, T(act), None, dt, S, mm, T(gq), T(gqd))
+    torch.cuda.synchronize()
+    n = q.shape[0]
+    return (qo.cpu().numpy().reshape(n, -1), qdo.cpu().numpy().reshape(n, -1), r[0].cpu().numpy().reshape(n, -1),
+            r[1].cpu().numpy().reshape(n, -1), r[2].cpu().numpy().reshape(n, -1))
+
+
+@pytest.mark.parametrize("n_links,shapes,floating", [(1, True, False), (4, True, True), (7, True, False)])
+def test_generic_kernels_on_user_models(n_links, shapes, floating):
+    from diffrl_amd.engine import Engine
+    t = _chain(n_links, shapes, floating)
+    eng = Engine(t, DEV)
+    assert eng.variant == 0, "a user-built model must run on the generic (runtime layout) kernels"
+    rng = np.random.default_rng(n_links)
+    n = 33
+    q = np.tile(t.joint_q0, (n, 1)) + rng.normal(0, 0.2, (n, t.n_q)).astype(np.float32)
+    if floating:
+        q[:, 3:7] /= np.linalg.norm(q[:, 3:7], axis=1, keepdims=True)
+    qd = rng.normal(0, 0.5, (n, t.n_qd)).astype(np.float32)
+    act = rng.normal(0, 1.0, (n, t.n_qd)).astype(np.float32)
+    gq, gqd = rng.normal(0, 1, q.shape).astype(np.float32), rng.normal(0, 1, qd.shape).astype(np.float32)
+    for S, mm in [(1, 1), (6, 4)]:
+        dt = S / 960.0
+        o = oracle_backward(t, q, qd, act, None, dt, S, mm, gq, gqd)
+        qo, qdo, g_q, g_qd, g_a = _run(eng, t, q, qd, act, dt, S, mm, gq, gqd)
+        assert relerr(qo, o["q_out"]) < 1e-4 and relerr(qdo, o["qd_out"]) < 1e-3
+        assert relerr(project_tangent(t, q, g_q), project_tangent(t, q, o["gq"])) < 1e-3
+        assert relerr(g_qd, o["gqd"]) < 1e-3 and relerr(g_a, o["gact"]) < 1e-3
+
+
+@pytest.mark.parametrize("n", [1, 3, 100003])
+def test_env_count_extremes(n):
+    """one env, a prime-ish count and ~1e5 envs: every env of a replicated batch gives the same answer"""
+    from diffrl_amd.engine import Engine
+    t = template_from_golden("ant")
+    g = golden("ant_step")
+    eng = Engine(t, DEV)
+    dev = torch.device(DEV)
+    S, mm, dt = 16, 16, 1 / 60
+    k = 9  # a state in ground contact
+    q = torch.tensor(g["q_in"][k], device=dev).repeat(n)
+    qd = torch.tensor(g["qd_in"][k], device=dev).repeat(n)
+    a = torch.tensor(g["act_in"][k], device=dev).repeat(n)
+    qo, qdo, ck = eng.forward(q, qd, a, None, dt, S, mm, True)
+    gq = torch.tensor(g["gq_out"][k], device=dev).repeat(n)
+    gqd = torch.tensor(g["gqd_out"][k], device=dev).repeat(n)
+    r = eng.backward(ck, a, None, dt, S, mm, gq, gqd)
+    torch.cuda.synchronize()
+    assert relerr(qo.view(n, -1)[0].cpu().numpy(), g["q_out"][k]) < 1e-4
+    assert relerr(r[2].view(n, -1)[0].cpu().numpy(), g["gact_in"][k]) < 1e-3
+    for x in (qo, qdo, r[0], r[1], r[2]):
+        x = x.view(n, -1)
+        assert torch.equal(x[0], x[n - 1]) and torch.equal(x[0], x[n // 2])
+
+
+def test_clip_range_gradients():
+    """actions beyond [-1, 1] are clipped inside the kernel; their gradient is zero, the others are untouched"""
+    from diffrl_amd import envs
+    e = envs.AntEnv(num_envs=4, device=DEV, no_grad=False, stochastic_init=False, MM_caching_frequency=16,
+                    early_termination=False)
+    e.initialize_trajectory()
+    a = torch.tensor([[0.5, -0.5, 1.5, -2.0, 0.0, 0.9, 1.0, -1.0]] * 4, device=DEV, requires_grad=True)
+    obs, rew, done, _ = e.step(a)
+    assert torch.allclose(obs[:, 29:37], torch.clip(a, -1, 1))
+    (rew.sum() + obs.sum()).backward()
+    g = a.grad
+    assert float(g[:, 2].abs().max()) == 0.0 and float(g[:, 3].abs().max()) == 0.0
+    assert float(g[:, [0, 1, 4, 5, 6, 7]].abs().min()) > 0.0
