@@ -154,6 +154,18 @@ def main():
                          "kernel_ms": t_bwd * 1e3, "alg_bytes_per_launch": bwd_bytes,
                          "note": "fused kernel is VALU/latency-bound by construction (SURVEY 8d); see DESIGN.md"},
         }
+        # forward-only serving path (dflex.config.no_grad: no checkpoint traffic), SURVEY.md 8(f).4 -- informational
+        with torch.no_grad():
+            eng, spec = env.model.engine(), env._spec()
+            q, qd = env.state.joint_q.detach().clone(), env.state.joint_qd.detach().clone()
+            for _ in range(5):
+                eng.env_forward(spec, q, qd, actions[0], env.sim_dt, env.sim_substeps, MM_FREQ[a.env], False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in range(100):
+                q, qd, _, _, _ = eng.env_forward(spec, q, qd, actions[t % H], env.sim_dt, env.sim_substeps, MM_FREQ[a.env], False)
+            torch.cuda.synchronize()
+            out["no_grad_forward_env_steps_per_s"] = 100 * n / (time.perf_counter() - t0)
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.env)
         print(json.dumps(out))
