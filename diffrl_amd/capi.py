@@ -43,6 +43,15 @@ class EnvSpec(C.Structure):
     ]
 
 
+class Episode(C.Structure):
+    """Mirror of `dsim_episode` (include/dsim.h): episode bookkeeping fused into the step kernel."""
+    _fields_ = [
+        ("progress", C.c_void_p), ("done", C.c_void_p), ("obs_before_reset", C.c_void_p), ("reset_q", C.c_void_p),
+        ("reset_qd", C.c_void_p), ("reset_count", C.c_void_p), ("reset_pool", C.c_int32),
+        ("episode_length", C.c_int32), ("height_terminate", C.c_int32), ("check_invalid", C.c_int32),
+    ]
+
+
 ENV_LOCOMOTION, ENV_CARTPOLE, ENV_PLANAR = 1, 2, 3
 REW_ANT, REW_HUMANOID, REW_SNU, REW_CARTPOLE, REW_HOPPER, REW_CHEETAH = 0, 1, 2, 3, 4, 5
 
@@ -125,8 +134,9 @@ def lib():
     L.dsim_step_backward.argtypes = [vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp,
                                      vp]
     ep = C.POINTER(EnvSpec)
-    L.dsim_env_step_forward.argtypes = [vp, ep, C.c_int, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
-    L.dsim_env_step_backward.argtypes = [vp, ep, C.c_int, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp,
+    L.dsim_env_step_forward.argtypes = [vp, ep, C.c_int, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp,
+                                        C.POINTER(Episode), vp]
+    L.dsim_env_step_backward.argtypes = [vp, ep, C.c_int, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp,
                                          vp, vp, vp, vp]
     L.dsim_env_observe.argtypes = [vp, ep, C.c_int, vp, vp, vp, vp, vp, vp]
     for fn in (L.dsim_model_create, L.dsim_model_destroy, L.dsim_step_forward, L.dsim_step_backward,

@@ -426,6 +426,11 @@ DSIM_FN int dsim_hinv_words_d(int nd) { return (nd * nd + 3) & ~3; }
 template <class Ctx> DSIM_FN float* dsim_ckpt_hinv(const Ctx& c, float* g_ckpt, int substeps, int group) {
     return g_ckpt + (size_t)substeps * c.o.save_words + (size_t)group * dsim_hinv_words_d(c.d.nd);
 }
+// tail of an environment's checkpoint: [q, qd at the end of the step (before any episode reset), episode flags]
+template <class Ctx> DSIM_FN float* dsim_ckpt_tail(const Ctx& c, float* g_ckpt, int substeps, int mm_freq) {
+    const int groups = (substeps + mm_freq - 1) / mm_freq;
+    return g_ckpt + (size_t)substeps * c.o.save_words + (size_t)groups * dsim_hinv_words_d(c.d.nd);
+}
 
 // one substep on the LDS-resident state; g_row / g_hinv: where to stream the saved block / the fresh inverse (or null)
 template <class Ctx, class Exec>
@@ -1036,6 +1041,23 @@ struct DsimEnvSpec {
     const float* act_scale;  // [n_act], device memory
 };
 
+// Episode bookkeeping fused into the step.  The reference does this with torch ops and a device->host sync per step:
+// progress_buf / reset_buf at the end of calculateReward (envs/ant.py:297-307, humanoid.py:340-356, hopper.py:288-293)
+// and reset(env_ids) (ant.py:192-234).  Here the step kernel flags the finished environments itself and restarts
+// them from a pool of start states the host drew from the environment's own reset distribution; entry
+// (reset_count[e] % pool) is consumed.  progress == nullptr: no episode handling (plain step).
+struct DsimEpisode {
+    long long* progress;    // [N] in/out: progress_buf
+    long long* done;        // [N] out: reset_buf
+    float* obs_before;      // [N][n_obs] out or nullptr: observation before the reset (extras['obs_before_reset'])
+    const float* reset_q;   // [pool][N][nq]
+    const float* reset_qd;  // [pool][N][nd]
+    int* reset_count;       // [N] in/out
+    int pool, episode_length, height_terminate, check_invalid;
+};
+#define DSIM_EP_DONE 1.0f
+#define DSIM_EP_INVALID 3.0f  // finished because the state blew up: reward forced to 0 (humanoid.py:340-356)
+
 // actions -> LDS: ua (what the env stores as self.actions), act / mact
 template <class Ctx, class Exec>
 DSIM_FN void dsim_env_load_actions(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, const float* g_actions) {
@@ -1057,8 +1079,8 @@ DSIM_FN void dsim_env_load_actions(const Ctx& c, Exec& ex, const DsimEnvSpec& sp
     });
 }
 
-template <class Ctx, class Exec>
-DSIM_FN void dsim_env_observe(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, float* g_obs, float* g_rew) {
+// observation of the state in LDS (q, qd, ua) -> LDS obs
+template <class Ctx, class Exec> DSIM_FN void dsim_env_obs_compute(const Ctx& c, Exec& ex, const DsimEnvSpec& sp) {
     const int nq = c.d.nq, nd = c.d.nd;
     ex.run([&](int lane) {
         const float *q = WF(q), *qd = WF(qd);
@@ -1097,65 +1119,83 @@ DSIM_FN void dsim_env_observe(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, flo
             for (int k = lane; k < nd; k += DSIM_NL) o[nq - 1 + k] = qd[k];
         }
     });
+}
+
+// reward of the observation in LDS (one lane calls this)
+template <class Ctx> DSIM_FN float dsim_env_reward(const Ctx& c, const DsimEnvSpec& sp) {
+    const int nq = c.d.nq, nd = c.d.nd;
+    const float* o = WF(obs);
+    float r = 0.f;
+    if (sp.kind == DSIM_ENV_LOCOMOTION) {
+        const int iu = 11 + (nq - 7) + (nd - 6);
+        r = o[5] + 0.1f * o[iu] + o[iu + 1];
+        float pen = 0.f;
+        if (sp.rew_kind == DSIM_REW_SNU) {
+            for (int k = 0; k < sp.n_act; ++k) pen += fabsf(WF(ua)[k]);
+        } else {
+            for (int k = 0; k < sp.n_act; ++k) pen += WF(ua)[k] * WF(ua)[k];
+        }
+        r += pen * sp.act_pen;
+        if (sp.rew_kind == DSIM_REW_ANT) {
+            r += o[0] - sp.term_h;
+        } else if (sp.rew_kind == DSIM_REW_HUMANOID) {
+            float hr = o[0] - (sp.term_h + sp.term_tol);
+            hr = hr < -1.0f ? -1.0f : (hr > sp.term_tol ? sp.term_tol : hr);
+            if (hr < 0.0f) hr = -200.0f * hr * hr;
+            if (hr > 0.0f) hr = sp.h_scale * hr;
+            r += hr;
+        }
+    } else if (sp.kind == DSIM_ENV_CARTPOLE) {
+        const float th = atan2f(o[2], o[3]);
+        const float a = WF(ua)[0];
+        r = -th * th * sp.pen[0] - o[4] * o[4] * sp.pen[1] - o[0] * o[0] * sp.pen[2] - o[1] * o[1] * sp.pen[3] -
+            a * a * sp.act_pen;
+    } else if (sp.kind == DSIM_ENV_PLANAR) {
+        float pen = 0.f;
+        for (int k = 0; k < sp.n_act; ++k) pen += WF(ua)[k] * WF(ua)[k];
+        r = o[nq - 1] + pen * sp.act_pen;  // progress = qd[0]
+        if (sp.rew_kind == DSIM_REW_HOPPER) {
+            // envs/hopper.py:279-288: clipped / shaped height term + upright term (pen[0] = termination angle)
+            float hr = o[0] - (sp.term_h + sp.term_tol);
+            hr = hr < -1.0f ? -1.0f : (hr > 0.3f ? 0.3f : hr);
+            if (hr < 0.0f) hr = -200.0f * hr * hr;
+            if (hr > 0.0f) hr = sp.h_scale * hr;
+            r += hr + (1.0f - o[1] * o[1] / (sp.pen[0] * sp.pen[0]));
+        }
+    }
+    return r;
+}
+
+template <class Ctx, class Exec>
+DSIM_FN void dsim_env_observe(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, float* g_obs, float* g_rew) {
+    dsim_env_obs_compute(c, ex, sp);
     ex.run([&](int lane) {
         const float* o = WF(obs);
         for (int k = lane; k < sp.n_obs; k += DSIM_NL) g_obs[k] = o[k];
-        if (lane == 0) {
-            float r = 0.f;
-            if (sp.kind == DSIM_ENV_LOCOMOTION) {
-                const int iu = 11 + (nq - 7) + (nd - 6);
-                r = o[5] + 0.1f * o[iu] + o[iu + 1];
-                float pen = 0.f;
-                if (sp.rew_kind == DSIM_REW_SNU) {
-                    for (int k = 0; k < sp.n_act; ++k) pen += fabsf(WF(ua)[k]);
-                } else {
-                    for (int k = 0; k < sp.n_act; ++k) pen += WF(ua)[k] * WF(ua)[k];
-                }
-                r += pen * sp.act_pen;
-                if (sp.rew_kind == DSIM_REW_ANT) {
-                    r += o[0] - sp.term_h;
-                } else if (sp.rew_kind == DSIM_REW_HUMANOID) {
-                    float hr = o[0] - (sp.term_h + sp.term_tol);
-                    hr = hr < -1.0f ? -1.0f : (hr > sp.term_tol ? sp.term_tol : hr);
-                    if (hr < 0.0f) hr = -200.0f * hr * hr;
-                    if (hr > 0.0f) hr = sp.h_scale * hr;
-                    r += hr;
-                }
-            } else if (sp.kind == DSIM_ENV_CARTPOLE) {
-                const float th = atan2f(o[2], o[3]);
-                const float a = WF(ua)[0];
-                r = -th * th * sp.pen[0] - o[4] * o[4] * sp.pen[1] - o[0] * o[0] * sp.pen[2] - o[1] * o[1] * sp.pen[3] -
-                    a * a * sp.act_pen;
-            } else if (sp.kind == DSIM_ENV_PLANAR) {
-                float pen = 0.f;
-                for (int k = 0; k < sp.n_act; ++k) pen += WF(ua)[k] * WF(ua)[k];
-                r = o[nq - 1] + pen * sp.act_pen;  // progress = qd[0]
-                if (sp.rew_kind == DSIM_REW_HOPPER) {
-                    // envs/hopper.py:279-288: clipped / shaped height term + upright term (pen[0] = termination angle)
-                    float hr = o[0] - (sp.term_h + sp.term_tol);
-                    hr = hr < -1.0f ? -1.0f : (hr > 0.3f ? 0.3f : hr);
-                    if (hr < 0.0f) hr = -200.0f * hr * hr;
-                    if (hr > 0.0f) hr = sp.h_scale * hr;
-                    r += hr + (1.0f - o[1] * o[1] / (sp.pen[0] * sp.pen[0]));
-                }
-            }
-            g_rew[0] = r;
-        }
+        if (lane == 0) g_rew[0] = dsim_env_reward(c, sp);
     });
 }
+
 
 // obs/reward^T: adds into aqn/aqdn (cotangents of the step's output state) and writes gua (d/d stored action)
 template <class Ctx, class Exec>
 DSIM_FN void dsim_env_observe_adjoint(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, const float* g_gobs,
-                                      const float* g_grew) {
+                                      const float* g_grew, const float* g_gobs_before, float ep_flags) {
     const int nq = c.d.nq, nd = c.d.nd;
-    // q/qd in LDS hold the step's OUTPUT state, ua the stored actions
+    // q/qd in LDS hold the step's end state (before any reset), ua the stored actions.  Any cotangent pointer may be
+    // null (= zeros).  An environment that was restarted by this step returned the observation of its NEW state as obs
+    // (no dependence on this step) and the old one as obs_before_reset; an invalid state had its reward overwritten.
+    const bool live = ep_flags == 0.f;
     ex.run([&](int lane) {
-        for (int k = lane; k < sp.n_obs; k += DSIM_NL) WF(obs)[k] = g_gobs[k];  // obs buffer reused for its cotangent
+        for (int k = lane; k < sp.n_obs; k += DSIM_NL) {  // obs buffer reused for its cotangent
+            float g = (live && g_gobs) ? g_gobs[k] : 0.f;
+            if (g_gobs_before) g += g_gobs_before[k];
+            WF(obs)[k] = g;
+        }
     });
     ex.run([&](int lane) {
         const float *q = WF(q), *qd = WF(qd);
-        const float gr = g_grew[0];
+        const float gr = (g_grew && ep_flags != DSIM_EP_INVALID) ? g_grew[0] : 0.f;
         float* go = WF(obs);
         if (sp.kind == DSIM_ENV_LOCOMOTION) {
             const int nj = nq - 7, njd = nd - 6, iu = 11 + nj + njd;
@@ -1245,26 +1285,90 @@ DSIM_FN void dsim_env_observe_adjoint(const Ctx& c, Exec& ex, const DsimEnvSpec&
     });
 }
 
-// whole fused env.step(): actions -> sim -> (q', qd', obs, rew)
+// whole fused env.step(): actions -> sim -> (q', qd', obs, rew) [+ episode bookkeeping: progress, done, restart]
 template <class Ctx, class Exec>
 DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, int substeps, int mm_freq,
                                     const float* g_q, const float* g_qd, const float* g_actions, float* g_q_out,
-                                    float* g_qd_out, float* g_obs, float* g_rew, float* g_ckpt) {
+                                    float* g_qd_out, float* g_obs, float* g_rew, float* g_ckpt, const DsimEpisode& ep,
+                                    int e, int n_envs) {
     const int nq = c.d.nq, nd = c.d.nd;
+    // requested first: these global loads complete while the substeps run
+    const long long p1 = ep.progress ? ep.progress[e] + 1 : 0;
+    const int cnt = ep.progress ? ep.reset_count[e] : 0;
     dsim_init_static(c, ex);
     ex.run([&](int lane) {
         for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = g_q[k];
         for (int k = lane; k < nd; k += DSIM_NL) WF(qd)[k] = g_qd[k];
+        if (lane == 0) WF(epf)[0] = 0.f;
     });
     dsim_env_load_actions(c, ex, sp, g_actions);
     for (int s = 0; s < substeps; ++s)
         dsim_fwd_substep(c, ex, (s % mm_freq) == 0, g_ckpt ? g_ckpt + (size_t)s * c.o.save_words : nullptr,
                          g_ckpt ? dsim_ckpt_hinv(c, g_ckpt, substeps, s / mm_freq) : nullptr);
-    ex.fire([&](int lane) {
-        for (int k = lane; k < nq; k += DSIM_NL) g_q_out[k] = WF(q)[k];
-        for (int k = lane; k < nd; k += DSIM_NL) g_qd_out[k] = WF(qd)[k];
+    float* tail = g_ckpt ? dsim_ckpt_tail(c, g_ckpt, substeps, mm_freq) : nullptr;
+    if (!ep.progress) {
+        ex.fire([&](int lane) {
+            for (int k = lane; k < nq; k += DSIM_NL) g_q_out[k] = WF(q)[k];
+            for (int k = lane; k < nd; k += DSIM_NL) g_qd_out[k] = WF(qd)[k];
+            if (tail) {
+                for (int k = lane; k < nq; k += DSIM_NL) tail[k] = WF(q)[k];
+                for (int k = lane; k < nd; k += DSIM_NL) tail[nq + k] = WF(qd)[k];
+                if (lane == 0) tail[nq + nd] = 0.f;
+            }
+        });
+        dsim_env_observe(c, ex, sp, g_obs, g_rew);
+        return;
+    }
+    dsim_env_obs_compute(c, ex, sp);
+    if (ep.check_invalid) {
+        // humanoid.py:340-356: non-finite observation / state, or |q|, |qd| > 1e6
+        ex.run([&](int lane) {
+            bool bad = false;
+            for (int k = lane; k < nq; k += DSIM_NL) bad = bad || !(fabsf(WF(q)[k]) <= 1e6f);
+            for (int k = lane; k < nd; k += DSIM_NL) bad = bad || !(fabsf(WF(qd)[k]) <= 1e6f);
+            for (int k = lane; k < sp.n_obs; k += DSIM_NL) bad = bad || !(fabsf(WF(obs)[k]) <= 3.4028235e38f);
+            if (bad) WF(epf)[0] = 1.f;  // every writer stores the same value
+        });
+    }
+    bool done = false;
+    ex.run([&](int lane) {
+        const float* o = WF(obs);
+        const bool bad = ep.check_invalid && WF(epf)[0] != 0.f;
+        done = (ep.height_terminate && o[0] < sp.term_h) || p1 > (long long)(ep.episode_length - 1) || bad;
+        if (ep.obs_before)
+            for (int k = lane; k < sp.n_obs; k += DSIM_NL) ep.obs_before[(size_t)e * sp.n_obs + k] = o[k];
+        if (tail) {
+            for (int k = lane; k < nq; k += DSIM_NL) tail[k] = WF(q)[k];
+            for (int k = lane; k < nd; k += DSIM_NL) tail[nq + k] = WF(qd)[k];
+        }
+        if (lane == 0) {
+            g_rew[0] = bad ? 0.f : dsim_env_reward(c, sp);
+            ep.progress[e] = done ? 0 : p1;
+            ep.done[e] = done ? 1 : 0;
+            if (tail) tail[nq + nd] = bad ? DSIM_EP_INVALID : (done ? DSIM_EP_DONE : 0.f);
+            if (done) ep.reset_count[e] = cnt + 1;
+        }
+        if (!done) {
+            for (int k = lane; k < sp.n_obs; k += DSIM_NL) g_obs[k] = o[k];
+            for (int k = lane; k < nq; k += DSIM_NL) g_q_out[k] = WF(q)[k];
+            for (int k = lane; k < nd; k += DSIM_NL) g_qd_out[k] = WF(qd)[k];
+        } else {
+            // restart: every lane replaces exactly the words it has just read
+            const size_t slot = (size_t)(cnt % ep.pool) * n_envs + e;
+            for (int k = lane; k < nq; k += DSIM_NL) g_q_out[k] = WF(q)[k] = ep.reset_q[slot * nq + k];
+            for (int k = lane; k < nd; k += DSIM_NL) g_qd_out[k] = WF(qd)[k] = ep.reset_qd[slot * nd + k];
+        }
     });
-    dsim_env_observe(c, ex, sp, g_obs, g_rew);
+    if (done) {
+        // observation of the new state with cleared stored actions (ant.py:228-233)
+        ex.run([&](int lane) {
+            for (int k = lane; k < sp.n_act; k += DSIM_NL) WF(ua)[k] = 0.f;
+        });
+        dsim_env_obs_compute(c, ex, sp);
+        ex.fire([&](int lane) {
+            for (int k = lane; k < sp.n_obs; k += DSIM_NL) g_obs[k] = WF(obs)[k];
+        });
+    }
 }
 
 // state-only observation (reset / initialize_trajectory path): obs of (q, qd) with the given stored actions
@@ -1279,29 +1383,43 @@ DSIM_FN void dsim_env_observe_only(const Ctx& c, Exec& ex, const DsimEnvSpec& sp
     dsim_env_observe(c, ex, sp, g_obs, g_rew);
 }
 
-// reverse of dsim_env_fused_forward; g_q_out/g_qd_out are the forward OUTPUT state (needed by obs^T)
+// reverse of dsim_env_fused_forward.  Cotangent inputs may be null (= zeros); the end state of the step and the episode
+// flags come from the checkpoint tail.
 template <class Ctx, class Exec>
 DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, int substeps, int mm_freq,
-                                     const float* g_ckpt, const float* g_actions, const float* g_q_out,
-                                     const float* g_qd_out, const float* g_gq_out, const float* g_gqd_out,
-                                     const float* g_gobs, const float* g_grew, float* g_gq_in, float* g_gqd_in,
-                                     float* g_gactions) {
+                                     const float* g_ckpt, const float* g_actions, const float* g_gq_out,
+                                     const float* g_gqd_out, const float* g_gobs, const float* g_grew,
+                                     const float* g_gobs_before, float* g_gq_in, float* g_gqd_in, float* g_gactions) {
     const int nq = c.d.nq, nd = c.d.nd, M = c.d.M;
+    const float* tail = dsim_ckpt_tail(c, const_cast<float*>(g_ckpt), substeps, mm_freq);
+    const float ep_flags = tail[nq + nd];
+    const bool live = ep_flags == 0.f;  // not restarted by this step: the returned state is the end state
+    if (ep_flags == DSIM_EP_INVALID) {
+        // The step ended in a non-finite / exploded state: its reward was overwritten and its successor state replaced, so
+        // only obs_before_reset could carry a cotangent -- through intermediates that are inf / NaN.  The reference
+        // scrubs what comes out of that with nan_to_num hooks (humanoid.py:195-206); here the gradient is zero outright.
+        ex.fire([&](int lane) {
+            for (int k = lane; k < nq; k += DSIM_NL) g_gq_in[k] = 0.f;
+            for (int k = lane; k < nd; k += DSIM_NL) g_gqd_in[k] = 0.f;
+            for (int k = lane; k < sp.n_act; k += DSIM_NL) g_gactions[k] = 0.f;
+        });
+        return;
+    }
     dsim_init_static(c, ex);
     ex.run([&](int lane) {
         for (int k = lane; k < nq; k += DSIM_NL) {
-            WF(q)[k] = g_q_out[k];
-            WF(aqn)[k] = g_gq_out[k];
+            WF(q)[k] = tail[k];
+            WF(aqn)[k] = (live && g_gq_out) ? g_gq_out[k] : 0.f;
         }
         for (int k = lane; k < nd; k += DSIM_NL) {
-            WF(qd)[k] = g_qd_out[k];
-            WF(aqdn)[k] = g_gqd_out[k];
+            WF(qd)[k] = tail[nq + k];
+            WF(aqdn)[k] = (live && g_gqd_out) ? g_gqd_out[k] : 0.f;
             WF(aact)[k] = 0.f;
         }
         for (int k = lane; k < M; k += DSIM_NL) WF(amact)[k] = 0.f;
     });
     dsim_env_load_actions(c, ex, sp, g_actions);
-    dsim_env_observe_adjoint(c, ex, sp, g_gobs, g_grew);
+    dsim_env_observe_adjoint(c, ex, sp, g_gobs, g_grew, g_gobs_before, ep_flags);
     const int groups = (substeps + mm_freq - 1) / mm_freq;
     for (int g = groups - 1; g >= 0; --g) {
         const int s0 = g * mm_freq, s1 = (s0 + mm_freq < substeps) ? s0 + mm_freq : substeps;

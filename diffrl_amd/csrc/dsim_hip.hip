@@ -127,7 +127,7 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_bwd_kernel(KCommonT<O, D> k, con
 }
 
 template <class O, class D>
-__global__ __launch_bounds__(DSIM_NL) void dsim_env_fwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp,
+__global__ __launch_bounds__(DSIM_NL) void dsim_env_fwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp, DsimEpisode ep,
                                                                const float* __restrict__ q_in,
                                                                const float* __restrict__ qd_in,
                                                                const float* __restrict__ actions, float* q_out,
@@ -140,19 +140,18 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_env_fwd_kernel(KCommonT<O, D> k,
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_forward(c, ex, sp, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, actions + (size_t)e * sp.n_act,
                            q_out + e * nq, qd_out + e * nd, obs + (size_t)e * sp.n_obs, rew + e,
-                           ckpt ? ckpt + (size_t)e * k.ckpt_stride : nullptr);
+                           ckpt ? ckpt + (size_t)e * k.ckpt_stride : nullptr, ep, e, k.n_envs);
 }
 
 template <class O, class D>
 __global__ __launch_bounds__(DSIM_NL) void dsim_env_bwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp,
                                                                const float* __restrict__ ckpt,
                                                                const float* __restrict__ actions,
-                                                               const float* __restrict__ q_out,
-                                                               const float* __restrict__ qd_out,
                                                                const float* __restrict__ gq_out,
                                                                const float* __restrict__ gqd_out,
                                                                const float* __restrict__ gobs,
-                                                               const float* __restrict__ grew, float* gq_in,
+                                                               const float* __restrict__ grew,
+                                                               const float* __restrict__ gobs_before, float* gq_in,
                                                                float* gqd_in, float* gactions) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
@@ -161,9 +160,10 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_env_bwd_kernel(KCommonT<O, D> k,
     DevExec ex;
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_backward(c, ex, sp, k.substeps, k.mm_freq, ckpt + (size_t)e * k.ckpt_stride,
-                            actions + (size_t)e * sp.n_act, q_out + e * nq, qd_out + e * nd, gq_out + e * nq,
-                            gqd_out + e * nd, gobs + (size_t)e * sp.n_obs, grew + e, gq_in + e * nq, gqd_in + e * nd,
-                            gactions + (size_t)e * sp.n_act);
+                            actions + (size_t)e * sp.n_act, gq_out ? gq_out + e * nq : nullptr,
+                            gqd_out ? gqd_out + e * nd : nullptr, gobs ? gobs + (size_t)e * sp.n_obs : nullptr,
+                            grew ? grew + e : nullptr, gobs_before ? gobs_before + (size_t)e * sp.n_obs : nullptr,
+                            gq_in + e * nq, gqd_in + e * nd, gactions + (size_t)e * sp.n_act);
 }
 
 template <class O, class D>
@@ -227,11 +227,11 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_timer_kernel(KCommonT<O, D> k, D
     if (!backward)
         dsim_env_fused_forward(c, ex, sp, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd,
                                actions + (size_t)e * sp.n_act, q_out + e * nq, qd_out + e * nd,
-                               obs + (size_t)e * sp.n_obs, rew + e, ck);
+                               obs + (size_t)e * sp.n_obs, rew + e, ck, DsimEpisode{}, e, k.n_envs);
     else
-        dsim_env_fused_backward(c, ex, sp, k.substeps, k.mm_freq, ck, actions + (size_t)e * sp.n_act, q_out + e * nq,
-                                qd_out + e * nd, gq_out + e * nq, gqd_out + e * nd, gobs + (size_t)e * sp.n_obs, grew + e,
-                                gq_in + e * nq, gqd_in + e * nd, gactions + (size_t)e * sp.n_act);
+        dsim_env_fused_backward(c, ex, sp, k.substeps, k.mm_freq, ck, actions + (size_t)e * sp.n_act, gq_out + e * nq,
+                                gqd_out + e * nd, gobs + (size_t)e * sp.n_obs, grew + e, nullptr, gq_in + e * nq,
+                                gqd_in + e * nd, gactions + (size_t)e * sp.n_act);
 }
 #endif
 
@@ -299,7 +299,7 @@ KCommonT<O, D> make_k(const dsim_model* m, O o, D d, int n_envs, float dt, int s
     k.substeps = substeps;
     k.mm_freq = mm_freq;
     k.n_envs = n_envs;
-    k.ckpt_stride = dsim_ckpt_words(m->lay.o.save_words, m->lay.d.nd, substeps, mm_freq);
+    k.ckpt_stride = dsim_ckpt_words(m->lay.o.save_words, m->lay.d.nq, m->lay.d.nd, substeps, mm_freq);
     return k;
 }
 
@@ -356,7 +356,7 @@ int make_spec(const dsim_model* m, const dsim_env_spec* e, DsimEnvSpec& sp) {
 extern "C" {
 
 const char* dsim_last_error(void) { return g_err.c_str(); }
-int dsim_version(void) { return 101; }
+int dsim_version(void) { return 102; }
 
 int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
     if (!desc || !out) return fail(DSIM_ERR_INVALID, "null argument");
@@ -413,7 +413,7 @@ int dsim_model_destroy(dsim_model* m) {
 
 int64_t dsim_ckpt_floats_mm(const dsim_model* m, int substeps, int mm_freq) {
     if (!m || substeps <= 0 || mm_freq <= 0) return 0;
-    return (int64_t)dsim_ckpt_words(m->lay.o.save_words, m->lay.d.nd, substeps, mm_freq);
+    return (int64_t)dsim_ckpt_words(m->lay.o.save_words, m->lay.d.nq, m->lay.d.nd, substeps, mm_freq);
 }
 
 int64_t dsim_ckpt_floats(const dsim_model* m, int substeps) { return dsim_ckpt_floats_mm(m, substeps, 1); }
@@ -454,39 +454,57 @@ int dsim_step_backward(const dsim_model* m, int n_envs, const float* ckpt, const
 
 int dsim_env_step_forward(const dsim_model* m, const dsim_env_spec* env, int n_envs, const float* q_in,
                           const float* qd_in, const float* actions, float dt, int substeps, int mm_freq, float* q_out,
-                          float* qd_out, float* obs, float* rew, float* ckpt, void* hip_stream) {
+                          float* qd_out, float* obs, float* rew, float* ckpt, const dsim_episode* episode,
+                          void* hip_stream) {
     int rc = check_common(m, n_envs, dt, substeps, mm_freq);
     if (rc) return rc;
     DsimEnvSpec sp;
     rc = make_spec(m, env, sp);
     if (rc) return rc;
     if (!q_in || !qd_in || !actions || !q_out || !qd_out || !obs || !rew) return fail(DSIM_ERR_INVALID, "null pointer");
+    DsimEpisode ep{};
+    if (episode) {
+        if (!episode->progress || !episode->done || !episode->reset_q || !episode->reset_qd || !episode->reset_count)
+            return fail(DSIM_ERR_INVALID, "episode: null pointer (progress/done/reset_q/reset_qd/reset_count)");
+        if (episode->reset_pool <= 0) return fail(DSIM_ERR_INVALID, "episode: reset_pool must be positive");
+        if (episode->episode_length <= 0) return fail(DSIM_ERR_INVALID, "episode: episode_length must be positive");
+        ep.progress = reinterpret_cast<long long*>(episode->progress);
+        ep.done = reinterpret_cast<long long*>(episode->done);
+        ep.obs_before = episode->obs_before_reset;
+        ep.reset_q = episode->reset_q;
+        ep.reset_qd = episode->reset_qd;
+        ep.reset_count = episode->reset_count;
+        ep.pool = episode->reset_pool;
+        ep.episode_length = episode->episode_length;
+        ep.height_terminate = episode->height_terminate;
+        ep.check_invalid = episode->check_invalid;
+    }
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     return dispatch(m, [&](auto o, auto d) {
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
         hipLaunchKernelGGL((dsim_env_fwd_kernel<decltype(o), decltype(d)>), dim3(n_envs), dim3(DSIM_NL),
-                           (size_t)m->lay.o.fwd_words * 4, st, k, sp, q_in, qd_in, actions, q_out, qd_out, obs, rew, ckpt);
+                           (size_t)m->lay.o.fwd_words * 4, st, k, sp, ep, q_in, qd_in, actions, q_out, qd_out, obs, rew,
+                           ckpt);
         return launched("launch dsim_env_fwd_kernel");
     });
 }
 
 int dsim_env_step_backward(const dsim_model* m, const dsim_env_spec* env, int n_envs, const float* ckpt,
-                           const float* actions, const float* q_out, const float* qd_out, float dt, int substeps,
-                           int mm_freq, const float* gq_out, const float* gqd_out, const float* gobs, const float* grew,
+                           const float* actions, float dt, int substeps, int mm_freq, const float* gq_out,
+                           const float* gqd_out, const float* gobs, const float* grew, const float* gobs_before_reset,
                            float* gq_in, float* gqd_in, float* gactions, void* hip_stream) {
     int rc = check_common(m, n_envs, dt, substeps, mm_freq);
     if (rc) return rc;
     DsimEnvSpec sp;
     rc = make_spec(m, env, sp);
     if (rc) return rc;
-    if (!ckpt || !actions || !q_out || !qd_out || !gq_out || !gqd_out || !gobs || !grew || !gq_in || !gqd_in || !gactions)
-        return fail(DSIM_ERR_INVALID, "null pointer");
+    if (!ckpt || !actions || !gq_in || !gqd_in || !gactions) return fail(DSIM_ERR_INVALID, "null pointer");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     return dispatch(m, [&](auto o, auto d) {
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
         hipLaunchKernelGGL((dsim_env_bwd_kernel<decltype(o), decltype(d)>), dim3(n_envs), dim3(DSIM_NL),
-                           (size_t)m->lay.o.total_words * 4, st, k, sp, ckpt, actions, q_out, qd_out, gq_out, gqd_out, gobs,
-                           grew, gq_in, gqd_in, gactions);
+                           (size_t)m->lay.o.total_words * 4, st, k, sp, ckpt, actions, gq_out, gqd_out, gobs, grew,
+                           gobs_before_reset, gq_in, gqd_in, gactions);
         return launched("launch dsim_env_bwd_kernel");
     });
 }

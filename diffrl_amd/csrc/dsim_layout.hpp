@@ -43,6 +43,7 @@ struct DsimOff {
     int const_words;
     // ---- forward work arrays (floats)
     int q, qd, act, mact, ua, obs, xsj, xsc, pm, S, vj, v, a, i10, f, ftot, cw, tau, qdd, ic10, F, hinv, prow, pcol, mus;
+    int epf;                    // episode flags (fused env surface): [0] invalid state seen, [1] episode finished
     int save_words;             // length of the saved block that starts at q (see dsim_build_layout)
     int fwd_words;
     // ---- adjoint work arrays (floats)
@@ -51,11 +52,16 @@ struct DsimOff {
     int total_words;
 };
 
-// checkpoint geometry (floats per environment): one saved block per substep + one H^-1 per mass-matrix group
+// checkpoint geometry (floats per environment): one saved block per substep + one H^-1 per mass-matrix group +
+// the tail [q, qd of the step's end state (before any episode reset), episode flags]
 inline int dsim_hinv_words(int nd) { return (nd * nd + 3) & ~3; }
-inline long long dsim_ckpt_words(int save_words, int nd, int substeps, int mm_freq) {
+inline int dsim_tail_words(int nq, int nd) { return (nq + nd + 1 + 3) & ~3; }
+inline long long dsim_ckpt_tail_offset(int save_words, int nd, int substeps, int mm_freq) {
     const int groups = (substeps + mm_freq - 1) / mm_freq;
     return (long long)substeps * save_words + (long long)groups * dsim_hinv_words(nd);
+}
+inline long long dsim_ckpt_words(int save_words, int nq, int nd, int substeps, int mm_freq) {
+    return dsim_ckpt_tail_offset(save_words, nd, substeps, mm_freq) + dsim_tail_words(nq, nd);
 }
 
 struct DsimLayout {
@@ -288,6 +294,7 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.f = take(6 * L); o.cw = take(6 * C); o.tau = take(nd);
     o.ic10 = take(10 * L); o.F = take(6 * nd); o.hinv = take(nd * nd); o.prow = take(nd); o.pcol = take(nd);
     o.mus = take(15 * NS);  // forward: 12 floats/segment (signed wrenches); adjoint: 15 floats/segment (cotangents)
+    o.epf = take(4);
     o.fwd_words = cur;
     o.aq = take(nq); o.aqd = take(nd); o.aqn = take(nq); o.aqdn = take(nd); o.aact = take(nd); o.amact = take(M);
     o.aqdd = take(nd); o.atau = take(nd); o.aS = take(6 * nd); o.af = take(6 * L);

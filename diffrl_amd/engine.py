@@ -92,7 +92,8 @@ class Engine:
 
 
     # ---- fused environment surface ------------------------------------------------------------------
-    def env_forward(self, spec, q, qd, actions, dt, substeps, mm_freq, need_ckpt):
+    def env_forward(self, spec, q, qd, actions, dt, substeps, mm_freq, need_ckpt, episode=None):
+        """-> (q_out, qd_out, obs, rew, ckpt[, obs_before_reset, done] when `episode` (an EpisodeIO) is given)"""
         self._check(q, self.n_q, "joint_q")
         self._check(qd, self.n_qd, "joint_qd")
         self._check(actions, spec.n_act, "actions")
@@ -103,23 +104,28 @@ class Engine:
         obs = torch.empty((n, spec.n_obs), dtype=torch.float32, device=self.device)
         rew = torch.empty(n, dtype=torch.float32, device=self.device)
         ckpt = self._alloc_ckpt(n, substeps, mm_freq) if need_ckpt else None
+        ep, extra = None, ()
+        if episode is not None:
+            ep, extra = episode.bind(self, n, spec.n_obs)
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             capi.check(self._lib.dsim_env_step_forward(self._h, C.byref(spec), n, _ptr(q), _ptr(qd), _ptr(actions),
                                                        C.c_float(dt), substeps, mm_freq, _ptr(q_out), _ptr(qd_out),
-                                                       _ptr(obs), _ptr(rew), _ptr(ckpt), st))
-        return q_out, qd_out, obs, rew, ckpt
+                                                       _ptr(obs), _ptr(rew), _ptr(ckpt),
+                                                       C.byref(ep) if ep is not None else None, st))
+        return (q_out, qd_out, obs, rew, ckpt) + extra
 
-    def env_backward(self, spec, ckpt, actions, q_out, qd_out, dt, substeps, mm_freq, gq_out, gqd_out, gobs, grew):
+    def env_backward(self, spec, ckpt, actions, dt, substeps, mm_freq, gq_out, gqd_out, gobs, grew, gobs_before=None):
+        """any cotangent may be None (= zeros: no fill kernels are launched for unused outputs)"""
         n = ckpt.shape[0]
         gq = torch.empty(n * self.n_q, dtype=torch.float32, device=self.device)
         gqd = torch.empty(n * self.n_qd, dtype=torch.float32, device=self.device)
         ga = torch.empty((n, spec.n_act), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            capi.check(self._lib.dsim_env_step_backward(self._h, C.byref(spec), n, _ptr(ckpt), _ptr(actions), _ptr(q_out),
-                                                        _ptr(qd_out), C.c_float(dt), substeps, mm_freq, _ptr(gq_out),
-                                                        _ptr(gqd_out), _ptr(gobs), _ptr(grew), _ptr(gq), _ptr(gqd),
+            capi.check(self._lib.dsim_env_step_backward(self._h, C.byref(spec), n, _ptr(ckpt), _ptr(actions),
+                                                        C.c_float(dt), substeps, mm_freq, _ptr(gq_out), _ptr(gqd_out),
+                                                        _ptr(gobs), _ptr(grew), _ptr(gobs_before), _ptr(gq), _ptr(gqd),
                                                         _ptr(ga), st))
         return gq, gqd, ga
 
@@ -134,34 +140,67 @@ class Engine:
         return obs, rew
 
 
+class EpisodeIO:
+    """Device buffers of the in-kernel episode bookkeeping (`dsim_episode`, include/dsim.h): progress_buf, the pool of
+    start states finished environments restart from, and the termination rules."""
+
+    def __init__(self, progress, reset_q, reset_qd, reset_count, episode_length, height_terminate, check_invalid,
+                 want_obs_before):
+        self.progress, self.reset_q, self.reset_qd, self.reset_count = progress, reset_q, reset_qd, reset_count
+        self.episode_length, self.height_terminate, self.check_invalid = episode_length, height_terminate, check_invalid
+        self.want_obs_before = want_obs_before
+
+    def bind(self, engine, n, n_obs):
+        dev = engine.device
+        for t, dt_, name in ((self.progress, torch.int64, "progress"), (self.reset_count, torch.int32, "reset_count")):
+            if t.device != dev or t.dtype != dt_ or t.numel() != n or not t.is_contiguous():
+                raise capi.DsimError("episode.%s must be a contiguous %s tensor of %d elements on %s" % (name, dt_, n, dev))
+        k = self.reset_q.shape[0]
+        for t, cols, name in ((self.reset_q, engine.n_q, "reset_q"), (self.reset_qd, engine.n_qd, "reset_qd")):
+            if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != k * n * cols:
+                raise capi.DsimError("episode.%s must be a contiguous float32 [pool][n_envs][%d] tensor on %s" % (name, cols, dev))
+        done = torch.empty(n, dtype=torch.int64, device=dev)
+        obs_before = torch.empty((n, n_obs), dtype=torch.float32, device=dev) if self.want_obs_before else None
+        ep = capi.Episode()
+        ep.progress, ep.done = self.progress.data_ptr(), done.data_ptr()
+        ep.obs_before_reset = obs_before.data_ptr() if obs_before is not None else None
+        ep.reset_q, ep.reset_qd, ep.reset_count = self.reset_q.data_ptr(), self.reset_qd.data_ptr(), self.reset_count.data_ptr()
+        ep.reset_pool, ep.episode_length = int(k), int(self.episode_length)
+        ep.height_terminate, ep.check_invalid = int(bool(self.height_terminate)), int(bool(self.check_invalid))
+        return ep, (obs_before, done)
+
+
 class EnvStep(torch.autograd.Function):
-    """Fused env.step(): (joint_q, joint_qd, actions) -> (joint_q', joint_qd', obs, rew); ONE launch each way."""
+    """Fused env.step(): (joint_q, joint_qd, actions) -> (joint_q', joint_qd', obs, rew); ONE launch each way.
+    With an EpisodeIO the launch also does the episode bookkeeping and the outputs gain (obs_before_reset, done)."""
 
     @staticmethod
-    def forward(ctx, engine, spec, dt, substeps, mm_freq, q, qd, actions):
+    def forward(ctx, engine, spec, episode, dt, substeps, mm_freq, q, qd, actions):
         q, qd, actions = q.contiguous(), qd.contiguous(), actions.contiguous()
         need = q.requires_grad or qd.requires_grad or actions.requires_grad
-        q_out, qd_out, obs, rew, ckpt = engine.env_forward(spec, q.detach(), qd.detach(), actions.detach(), dt, substeps,
-                                                           mm_freq, need)
+        out = engine.env_forward(spec, q.detach(), qd.detach(), actions.detach(), dt, substeps, mm_freq, need, episode)
+        q_out, qd_out, obs, rew, ckpt = out[:5]
         ctx.engine, ctx.spec, ctx.dt, ctx.substeps, ctx.mm_freq = engine, spec, dt, substeps, mm_freq
         ctx.shapes = (q.shape, qd.shape, actions.shape)
+        ctx.set_materialize_grads(False)
         if need:
-            ctx.save_for_backward(ckpt, actions.detach(), q_out, qd_out)
-        return q_out.view(q.shape), qd_out.view(qd.shape), obs, rew
+            ctx.save_for_backward(ckpt, actions.detach())
+        res = (q_out.view(q.shape), qd_out.view(qd.shape), obs, rew)
+        if episode is not None:
+            obs_before, done = out[5], out[6]
+            ctx.mark_non_differentiable(done)
+            res = res + ((obs_before if obs_before is not None else obs.new_empty(0)), done)
+        return res
 
     @staticmethod
-    def backward(ctx, gq_out, gqd_out, gobs, grew):
-        ckpt, actions, q_out, qd_out = ctx.saved_tensors
-        dev = ckpt.device
-        n = ckpt.shape[0]
-        z = lambda shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
-        gq_out = gq_out.contiguous() if gq_out is not None else z(ctx.shapes[0])
-        gqd_out = gqd_out.contiguous() if gqd_out is not None else z(ctx.shapes[1])
-        gobs = gobs.contiguous() if gobs is not None else z((n, ctx.spec.n_obs))
-        grew = grew.contiguous() if grew is not None else z((n,))
-        gq, gqd, ga = ctx.engine.env_backward(ctx.spec, ckpt, actions, q_out, qd_out, ctx.dt, ctx.substeps, ctx.mm_freq,
-                                              gq_out, gqd_out, gobs, grew)
-        return None, None, None, None, None, gq.view(ctx.shapes[0]), gqd.view(ctx.shapes[1]), ga.view(ctx.shapes[2])
+    def backward(ctx, gq_out, gqd_out, gobs, grew, gobs_before=None, gdone=None):
+        ckpt, actions = ctx.saved_tensors
+        c = lambda g: g.contiguous() if g is not None else None  # noqa: E731
+        if gobs_before is not None and gobs_before.numel() == 0:
+            gobs_before = None
+        gq, gqd, ga = ctx.engine.env_backward(ctx.spec, ckpt, actions, ctx.dt, ctx.substeps, ctx.mm_freq, c(gq_out),
+                                              c(gqd_out), c(gobs), c(grew), c(gobs_before))
+        return None, None, None, None, None, None, gq.view(ctx.shapes[0]), gqd.view(ctx.shapes[1]), ga.view(ctx.shapes[2])
 
 
 class SimStep(torch.autograd.Function):

@@ -72,6 +72,7 @@ class CartPoleSwingUpEnv(DFlexEnv):
             q, qd, act = self.state.joint_q.clone(), self.state.joint_qd.clone(), self.state.joint_act.clone()
             self.state = self.model.state()
             self.state.joint_q, self.state.joint_qd, self.state.joint_act = q, qd, act
+            self._pool_stale = True
 
     def calculateObservations(self):
         q, qd = self._q(), self._qd()

@@ -124,8 +124,46 @@ class DFlexEnv:
         return torch.clip(actions, -1.0, 1.0)
 
     def _may_reset(self):
-        """False when no environment can possibly be flagged this step (skips the device->host sync)."""
+        """(unfused path) False when no environment can possibly be flagged this step: skips the device->host sync"""
         return True
+
+    # termination rules the fused step applies in-kernel (the tail of the reference's calculateReward)
+    height_terminate = False     # obs[:, 0] < termination_height
+    check_invalid = False        # non-finite / exploded state -> reset with reward 0 (humanoid.py:340-356)
+    reset_pool_size = 2          # start states kept per environment when resets are stochastic
+
+    def _draw_start_states(self, k):
+        """[k][num_envs][nq], [k][num_envs][nd]: k independent draws of reset_state() for every environment"""
+        saved_state, saved_actions = self.state, self.actions
+        ids = torch.arange(self.num_envs, dtype=torch.long, device=self.device)
+        qs, qds = [], []
+        with torch.no_grad():
+            for _ in range(k):
+                st = self.model.state()
+                st.joint_q, st.joint_qd = self.model.joint_q.clone(), self.model.joint_qd.clone()
+                self.state = st
+                self.reset_state(ids)
+                qs.append(self.state.joint_q.view(self.num_envs, -1))
+                qds.append(self.state.joint_qd.view(self.num_envs, -1))
+        self.state, self.actions = saved_state, saved_actions
+        return torch.stack(qs).contiguous(), torch.stack(qds).contiguous()
+
+    def _episode_io(self):
+        """EpisodeIO of the fused step: progress_buf + the pool of start states that finished environments restart from.
+        The pool is drawn with this environment's own reset_state(); with stochastic resets it is redrawn after every
+        clear_grad() (once per rollout), so an environment repeats a start state only if it finishes more than
+        reset_pool_size times within one rollout."""
+        from ..engine import EpisodeIO
+        stochastic = bool(getattr(self, "stochastic_init", False))
+        if getattr(self, "_pool", None) is None or (stochastic and self._pool_stale):
+            self._pool = self._draw_start_states(self.reset_pool_size if stochastic else 1)
+            self._pool_stale = False
+            if getattr(self, "_reset_count", None) is None:
+                self._reset_count = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        if not self.progress_buf.is_contiguous():
+            self.progress_buf = self.progress_buf.contiguous()
+        return EpisodeIO(self.progress_buf, self._pool[0], self._pool[1], self._reset_count, self.episode_length,
+                         self.height_terminate, self.check_invalid, want_obs_before=not self.no_grad)
 
     def _step_fused(self, actions, spec):
         actions = actions.view((self.num_envs, self.num_actions))
@@ -136,39 +174,48 @@ class DFlexEnv:
                 if t.requires_grad:
                     t.register_hook(scrub)
         eng = self.model.engine()
+        epi = self._episode_io()
         if self.no_grad:
             with torch.no_grad():
-                q, qd, obs, rew, _ = eng.env_forward(spec, self.state.joint_q.contiguous(), self.state.joint_qd.contiguous(),
-                                                     actions.contiguous(), float(self.sim_dt), self.sim_substeps,
-                                                     self.MM_caching_frequency, False)
+                q, qd, obs, rew, _, _, done = eng.env_forward(spec, self.state.joint_q.contiguous(),
+                                                              self.state.joint_qd.contiguous(), actions.contiguous(),
+                                                              float(self.sim_dt), self.sim_substeps,
+                                                              self.MM_caching_frequency, False, epi)
+            obs_before = None
         else:
-            q, qd, obs, rew = EnvStep.apply(eng, spec, float(self.sim_dt), self.sim_substeps, self.MM_caching_frequency,
-                                            self.state.joint_q, self.state.joint_qd, actions)
+            q, qd, obs, rew, obs_before, done = EnvStep.apply(eng, spec, epi, float(self.sim_dt), self.sim_substeps,
+                                                              self.MM_caching_frequency, self.state.joint_q,
+                                                              self.state.joint_qd, actions)
         st = df.State(act_like=self.model.joint_qd)
         st.joint_q, st.joint_qd = q, qd
         self.state = st
-        if spec.obs_actions:
-            self.actions = obs[:, self.num_observations - self.num_actions:]
-        else:
-            self.actions = self.stored_actions(actions)
-        self.obs_buf, self.rew_buf = obs, rew
+        # self.actions (clipped / remapped, zero for restarted environments) is materialised on first use
+        self._lazy_actions = (obs, spec.obs_actions, actions.detach(), done)
+        self.obs_buf, self.rew_buf, self.reset_buf = obs, rew, done
         self.sim_time += self.sim_dt
-        self.progress_buf += 1
-        self._progress_hi = getattr(self, "_progress_hi", 0) + 1
         self.num_frames += 1
-        if self._may_reset():
-            self.reset_buf = torch.zeros_like(self.reset_buf)
-            self.flag_resets()
-            env_ids = self.reset_buf.nonzero(as_tuple=False).squeeze(-1)
-        else:
-            self.reset_buf = self._zeros_long()
-            env_ids = ()
         if not self.no_grad:
-            self.obs_buf_before_reset = self.obs_buf
+            self.obs_buf_before_reset = obs_before
             self.extras = {"obs_before_reset": self.obs_buf_before_reset, "episode_end": self.termination_buf}
-        if len(env_ids) > 0:
-            self.reset(env_ids)
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    @property
+    def actions(self):
+        lazy = self.__dict__.get("_lazy_actions")
+        if lazy is not None:
+            obs, in_obs, raw, done = lazy
+            if in_obs:
+                self.__dict__["_actions"] = obs.detach()[:, self.num_observations - self.num_actions:]
+            else:
+                self.__dict__["_actions"] = torch.where(done.bool().unsqueeze(-1), torch.zeros_like(raw),
+                                                        self.stored_actions(raw))
+            self.__dict__["_lazy_actions"] = None
+        return self.__dict__["_actions"]
+
+    @actions.setter
+    def actions(self, value):
+        self.__dict__["_lazy_actions"] = None
+        self.__dict__["_actions"] = value
 
     def _zeros_long(self):
         z = getattr(self, "_zl", None)
@@ -180,6 +227,17 @@ class DFlexEnv:
         """sets reset_buf from obs_buf / progress_buf (the tail of the reference's calculateReward)"""
         self.reset_buf = torch.where(self.progress_buf > self.episode_length - 1, torch.ones_like(self.reset_buf),
                                      self.reset_buf)
+
+    def _refresh_obs(self):
+        """calculateObservations(); one kernel launch instead of ~25 torch ops when no gradient can flow through it"""
+        spec = self._spec() if (self.fused and torch.device(self.device).type == "cuda") else None
+        q, qd, a = self.state.joint_q, self.state.joint_qd, self.actions
+        if spec is None or q.requires_grad or qd.requires_grad or a.requires_grad:
+            self.calculateObservations()
+        else:
+            self.obs_buf, _ = self.model.engine().env_observe(spec, q.contiguous(), qd.contiguous(),
+                                                              a.float().contiguous())
+        return self.obs_buf
 
     # ---- hooks an environment implements ---------------------------------------------------------
     def apply_actions(self, actions):
@@ -237,7 +295,7 @@ class DFlexEnv:
             self.progress_buf[env_ids] = 0
             if len(env_ids) == self.num_envs:
                 self._progress_hi = 0
-            self.calculateObservations()
+            self._refresh_obs()
         return self.obs_buf
 
     def clear_grad(self, checkpoint=None):
@@ -252,14 +310,14 @@ class DFlexEnv:
             if act is not None:
                 self.state.joint_act = act
             self.actions = checkpoint["actions"].clone()
-            if not torch.equal(self.progress_buf, checkpoint["progress_buf"]):
+            if not self.fused and not torch.equal(self.progress_buf, checkpoint["progress_buf"]):
                 self._progress_hi = int(checkpoint["progress_buf"].max())
             self.progress_buf = checkpoint["progress_buf"].clone()
+            self._pool_stale = True
 
     def initialize_trajectory(self):
         self.clear_grad()
-        self.calculateObservations()
-        return self.obs_buf
+        return self._refresh_obs()
 
     def get_checkpoint(self):
         return {"joint_q": self.state.joint_q.clone(), "joint_qd": self.state.joint_qd.clone(),
@@ -277,5 +335,5 @@ class DFlexEnv:
             self._q()[env_ids, :] = init_joint_q.view(-1, self.num_joint_q)[env_ids, :].clone()
             self._qd()[env_ids, :] = init_joint_qd.view(-1, self.num_joint_qd)[env_ids, :].clone()
             self.progress_buf[env_ids] = 0
-            self.calculateObservations()
+            self._refresh_obs()
         return self.obs_buf

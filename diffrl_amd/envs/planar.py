@@ -85,6 +85,7 @@ class HopperEnv(PlanarEnv):
         super().__init__(num_envs, 11, 3, episode_length, MM_caching_frequency, seed, no_grad, render, device)
         self.stochastic_init = stochastic_init
         self.early_termination = early_termination
+        self.height_terminate = bool(early_termination)
         self._build()
 
     def fused_spec(self):

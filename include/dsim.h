@@ -155,17 +155,41 @@ typedef struct dsim_env_spec {
     const float* act_scale;        /* [n_act] DEVICE pointer, borrowed per call */
 } dsim_env_spec;
 
-/* actions[N][n_act] -> q_out, qd_out, obs[N][n_obs], rew[N]  (+ ckpt as in dsim_step_forward) */
+/* Episode bookkeeping fused into the step kernel.  Replaces, per env.step(), the torch ops and the device->host sync of
+ * the reference: progress_buf += 1 and reset_buf at the end of calculateReward (envs/ant.py:176-184, 297-307;
+ * humanoid.py:340-356; hopper.py:288-293), env_ids = reset_buf.nonzero() and reset(env_ids) (ant.py:186-234).
+ * A finished environment e restarts from entry (reset_count[e] % reset_pool) of a pool of start states which the host
+ * draws from the environment's own reset distribution; q_out / qd_out / obs then describe the NEW state (stored actions
+ * cleared), obs_before_reset the old one, rew the old one (0 for an invalid state), progress[e] = 0, done[e] = 1. */
+typedef struct dsim_episode {
+    int64_t* progress;          /* [N] in/out: progress_buf */
+    int64_t* done;              /* [N] out: reset_buf */
+    float* obs_before_reset;    /* [N][n_obs] out, may be NULL */
+    const float* reset_q;       /* [reset_pool][N][n_q] */
+    const float* reset_qd;      /* [reset_pool][N][n_qd] */
+    int32_t* reset_count;       /* [N] in/out: restarts so far */
+    int32_t reset_pool;
+    int32_t episode_length;     /* done when progress > episode_length - 1 */
+    int32_t height_terminate;   /* done when obs[0] < spec.termination_height */
+    int32_t check_invalid;      /* done, reward 0, when obs / q / qd is non-finite or |q|, |qd| > 1e6 */
+} dsim_episode;
+
+/* actions[N][n_act] -> q_out, qd_out, obs[N][n_obs], rew[N]  (+ ckpt as in dsim_step_forward; use dsim_ckpt_floats_mm).
+ * episode may be NULL: plain step, no bookkeeping. */
 int dsim_env_step_forward(const dsim_model* m, const dsim_env_spec* env, int n_envs,
                           const float* q_in, const float* qd_in, const float* actions,
                           float dt, int substeps, int mm_freq,
-                          float* q_out, float* qd_out, float* obs, float* rew, float* ckpt, void* hip_stream);
+                          float* q_out, float* qd_out, float* obs, float* rew, float* ckpt,
+                          const dsim_episode* episode, void* hip_stream);
 
-/* cotangents (gq_out, gqd_out, gobs, grew) -> (gq_in, gqd_in, gactions).  q_out/qd_out: the forward outputs. */
+/* cotangents (gq_out, gqd_out, gobs, grew, gobs_before_reset) -> (gq_in, gqd_in, gactions).  Any of the five inputs may
+ * be NULL (= zeros).  For an environment the forward step restarted, gq_out / gqd_out / gobs refer to the new state and
+ * are ignored, as autograd does in the reference after reset()'s in-place writes. */
 int dsim_env_step_backward(const dsim_model* m, const dsim_env_spec* env, int n_envs,
-                           const float* ckpt, const float* actions, const float* q_out, const float* qd_out,
+                           const float* ckpt, const float* actions,
                            float dt, int substeps, int mm_freq,
                            const float* gq_out, const float* gqd_out, const float* gobs, const float* grew,
+                           const float* gobs_before_reset,
                            float* gq_in, float* gqd_in, float* gactions, void* hip_stream);
 
 /* observation + reward of a given state with given stored actions (reset / initialize_trajectory path) */

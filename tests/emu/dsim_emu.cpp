@@ -80,7 +80,7 @@ int dsim_emu_step_forward(const dsim_model_desc* m, int n_envs, const float* q_i
         make_ctx(lay, lds, c, dt / float(substeps));
         dsim_sim_step_forward(c, ex, substeps, mm_freq, q_in + (size_t)e * nq, qd_in + (size_t)e * nd,
                               act + (size_t)e * nd, M ? mact + (size_t)e * M : nullptr, q_out + (size_t)e * nq,
-                              qd_out + (size_t)e * nd, ckpt ? ckpt + (size_t)e * dsim_ckpt_words(lay.o.save_words, nd, substeps, mm_freq) : nullptr);
+                              qd_out + (size_t)e * nd, ckpt ? ckpt + (size_t)e * dsim_ckpt_words(lay.o.save_words, nq, nd, substeps, mm_freq) : nullptr);
     }
     return 0;
 }
@@ -97,7 +97,7 @@ extern "C" int dsim_emu_step_backward(const dsim_model_desc* m, int n_envs, cons
         std::vector<float> lds;
         DsimCtx c;
         make_ctx(lay, lds, c, dt / float(substeps));
-        dsim_sim_step_backward(c, ex, substeps, mm_freq, ckpt + (size_t)e * dsim_ckpt_words(lay.o.save_words, nd, substeps, mm_freq), act + (size_t)e * nd,
+        dsim_sim_step_backward(c, ex, substeps, mm_freq, ckpt + (size_t)e * dsim_ckpt_words(lay.o.save_words, nq, nd, substeps, mm_freq), act + (size_t)e * nd,
                                M ? mact + (size_t)e * M : nullptr, gq_out + (size_t)e * nq, gqd_out + (size_t)e * nd,
                                gq_in + (size_t)e * nq, gqd_in + (size_t)e * nd, gact ? gact + (size_t)e * nd : nullptr,
                                (gmact && M) ? gmact + (size_t)e * M : nullptr);
@@ -119,11 +119,21 @@ static DsimEnvSpec to_spec(const dsim_env_spec* e) {
 
 extern "C" int dsim_emu_env_forward(const dsim_model_desc* m, const dsim_env_spec* env, int n_envs, const float* q_in,
                                     const float* qd_in, const float* actions, float dt, int substeps, int mm_freq,
-                                    float* q_out, float* qd_out, float* obs, float* rew, float* ckpt) {
+                                    float* q_out, float* qd_out, float* obs, float* rew, float* ckpt,
+                                    const dsim_episode* episode) {
     DsimLayout lay;
     if (!dsim_build_layout(*m, lay).empty()) return -1;
     const int nq = lay.d.nq, nd = lay.d.nd;
     DsimEnvSpec sp = to_spec(env);
+    DsimEpisode ep{};
+    if (episode) {
+        ep.progress = reinterpret_cast<long long*>(episode->progress);
+        ep.done = reinterpret_cast<long long*>(episode->done);
+        ep.obs_before = episode->obs_before_reset;
+        ep.reset_q = episode->reset_q; ep.reset_qd = episode->reset_qd; ep.reset_count = episode->reset_count;
+        ep.pool = episode->reset_pool; ep.episode_length = episode->episode_length;
+        ep.height_terminate = episode->height_terminate; ep.check_invalid = episode->check_invalid;
+    }
     HostExec ex;
     for (int e = 0; e < n_envs; ++e) {
         std::vector<float> lds;
@@ -131,15 +141,17 @@ extern "C" int dsim_emu_env_forward(const dsim_model_desc* m, const dsim_env_spe
         make_ctx(lay, lds, c, dt / float(substeps));
         dsim_env_fused_forward(c, ex, sp, substeps, mm_freq, q_in + (size_t)e * nq, qd_in + (size_t)e * nd,
                                actions + (size_t)e * sp.n_act, q_out + (size_t)e * nq, qd_out + (size_t)e * nd,
-                               obs + (size_t)e * sp.n_obs, rew + e, ckpt ? ckpt + (size_t)e * dsim_ckpt_words(lay.o.save_words, nd, substeps, mm_freq) : nullptr);
+                               obs + (size_t)e * sp.n_obs, rew + e,
+                               ckpt ? ckpt + (size_t)e * dsim_ckpt_words(lay.o.save_words, nq, nd, substeps, mm_freq) : nullptr,
+                               ep, e, n_envs);
     }
     return 0;
 }
 
 extern "C" int dsim_emu_env_backward(const dsim_model_desc* m, const dsim_env_spec* env, int n_envs, const float* ckpt,
-                                     const float* actions, const float* q_out, const float* qd_out, float dt,
-                                     int substeps, int mm_freq, const float* gq_out, const float* gqd_out,
-                                     const float* gobs, const float* grew, float* gq_in, float* gqd_in, float* gactions) {
+                                     const float* actions, float dt, int substeps, int mm_freq, const float* gq_out,
+                                     const float* gqd_out, const float* gobs, const float* grew,
+                                     const float* gobs_before, float* gq_in, float* gqd_in, float* gactions) {
     DsimLayout lay;
     if (!dsim_build_layout(*m, lay).empty()) return -1;
     const int nq = lay.d.nq, nd = lay.d.nd;
@@ -149,9 +161,11 @@ extern "C" int dsim_emu_env_backward(const dsim_model_desc* m, const dsim_env_sp
         std::vector<float> lds;
         DsimCtx c;
         make_ctx(lay, lds, c, dt / float(substeps));
-        dsim_env_fused_backward(c, ex, sp, substeps, mm_freq, ckpt + (size_t)e * dsim_ckpt_words(lay.o.save_words, nd, substeps, mm_freq),
-                                actions + (size_t)e * sp.n_act, q_out + (size_t)e * nq, qd_out + (size_t)e * nd,
-                                gq_out + (size_t)e * nq, gqd_out + (size_t)e * nd, gobs + (size_t)e * sp.n_obs, grew + e,
+        dsim_env_fused_backward(c, ex, sp, substeps, mm_freq,
+                                ckpt + (size_t)e * dsim_ckpt_words(lay.o.save_words, nq, nd, substeps, mm_freq),
+                                actions + (size_t)e * sp.n_act, gq_out ? gq_out + (size_t)e * nq : nullptr,
+                                gqd_out ? gqd_out + (size_t)e * nd : nullptr, gobs ? gobs + (size_t)e * sp.n_obs : nullptr,
+                                grew ? grew + e : nullptr, gobs_before ? gobs_before + (size_t)e * sp.n_obs : nullptr,
                                 gq_in + (size_t)e * nq, gqd_in + (size_t)e * nd, gactions + (size_t)e * sp.n_act);
     }
     return 0;
@@ -160,5 +174,5 @@ extern "C" int dsim_emu_env_backward(const dsim_model_desc* m, const dsim_env_sp
 extern "C" long long dsim_emu_ckpt_floats(const dsim_model_desc* m, int substeps, int mm_freq) {
     DsimLayout lay;
     if (!dsim_build_layout(*m, lay).empty()) return -1;
-    return dsim_ckpt_words(lay.o.save_words, lay.d.nd, substeps, mm_freq);
+    return dsim_ckpt_words(lay.o.save_words, lay.d.nq, lay.d.nd, substeps, mm_freq);
 }

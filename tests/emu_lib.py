@@ -141,7 +141,20 @@ def env_spec_for(env_name, t):
     return spec, sc
 
 
-def emu_env_forward(t, spec, q, qd, actions, dt, substeps, mm_freq):
+def make_episode(progress, done, obs_before, reset_q, reset_qd, reset_count, episode_length, height_terminate,
+                 check_invalid):
+    """capi.Episode over numpy arrays (int64 progress/done, float32 pool [K][N][.], int32 reset_count)"""
+    from diffrl_amd import capi
+    ep = capi.Episode()
+    ep.progress, ep.done = progress.ctypes.data, done.ctypes.data
+    ep.obs_before_reset = obs_before.ctypes.data if obs_before is not None else None
+    ep.reset_q, ep.reset_qd, ep.reset_count = reset_q.ctypes.data, reset_qd.ctypes.data, reset_count.ctypes.data
+    ep.reset_pool, ep.episode_length = int(reset_q.shape[0]), int(episode_length)
+    ep.height_terminate, ep.check_invalid = int(bool(height_terminate)), int(bool(check_invalid))
+    return ep
+
+
+def emu_env_forward(t, spec, q, qd, actions, dt, substeps, mm_freq, episode=None):
     desc, keep = make_desc(t)
     N = q.shape[0]
     q, qd, actions = _c(q), _c(qd), _c(actions)
@@ -149,19 +162,22 @@ def emu_env_forward(t, spec, q, qd, actions, dt, substeps, mm_freq):
     obs, rew = np.zeros((N, spec.n_obs), np.float32), np.zeros(N, np.float32)
     ck = np.zeros((N, ckpt_floats(t, substeps, mm_freq)), np.float32)
     rc = emu().dsim_emu_env_forward(C.byref(desc), C.byref(spec), C.c_int(N), _p(q), _p(qd), _p(actions), C.c_float(dt),
-                                    C.c_int(substeps), C.c_int(mm_freq), _p(qo), _p(qdo), _p(obs), _p(rew), _p(ck))
+                                    C.c_int(substeps), C.c_int(mm_freq), _p(qo), _p(qdo), _p(obs), _p(rew), _p(ck),
+                                    C.byref(episode) if episode is not None else None)
     assert rc == 0
     return qo, qdo, obs, rew, ck
 
 
-def emu_env_backward(t, spec, ck, actions, q_out, qd_out, dt, substeps, mm_freq, gq_out, gqd_out, gobs, grew):
+def emu_env_backward(t, spec, ck, actions, dt, substeps, mm_freq, gq_out, gqd_out, gobs, grew, gobs_before=None):
     desc, keep = make_desc(t)
     N = actions.shape[0]
-    args = [_c(a) for a in (ck, actions, q_out, qd_out)]
-    g = [_c(a) for a in (gq_out, gqd_out, gobs, grew)]
-    gq, gqd, ga = np.zeros_like(g[0]), np.zeros_like(g[1]), np.zeros_like(args[1])
-    rc = emu().dsim_emu_env_backward(C.byref(desc), C.byref(spec), C.c_int(N), _p(args[0]), _p(args[1]), _p(args[2]),
-                                     _p(args[3]), C.c_float(dt), C.c_int(substeps), C.c_int(mm_freq), _p(g[0]), _p(g[1]),
-                                     _p(g[2]), _p(g[3]), _p(gq), _p(gqd), _p(ga))
+    ck, actions = _c(ck), _c(actions)
+    g = [_c(a) if a is not None else None for a in (gq_out, gqd_out, gobs, grew, gobs_before)]
+    nq, nd = t.n_q, t.n_qd
+    gq, gqd, ga = np.zeros((N, nq), np.float32), np.zeros((N, nd), np.float32), np.zeros_like(actions)
+    po = lambda a: _p(a) if a is not None else None  # noqa: E731
+    rc = emu().dsim_emu_env_backward(C.byref(desc), C.byref(spec), C.c_int(N), _p(ck), _p(actions), C.c_float(dt),
+                                     C.c_int(substeps), C.c_int(mm_freq), po(g[0]), po(g[1]), po(g[2]), po(g[3]),
+                                     po(g[4]), _p(gq), _p(gqd), _p(ga))
     assert rc == 0
     return gq, gqd, ga

@@ -37,6 +37,27 @@ def test_modeldesc_matches_header_field_order():
     assert names == [f[0] for f in capi.ModelDesc._fields_]
 
 
+def _struct_fields(name):
+    src = open(os.path.join(ROOT, "include", "dsim.h")).read()
+    body = src[src.index("typedef struct %s {" % name):src.index("} %s;" % name)]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.split("{")[-1].strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            out.append(re.sub(r"\[\d+\]", "", part.strip().split()[-1].lstrip("*")))
+    return out
+
+
+def test_envspec_and_episode_match_header_field_order():
+    assert _struct_fields("dsim_env_spec") == [f[0] for f in capi.EnvSpec._fields_]
+    assert _struct_fields("dsim_episode") == [f[0] for f in capi.Episode._fields_]
+    # layout as the C compiler sees it: 6 pointers + 4 int32
+    assert ctypes.sizeof(capi.Episode) == 6 * 8 + 4 * 4
+
+
 def test_engine_refuses_cpu():
     import numpy as np
 

@@ -29,7 +29,7 @@ def test_fused_rollout_vs_reference(env):
     ga = np.zeros_like(g["actions"])
     for s in reversed(range(H)):
         ck, qo, qdo = tape[s]
-        gq, gqd, ga[s] = emu_env_backward(t, spec, ck, g["actions"][s], qo, qdo, dt, S, mm, gq, gqd,
+        gq, gqd, ga[s] = emu_env_backward(t, spec, ck, g["actions"][s], dt, S, mm, gq, gqd,
                                           np.zeros((n, spec.n_obs), np.float32), -np.ones(n, np.float32))
     a, r = ga.astype(np.float64), g["grad_actions"].astype(np.float64)
     assert (a * r).sum() / (np.linalg.norm(a) * np.linalg.norm(r)) > 0.9999
@@ -56,7 +56,7 @@ def test_fused_obs_cotangent_matches_finite_difference():
     q, qd, a = g["q0"][:1], g["qd0"][:1], (0.5 * g["actions"][0][:1]).astype(np.float32)
     w = rng.normal(0, 1, (1, 37)).astype(np.float32)
     qo, qdo, obs, rew, ck = emu_env_forward(t, spec, q, qd, a, 1 / 60, 16, 16)
-    _, _, ga = emu_env_backward(t, spec, ck, a, qo, qdo, 1 / 60, 16, 16, np.zeros_like(q), np.zeros_like(qd), w,
+    _, _, ga = emu_env_backward(t, spec, ck, a, 1 / 60, 16, 16, np.zeros_like(q), np.zeros_like(qd), w,
                                 np.ones(1, np.float32))
 
     def f(x):

@@ -113,6 +113,65 @@ def test_fused_and_unfused_agree_with_resets():
     assert sum(int(d.sum()) for _, _, d in outs[0]) >= 32    # the episode_length reset happened
 
 
+def test_fused_episode_gradients_match_the_torch_path():
+    """grad mode with restarts inside the rollout: the in-kernel episode handling (progress, done, restart, obs_before_reset,
+    graph cut) gives the same outputs and the same action gradients as the reference-style torch ops + reset()"""
+    dev = torch.device("cuda:0")
+    from diffrl_amd import envs
+    H, n = 8, 32
+    gen = torch.Generator().manual_seed(3)
+    acts0 = (2.0 * torch.rand((H, n, 8), generator=gen) - 1.0).to(dev)
+    w = torch.randn((n, 37), generator=gen).to(dev)
+    res = []
+    for fused in (True, False):
+        e = envs.AntEnv(num_envs=n, device="cuda:0", no_grad=False, stochastic_init=False, MM_caching_frequency=16,
+                        early_termination=True, episode_length=5)
+        e.fused = fused
+        e.reset()
+        e.progress_buf[: n // 2] = 2           # half of the environments finish their episode two steps earlier
+        e.initialize_trajectory()
+        a = acts0.clone().requires_grad_(True)
+        loss, rec = 0.0, []
+        for t in range(H):
+            obs, rew, done, info = e.step(a[t])
+            loss = loss - rew.sum() + 0.01 * (w * info["obs_before_reset"]).sum() + 0.01 * (w * obs).sum()
+            rec.append((obs.detach().clone(), rew.detach().clone(), done.clone(), info["obs_before_reset"].detach().clone(),
+                        e.progress_buf.clone()))
+        loss.backward()
+        res.append((rec, a.grad.clone(), e.state.joint_q.detach().clone()))
+    for (o1, r1, d1, b1, p1), (o2, r2, d2, b2, p2) in zip(res[0][0], res[1][0]):
+        assert torch.equal(d1, d2) and torch.equal(p1, p2)
+        assert torch.allclose(o1, o2, rtol=1e-4, atol=1e-5) and torch.allclose(r1, r2, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(b1, b2, rtol=1e-4, atol=1e-5)
+    assert sum(int(d.sum()) for _, _, d, _, _ in res[0][0]) >= n
+    assert relerr(res[0][1].cpu().numpy(), res[1][1].cpu().numpy()) < 2e-3
+    assert torch.allclose(res[0][2], res[1][2], rtol=1e-4, atol=1e-5)
+
+
+def test_stochastic_restarts_come_from_a_fresh_pool():
+    dev = torch.device("cuda:0")
+    from diffrl_amd import envs
+    n = 64
+    e = envs.AntEnv(num_envs=n, device="cuda:0", no_grad=True, stochastic_init=True, MM_caching_frequency=16,
+                    early_termination=True, episode_length=2)
+    e.reset()
+    a = torch.zeros((n, 8), device=dev)
+    e.step(a)
+    obs, rew, done, _ = e.step(a)
+    assert int(done.sum()) == n and int(e.progress_buf.sum()) == 0
+    pool_q = e._pool[0]
+    q = e.state.joint_q.view(n, -1)
+    assert torch.equal(q, pool_q[0])                       # first restart of every environment: pool entry 0
+    assert (q[:, 7:].std(0) > 0.01).all()                 # and it is a random draw (+-0.2 rad on the joints)
+    assert not torch.equal(pool_q[0], pool_q[1])
+    e.step(a)
+    obs, rew, done, _ = e.step(a)
+    assert torch.equal(e.state.joint_q.view(n, -1), pool_q[1])
+    e.clear_grad()                                        # a new rollout redraws the pool
+    e.step(a)
+    assert not torch.equal(e._pool[0][0], pool_q[0])
+
+
 def test_shac_style_usage():
     """the call pattern of algorithms/shac.py:184-251 (initialize_trajectory, H steps, backward, clear)"""
     e = _make("ant", 64)

@@ -14,7 +14,11 @@ for _ in range(3):
     bench.rollout(env, actions)
 torch.cuda.synchronize()
 for rep in range(3):
-    env.clear_grad(); env.reset(); env.initialize_trajectory()
+    torch.cuda.synchronize(); ta = time.perf_counter()
+    env.clear_grad(); torch.cuda.synchronize(); tb = time.perf_counter()
+    env.reset(); torch.cuda.synchronize(); tc = time.perf_counter()
+    env.initialize_trajectory(); torch.cuda.synchronize(); td = time.perf_counter()
+    print("clear_grad %.2f ms  reset %.2f ms  initialize_trajectory %.2f ms" % ((tb - ta) * 1e3, (tc - tb) * 1e3, (td - tc) * 1e3))
     acts = actions.detach().requires_grad_(True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     loss = 0.0
