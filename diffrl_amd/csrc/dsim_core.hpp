@@ -22,6 +22,8 @@
 //   integrate   sim.py:1505-1636
 // and the reverse sweep with the reference's adjoint conventions.
 #pragma once
+#include <type_traits>
+
 #include "dsim_layout.hpp"
 #include "dsim_math.hpp"
 
@@ -69,9 +71,33 @@ DSIM_FN float dsim_range_sum(const float* data, int stride, int comp, int first,
     for (; e < count; ++e) acc += p[stride * e];
     return acc;
 }
+// Per-model specialised kernels (all-constexpr layout structs, which are empty classes) know an upper bound of every
+// list length at compile time.  One wavefront per SIMD means every DEPENDENT LDS round trip costs its full latency, and
+// a loop with a run-time trip count is a chain of them; with a bound B the loads of a whole list are issued together
+// (entries past the end re-read entry 0 and are discarded), then summed in the usual order: one round trip, not count/4.
+template <class Ctx> struct DsimIsStatic {
+    static constexpr bool value = std::is_empty<decltype(Ctx::d)>::value;
+};
+template <int B>
+DSIM_FN float dsim_range_sum_b(const float* data, int stride, int comp, int first, int count, float acc) {
+    const float* p = data + comp + stride * (count > 0 ? first : 0);
+    float x[B];
+#pragma unroll
+    for (int e = 0; e < B; ++e) x[e] = p[stride * (e < count ? e : 0)];
+#pragma unroll
+    for (int e = 0; e < B; ++e) acc += (e < count) ? x[e] : 0.f;
+    if (count > B) acc = dsim_range_sum(data, stride, comp, first + B, count - B, acc);
+    return acc;
+}
+// Bounds: whole lists for small trees (each lane makes one pass over its items); 8 for larger models, where the lanes
+// loop over several items and loading a long mostly-unused tail per item costs more issue slots than it saves latency.
+template <class D> constexpr int dsim_cap_links() { return D::L <= 10 ? D::L : 8; }
+template <class D> constexpr int dsim_cap_subtree_contacts() { return D::C >= 8 ? 8 : (D::C > 0 ? D::C : 1); }
+template <class D> constexpr int dsim_cap_body_contacts() { return D::C >= 8 ? 8 : (D::C > 0 ? D::C : 1); }
 struct __attribute__((aligned(16), may_alias)) dsim_i4 {
     int x, y, z, w;
 };
+
 // packed per-link record (dsim_layout.hpp: linfo): two 16-byte LDS reads instead of a chain of dependent 4-byte reads
 struct DsimLinkInfo {
     int parent, type, cs, ds, level, nsub, c0, nc;
@@ -85,7 +111,10 @@ template <class Ctx> DSIM_FN DsimLinkInfo dsim_link_info(const Ctx& c, int i) {
 template <class Ctx> DSIM_FN float dsim_subtree_sum(const Ctx& c, const float* data, int stride, int comp, int i) {
     if (c.d.flags & DSIM_F_RANGES) {
         const int n = reinterpret_cast<const dsim_int_a*>(c.s)[c.o.linfo + 8 * i + 5];
-        return dsim_range_sum(data, stride, comp, i, n, 0.f);
+        if constexpr (DsimIsStatic<Ctx>::value)
+            return dsim_range_sum_b<dsim_cap_links<decltype(c.d)>()>(data, stride, comp, i, n, 0.f);
+        else
+            return dsim_range_sum(data, stride, comp, i, n, 0.f);
     }
     return dsim_gather_sum(data, stride, comp, CI(sub_list), CI(sub_start)[i], CI(sub_start)[i + 1], 0.f);
 }
@@ -292,8 +321,13 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_tau(const Ctx& c, Exec& e
             float acc;
             if (c.d.flags & DSIM_F_RANGES) {
                 const DsimLinkInfo li = dsim_link_info(c, i);
-                acc = dsim_range_sum(WF(f), 6, k, i, li.nsub, 0.f);
-                acc = dsim_range_sum(WF(cw), 6, k, li.c0, li.nc, acc);
+                if constexpr (DsimIsStatic<Ctx>::value) {
+                    acc = dsim_range_sum_b<dsim_cap_links<decltype(c.d)>()>(WF(f), 6, k, i, li.nsub, 0.f);
+                    acc = dsim_range_sum_b<dsim_cap_subtree_contacts<decltype(c.d)>()>(WF(cw), 6, k, li.c0, li.nc, acc);
+                } else {
+                    acc = dsim_range_sum(WF(f), 6, k, i, li.nsub, 0.f);
+                    acc = dsim_range_sum(WF(cw), 6, k, li.c0, li.nc, acc);
+                }
             } else {
                 acc = dsim_gather_sum(WF(f), 6, k, CI(sub_list), CI(sub_start)[i], CI(sub_start)[i + 1], 0.f);
                 acc = dsim_gather_sum(WF(cw), 6, k, CI(scb_list), CI(scb_start)[i], CI(scb_start)[i + 1], acc);
@@ -483,7 +517,8 @@ DSIM_FN void dsim_sim_step_forward(const Ctx& c, Exec& ex, int substeps, int mm_
 // ================================================================================================
 // Preconditions: LDS q/qd hold the substep's INPUT state; kinematics, external, tau and solve have
 // been recomputed for it (and dsim_fwd_composite on an update substep); hinv is the inverse that the
-// forward pass used for this substep; aqn/aqdn hold the cotangents of the substep outputs.
+// forward pass used for this substep; aqn/aqdn hold the cotangents of the substep outputs (the layout aliases them with
+// aq/aqd: the integrate^T phase replaces them in place, every lane reading its own link's words before writing them).
 // Postconditions: aq/aqd = cotangents of the substep inputs; aact/amact/aH accumulated.
 
 // integrate^T, solve^T (matnn.h:310-336), tau^T
@@ -562,16 +597,32 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
                 WF(aqd)[d] += -CF(tkd)[i] * at;
             }
         }
-    });
-    // cotangent of body_f_s[j]: f_tot of every ancestor-or-self i of j contains f[j] and tau_d = -S_d . f_tot[link(d)], so
-    // af[j] = -sum over the dofs d of all ancestors-or-self of j of S_d atau_d (one phase, batched over the dof list)
-    ex.run([&](int lane) {
-        for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
+        // cotangent of body_f_s[j]: f_tot of every ancestor-or-self i of j contains f[j] and tau_d = -S_d . f_tot[link(d)], so
+        // af[j] = -sum over the dofs d of all ancestors-or-self of j of S_d atau_d (same phase: reads only S and atau;
+        // items are dealt from the top lane down so that they do not pile onto the lanes of the per-dof loop above)
+        for (int it = DSIM_NL - 1 - lane; it < 6 * c.d.L; it += DSIM_NL) {
             const int j = it / 6, k = it - 6 * j;
             float acc = 0.f;
             const dsim_int_a* lst = CI(adof_list);
             int e = CI(adof_start)[j];
             const int e1 = CI(adof_start)[j + 1];
+            if constexpr (DsimIsStatic<Ctx>::value) {
+                // bounded list: indices in one round trip, operands in a second one (see dsim_range_sum_b)
+                constexpr int B = decltype(c.d)::nd <= 16 ? decltype(c.d)::nd : 8;
+                const int cnt = e1 - e;
+                int dd[B];
+                float sv[B], tv[B];
+#pragma unroll
+                for (int u = 0; u < B; ++u) dd[u] = lst[e + (u < cnt ? u : 0)];
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    sv[u] = WF(S)[6 * dd[u] + k];
+                    tv[u] = WF(atau)[dd[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < B; ++u) acc -= (u < cnt) ? sv[u] * tv[u] : 0.f;
+                e += cnt < B ? cnt : B;
+            }
             for (; e + 4 <= e1; e += 4) {
                 const int d0 = lst[e], d1 = lst[e + 1], d2 = lst[e + 2], d3 = lst[e + 3];
                 const float s0 = WF(S)[6 * d0 + k], s1 = WF(S)[6 * d1 + k], s2 = WF(S)[6 * d2 + k], s3 = WF(S)[6 * d3 + k];
@@ -587,11 +638,10 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
     });
 }
 
-// contacts^T and muscles^T: per-item cotangents of (X_sc, v_s) / (X_sc, activation)
-template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external(const Ctx& c, Exec& ex) {
-    ex.mark(8);
-    if (c.d.C == 0 && c.d.NS == 0) return;
-    ex.run([&](int lane) {
+// contacts^T and muscles^T: per-item cotangents of (X_sc, v_s) / (X_sc, activation).  Runs inside the first body-level
+// phase (both only need af); `lane` is counted from the top of the wavefront there.
+template <class Ctx> DSIM_FN void dsim_bwd_external_items(const Ctx& c, int lane) {
+    {
         for (int k = lane; k < c.d.C; k += DSIM_NL) {
             float* o = WF(acx) + 13 * k;
             for (int r = 0; r < 13; ++r) o[r] = 0.f;
@@ -680,7 +730,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external(const Ctx& c, Ex
             stq(o + 10, rotate_adj_q(ldq(WF(xsc) + 7 * l1 + 3), ld3(CF(mpoints) + 3 * w + 3), a_p1));
             o[14] = a_act;
         }
-    });
+    }
 }
 
 // mass matrix^T (update substeps): aH -> aS (added), ai10m
@@ -806,13 +856,14 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             st3(WF(ac) + 3 * i, cross(r.w, ld3(CF(grav)) * I.m));
             stsv(WF(av) + 6 * i, a_v);  // contact cotangents are added by the item-parallel gather below
         }
+        dsim_bwd_external_items(c, DSIM_NL - 1 - lane);
+    });
+    ex.run([&](int lane) {
         for (int m = lane; m < c.d.M; m += DSIM_NL) {
             float acc = 0.f;
             for (int s = CI(ms_start)[m]; s < CI(ms_start)[m + 1]; ++s) acc += WF(mus)[15 * s + 14];
             WF(amact)[m] += acc;
         }
-    });
-    ex.run([&](int lane) {
         for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
             const int i = it / 6, k = it - 6 * i;
             WF(aatot)[it] = dsim_subtree_sum(c, WF(aa), 6, k, i);
@@ -821,11 +872,15 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
         for (int it = lane; it < 13 * c.d.L; it += DSIM_NL) {
             const int i = it / 13, r = it - 13 * i;
             float acc;
-            if (c.d.flags & DSIM_F_RANGES)  // pre-order numbering: a body's own contacts are one contiguous range
-                acc = dsim_range_sum(WF(acx), 13, r, CI(cb_start)[i], CI(cb_start)[i + 1] - CI(cb_start)[i], 0.f);
-            else
+            if (c.d.flags & DSIM_F_RANGES) {  // pre-order numbering: a body's own contacts are one contiguous range
+                if constexpr (DsimIsStatic<Ctx>::value)
+                    acc = dsim_range_sum_b<dsim_cap_body_contacts<decltype(c.d)>()>(WF(acx), 13, r, CI(cb_start)[i],
+                                                                                   CI(cb_start)[i + 1] - CI(cb_start)[i], 0.f);
+                else
+                    acc = dsim_range_sum(WF(acx), 13, r, CI(cb_start)[i], CI(cb_start)[i + 1] - CI(cb_start)[i], 0.f);
+            } else
                 acc = dsim_gather_sum(WF(acx), 13, r, CI(cb_list), CI(cb_start)[i], CI(cb_start)[i + 1], 0.f);
-            if (r < 7)
+            if (c.d.NS > 0 && r < 7)
                 for (int e = CI(ml_start)[i]; e < CI(ml_start)[i + 1]; ++e) {
                     const int code = CI(ml_list)[e];
                     acc += WF(mus)[15 * (code >> 1) + 7 * (code & 1) + r];
@@ -950,7 +1005,6 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
 
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_substep(const Ctx& c, Exec& ex, bool update_mass) {
     dsim_bwd_joint_space(c, ex);
-    dsim_bwd_external(c, ex);
     if (update_mass) dsim_bwd_mass(c, ex);
     dsim_bwd_bodies(c, ex, update_mass);
 }
@@ -994,11 +1048,7 @@ DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
             });
             if (s > 0) ex.prefetch(g_ckpt + (size_t)(s - 1) * c.o.save_words, c.o.save_words);
             if (s == s0) dsim_fwd_composite(c, ex);
-            dsim_bwd_substep(c, ex, s == s0);
-            ex.run([&](int lane) {
-                for (int k = lane; k < nq; k += DSIM_NL) WF(aqn)[k] = WF(aq)[k];
-                for (int k = lane; k < nd; k += DSIM_NL) WF(aqdn)[k] = WF(aqd)[k];
-            });
+            dsim_bwd_substep(c, ex, s == s0);  // aq / aqd (== aqn / aqdn, same LDS words) now belong to substep s - 1
         }
     }
     ex.run([&](int lane) {
@@ -1439,11 +1489,7 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
             });
             if (s > 0) ex.prefetch(g_ckpt + (size_t)(s - 1) * c.o.save_words, c.o.save_words);
             if (s == s0) dsim_fwd_composite(c, ex);
-            dsim_bwd_substep(c, ex, s == s0);
-            ex.run([&](int lane) {
-                for (int k = lane; k < nq; k += DSIM_NL) WF(aqn)[k] = WF(aq)[k];
-                for (int k = lane; k < nd; k += DSIM_NL) WF(aqdn)[k] = WF(aqd)[k];
-            });
+            dsim_bwd_substep(c, ex, s == s0);  // aq / aqd (== aqn / aqdn, same LDS words) now belong to substep s - 1
         }
     }
     ex.run([&](int lane) {

@@ -296,7 +296,9 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.mus = take(15 * NS);  // forward: 12 floats/segment (signed wrenches); adjoint: 15 floats/segment (cotangents)
     o.epf = take(4);
     o.fwd_words = cur;
-    o.aq = take(nq); o.aqd = take(nd); o.aqn = take(nq); o.aqdn = take(nd); o.aact = take(nd); o.amact = take(M);
+    o.aq = take(nq); o.aqd = take(nd);
+    o.aqn = o.aq; o.aqdn = o.aqd;  // integrate^T turns the output cotangents into the input cotangents in place (per-link lanes)
+    o.aact = take(nd); o.amact = take(M);
     o.aqdd = take(nd); o.atau = take(nd); o.aS = take(6 * nd); o.af = take(6 * L);
     o.acx = take(13 * C); o.axsc = take(7 * L); o.axsj = take(7 * L); o.ac = take(3 * L);
     o.av = take(6 * L); o.aa = take(6 * L); o.aatot = take(6 * L); o.avtot = take(6 * L); o.avj = take(6 * L);
