@@ -288,10 +288,18 @@ class DFlexEnv:
         if env_ids is None and force_reset:
             env_ids = torch.arange(self.num_envs, dtype=torch.long, device=self.device)
         if env_ids is not None:
-            # fresh tensors: the old ones may be part of an autograd graph
-            self.state.joint_q = self.state.joint_q.clone()
-            self.state.joint_qd = self.state.joint_qd.clone()
-            self.reset_state(env_ids)
+            full = len(env_ids) == self.num_envs
+            if full and self.fused and not getattr(self, "stochastic_init", False) and torch.device(self.device).type == "cuda":
+                # every environment back to the (deterministic) start state: two copies from the start-state pool
+                # instead of ~25 indexed writes
+                pool_q, pool_qd = self._episode_io().reset_q, self._episode_io().reset_qd
+                self.state.joint_q, self.state.joint_qd = pool_q[0].reshape(-1).clone(), pool_qd[0].reshape(-1).clone()
+                self.actions = torch.zeros_like(self.actions)
+            else:
+                # fresh tensors: the old ones may be part of an autograd graph
+                self.state.joint_q = self.state.joint_q.clone()
+                self.state.joint_qd = self.state.joint_qd.clone()
+                self.reset_state(env_ids)
             self.progress_buf[env_ids] = 0
             if len(env_ids) == self.num_envs:
                 self._progress_hi = 0
@@ -301,18 +309,22 @@ class DFlexEnv:
     def clear_grad(self, checkpoint=None):
         """Cuts the graph between the current state and everything before it."""
         with torch.no_grad():
-            if checkpoint is None:
-                checkpoint = self.get_checkpoint()
             act = self.state.joint_act.clone() if self.keep_act_on_clear else None
-            self.state = self.model.state()
-            self.state.joint_q = checkpoint["joint_q"].clone()
-            self.state.joint_qd = checkpoint["joint_qd"].clone()
+            st = df.State(act_like=self.model.joint_qd)
+            if checkpoint is None:
+                # same result as restoring get_checkpoint(), without copying everything twice
+                st.joint_q, st.joint_qd = self.state.joint_q.detach().clone(), self.state.joint_qd.detach().clone()
+                self.actions = self.actions.detach().clone()
+                self.progress_buf = self.progress_buf.clone()
+            else:
+                st.joint_q, st.joint_qd = checkpoint["joint_q"].clone(), checkpoint["joint_qd"].clone()
+                self.actions = checkpoint["actions"].clone()
+                if not self.fused and not torch.equal(self.progress_buf, checkpoint["progress_buf"]):
+                    self._progress_hi = int(checkpoint["progress_buf"].max())
+                self.progress_buf = checkpoint["progress_buf"].clone()
+            self.state = st
             if act is not None:
                 self.state.joint_act = act
-            self.actions = checkpoint["actions"].clone()
-            if not self.fused and not torch.equal(self.progress_buf, checkpoint["progress_buf"]):
-                self._progress_hi = int(checkpoint["progress_buf"].max())
-            self.progress_buf = checkpoint["progress_buf"].clone()
             self._pool_stale = True
 
     def initialize_trajectory(self):
