@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdsim_hip.so")
+LIB_PATH = os.environ.get("DSIM_LIB") or os.path.join(_HERE, "csrc", "libdsim_hip.so")  # DSIM_LIB: developer override (A/B builds)
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
