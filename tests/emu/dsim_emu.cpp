@@ -9,6 +9,7 @@
 
 #define DSIM_FN static inline
 #include "../../diffrl_amd/csrc/dsim_core.hpp"
+#include "../../diffrl_amd/csrc/dsim_static_layouts.hpp"
 
 struct HostExec {
     template <class F> void run(F&& f) {
@@ -117,14 +118,25 @@ static DsimEnvSpec to_spec(const dsim_env_spec* e) {
     return sp;
 }
 
-extern "C" int dsim_emu_env_forward(const dsim_model_desc* m, const dsim_env_spec* env, int n_envs, const float* q_in,
-                                    const float* qd_in, const float* actions, float dt, int substeps, int mm_freq,
-                                    float* q_out, float* qd_out, float* obs, float* rew, float* ckpt,
-                                    const dsim_episode* episode) {
-    DsimLayout lay;
-    if (!dsim_build_layout(*m, lay).empty()) return -1;
-    const int nq = lay.d.nq, nd = lay.d.nd;
-    DsimEnvSpec sp = to_spec(env);
+// The per-model specialised code paths (compile-time layouts: `if constexpr (DsimIsStatic...)` branches, bounded sums)
+// can be exercised on the host too: with dsim_emu_use_static(1) the env entry points below instantiate the phase code
+// with the generated all-constexpr layout of the matching model, exactly as the library's dispatch() does.
+static int g_use_static = 0;
+extern "C" void dsim_emu_use_static(int on) { g_use_static = on; }
+
+template <class F> static int emu_dispatch(const DsimLayout& lay, F&& f) {
+    if (!g_use_static) return f(lay.o, lay.d);
+    const size_t no = sizeof(DsimOff) / sizeof(int), nd = sizeof(DsimDims) / sizeof(int);
+#define DSIM_EMU_CASE(T)                                                                                            \
+    if (sizeof(kDsimStatic##T) == (no + nd) * sizeof(int) && memcmp(kDsimStatic##T, &lay.o, no * sizeof(int)) == 0 && \
+        memcmp(kDsimStatic##T + no, &lay.d, nd * sizeof(int)) == 0)                                                  \
+        return f(DsimOff##T{}, DsimDims##T{});
+    DSIM_STATIC_VARIANTS(DSIM_EMU_CASE)
+#undef DSIM_EMU_CASE
+    return -2;  // no specialised variant for this model
+}
+
+static DsimEpisode to_episode(const dsim_episode* episode) {
     DsimEpisode ep{};
     if (episode) {
         ep.progress = reinterpret_cast<long long*>(episode->progress);
@@ -134,18 +146,33 @@ extern "C" int dsim_emu_env_forward(const dsim_model_desc* m, const dsim_env_spe
         ep.pool = episode->reset_pool; ep.episode_length = episode->episode_length;
         ep.height_terminate = episode->height_terminate; ep.check_invalid = episode->check_invalid;
     }
-    HostExec ex;
-    for (int e = 0; e < n_envs; ++e) {
-        std::vector<float> lds;
-        DsimCtx c;
-        make_ctx(lay, lds, c, dt / float(substeps));
-        dsim_env_fused_forward(c, ex, sp, substeps, mm_freq, q_in + (size_t)e * nq, qd_in + (size_t)e * nd,
-                               actions + (size_t)e * sp.n_act, q_out + (size_t)e * nq, qd_out + (size_t)e * nd,
-                               obs + (size_t)e * sp.n_obs, rew + e,
-                               ckpt ? ckpt + (size_t)e * dsim_ckpt_words(lay.o.save_words, nq, nd, substeps, mm_freq) : nullptr,
-                               ep, e, n_envs);
-    }
-    return 0;
+    return ep;
+}
+
+extern "C" int dsim_emu_env_forward(const dsim_model_desc* m, const dsim_env_spec* env, int n_envs, const float* q_in,
+                                    const float* qd_in, const float* actions, float dt, int substeps, int mm_freq,
+                                    float* q_out, float* qd_out, float* obs, float* rew, float* ckpt,
+                                    const dsim_episode* episode) {
+    DsimLayout lay;
+    if (!dsim_build_layout(*m, lay).empty()) return -1;
+    const int nq = lay.d.nq, nd = lay.d.nd;
+    DsimEnvSpec sp = to_spec(env);
+    DsimEpisode ep = to_episode(episode);
+    const size_t stride = dsim_ckpt_words(lay.o.save_words, nq, nd, substeps, mm_freq);
+    return emu_dispatch(lay, [&](auto o, auto d) {
+        HostExec ex;
+        for (int e = 0; e < n_envs; ++e) {
+            std::vector<float> lds(lay.o.total_words, 0.f);
+            memcpy(lds.data(), lay.cblob.data(), sizeof(uint32_t) * lay.o.const_words);
+            DsimCtxT<decltype(o), decltype(d)> c;
+            c.s = lds.data(); c.o = o; c.d = d; c.h = dt / float(substeps);
+            dsim_env_fused_forward(c, ex, sp, substeps, mm_freq, q_in + (size_t)e * nq, qd_in + (size_t)e * nd,
+                                   actions + (size_t)e * sp.n_act, q_out + (size_t)e * nq, qd_out + (size_t)e * nd,
+                                   obs + (size_t)e * sp.n_obs, rew + e, ckpt ? ckpt + (size_t)e * stride : nullptr, ep, e,
+                                   n_envs);
+        }
+        return 0;
+    });
 }
 
 extern "C" int dsim_emu_env_backward(const dsim_model_desc* m, const dsim_env_spec* env, int n_envs, const float* ckpt,
@@ -156,19 +183,23 @@ extern "C" int dsim_emu_env_backward(const dsim_model_desc* m, const dsim_env_sp
     if (!dsim_build_layout(*m, lay).empty()) return -1;
     const int nq = lay.d.nq, nd = lay.d.nd;
     DsimEnvSpec sp = to_spec(env);
-    HostExec ex;
-    for (int e = 0; e < n_envs; ++e) {
-        std::vector<float> lds;
-        DsimCtx c;
-        make_ctx(lay, lds, c, dt / float(substeps));
-        dsim_env_fused_backward(c, ex, sp, substeps, mm_freq,
-                                ckpt + (size_t)e * dsim_ckpt_words(lay.o.save_words, nq, nd, substeps, mm_freq),
-                                actions + (size_t)e * sp.n_act, gq_out ? gq_out + (size_t)e * nq : nullptr,
-                                gqd_out ? gqd_out + (size_t)e * nd : nullptr, gobs ? gobs + (size_t)e * sp.n_obs : nullptr,
-                                grew ? grew + e : nullptr, gobs_before ? gobs_before + (size_t)e * sp.n_obs : nullptr,
-                                gq_in + (size_t)e * nq, gqd_in + (size_t)e * nd, gactions + (size_t)e * sp.n_act);
-    }
-    return 0;
+    const size_t stride = dsim_ckpt_words(lay.o.save_words, nq, nd, substeps, mm_freq);
+    return emu_dispatch(lay, [&](auto o, auto d) {
+        HostExec ex;
+        for (int e = 0; e < n_envs; ++e) {
+            std::vector<float> lds(lay.o.total_words, 0.f);
+            memcpy(lds.data(), lay.cblob.data(), sizeof(uint32_t) * lay.o.const_words);
+            DsimCtxT<decltype(o), decltype(d)> c;
+            c.s = lds.data(); c.o = o; c.d = d; c.h = dt / float(substeps);
+            dsim_env_fused_backward(c, ex, sp, substeps, mm_freq, ckpt + (size_t)e * stride,
+                                    actions + (size_t)e * sp.n_act, gq_out ? gq_out + (size_t)e * nq : nullptr,
+                                    gqd_out ? gqd_out + (size_t)e * nd : nullptr,
+                                    gobs ? gobs + (size_t)e * sp.n_obs : nullptr, grew ? grew + e : nullptr,
+                                    gobs_before ? gobs_before + (size_t)e * sp.n_obs : nullptr, gq_in + (size_t)e * nq,
+                                    gqd_in + (size_t)e * nd, gactions + (size_t)e * sp.n_act);
+        }
+        return 0;
+    });
 }
 
 extern "C" long long dsim_emu_ckpt_floats(const dsim_model_desc* m, int substeps, int mm_freq) {

@@ -1,0 +1,56 @@
+"""CPU-only: the per-model specialised code paths (compile-time layouts, `if constexpr` branches such as the bounded
+one-round-trip sums) executed lane-serially and compared with the generic run-time-layout paths of the same phase code.
+On the GPU the same comparison is tests/test_gpu_parity.py::test_specialised_kernels_match_generic."""
+import numpy as np
+import pytest
+
+from emu_lib import emu, emu_env_backward, emu_env_forward, env_spec_for
+from oracle_lib import golden, template_from_golden
+
+SUBSTEPS = {"cartpole": 4, "ant": 16, "humanoid": 48, "snu": 48, "hopper": 16, "cheetah": 16}
+
+
+@pytest.fixture
+def static_mode():
+    emu().dsim_emu_use_static(1)
+    yield
+    emu().dsim_emu_use_static(0)
+
+
+@pytest.mark.parametrize("env", ["cartpole", "ant", "humanoid", "snu", "hopper", "cheetah"])
+def test_specialised_paths_match_generic(env, static_mode):
+    t = template_from_golden(env)
+    g = golden(env + "_rollout")
+    spec, keep = env_spec_for(env, t)
+    S, mm, dt = SUBSTEPS[env], int(g["mm_freq"]), 1.0 / 60.0
+    n = min(2, g["q0"].shape[0])
+    q, qd, a = g["q0"][:n], g["qd0"][:n], g["actions"][0][:n]
+    rng = np.random.default_rng(0)
+    cot = [rng.normal(size=x.shape).astype(np.float32) for x in (q, qd)]
+    gobs, grew = rng.normal(size=(n, spec.n_obs)).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    out = {}
+    for mode in (1, 0):
+        emu().dsim_emu_use_static(mode)
+        f = emu_env_forward(t, spec, q, qd, a, dt, S, mm)   # asserts rc == 0: a specialised variant exists for every env
+        b = emu_env_backward(t, spec, f[4], a, dt, S, mm, cot[0], cot[1], gobs, grew)
+        out[mode] = (f[:4], b)
+    for x, y in zip(out[1][0] + out[1][1], out[0][0] + out[0][1]):
+        # same operations in the same order; the bounded sums only add exact zeros for the unused slots
+        np.testing.assert_allclose(x, y, rtol=0, atol=0)
+
+
+def test_unknown_model_has_no_specialised_variant(static_mode):
+    """a model whose layout is not in the generated table must not silently run a specialised path"""
+    import copy
+    t = copy.deepcopy(template_from_golden("ant"))
+    t.joint_armature = np.asarray(t.joint_armature) * 1.0
+    t.contact_point = np.asarray(t.contact_point)[:-1]     # one contact less: different layout
+    t.contact_dist = np.asarray(t.contact_dist)[:-1]
+    t.contact_body = np.asarray(t.contact_body)[:-1]
+    t.contact_material = np.asarray(t.contact_material)[:-1]
+    g = golden("ant_rollout")
+    spec, keep = env_spec_for("ant", t)
+    with pytest.raises(AssertionError):
+        emu_env_forward(t, spec, g["q0"][:1], g["qd0"][:1], g["actions"][0][:1], 1 / 60, 16, 16)
+    emu().dsim_emu_use_static(0)
+    emu_env_forward(t, spec, g["q0"][:1], g["qd0"][:1], g["actions"][0][:1], 1 / 60, 16, 16)
