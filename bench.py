@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=1024)
     ap.add_argument("--horizon", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="time the Python-driven step loop instead of the graph replay")
     a = ap.parse_args()
 
     from diffrl_amd import sharding
@@ -116,14 +117,47 @@ def main():
         torch.cuda.synchronize()
 
     import gc
+    ap_eager = a.eager
+    submission = "eager: one launch per env.step each way, issued from the Python loop"
+    roll = None
+    if not ap_eager:
+        # whole rollout (32 x DFlexEnv.step + the backward sweep) captured once as a HIP graph, replayed as one submission
+        # (diffrl_amd/graph.py).  Every replay re-executes all 64 launches on the same inputs.
+        try:
+            from diffrl_amd.graph import GraphedRollout
+            g_eager = rollout(env, actions).clone()
+            acts = actions.detach().clone().requires_grad_(True)
+
+            def body(e):
+                e.initialize_trajectory()
+                rews = [e.step(a_t)[1] for a_t in acts.unbind(0)]
+                return -torch.stack(rews).sum()
+
+            env.clear_grad()
+            env.reset()
+            roll = GraphedRollout(env, body, leaves=[acts], carry_state=False)
+            roll.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(acts.grad, g_eager), "graph replay and eager rollout disagree"
+            submission = "one HIP graph per rollout: the 32 forward + 32 adjoint launches captured through DFlexEnv.step"
+        except Exception as ex:  # capture unsupported on this stack: measure the eager loop instead, and say so
+            roll = None
+            submission = "eager (graph capture failed: %s)" % str(ex)[:120]
+
+    def one():
+        if roll is not None:
+            roll.replay()
+            return acts.grad
+        return rollout(env, actions)
+
     for _ in range(a.warmup):
-        rollout(env, actions)
+        one()
     gc.collect()
     gc.disable()   # no cyclic-GC pause inside the timed region (a gen-2 collection costs tens of ms once every few rollouts)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        grad = rollout(env, actions)
+        grad = one()
     barrier()
     el = time.perf_counter() - t0
     gc.enable()
@@ -131,6 +165,19 @@ def main():
     el = sharding.max_over_ranks(el, device)
     total_env_steps = a.steps * world * n * H
     value = total_env_steps / el
+    eager_value = None
+    if roll is not None and rank == 0:
+        # the same rollouts driven step by step from Python (what a caller that does not capture gets)
+        env2 = make_env(a.env, n, str(device))
+        for _ in range(2):
+            rollout(env2, actions)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            rollout(env2, actions)
+        torch.cuda.synchronize()
+        eager_value = 5 * n * H / (time.perf_counter() - t0)
+        del env2
 
     if rank == 0:
         t_bwd = time_backward_kernel(env, a.env, n, H, 50, device)
@@ -154,7 +201,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %d envs/GPU x H=%d through DFlexEnv.step, loss=-sum(rew), 1 backward"
                                    % (a.env, n, H), "envs_per_gpu": n, "horizon": H, "substeps": env.sim_substeps,
-                       "mm_freq": MM_FREQ[a.env], "sharding": "envs by index, no collective"},
+                       "mm_freq": MM_FREQ[a.env], "sharding": "envs by index, no collective", "submission": submission},
+            "eager_env_steps_per_s": eager_value,
             "roofline": {"bound": "hbm", "kernel": "dsim_env_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": t_bwd * 1e3, "alg_bytes_per_launch": bwd_bytes,

@@ -155,7 +155,7 @@ class DFlexEnv:
         reset_pool_size times within one rollout."""
         from ..engine import EpisodeIO
         stochastic = bool(getattr(self, "stochastic_init", False))
-        if getattr(self, "_pool", None) is None or (stochastic and self._pool_stale):
+        if getattr(self, "_pool", None) is None or (stochastic and self._pool_stale and not getattr(self, "_pool_frozen", False)):
             self._pool = self._draw_start_states(self.reset_pool_size if stochastic else 1)
             self._pool_stale = False
             if getattr(self, "_reset_count", None) is None:
@@ -164,6 +164,15 @@ class DFlexEnv:
             self.progress_buf = self.progress_buf.contiguous()
         return EpisodeIO(self.progress_buf, self._pool[0], self._pool[1], self._reset_count, self.episode_length,
                          self.height_terminate, self.check_invalid, want_obs_before=not self.no_grad)
+
+    def redraw_start_states(self):
+        """new random start states into the EXISTING pool tensors (graph replays keep their addresses, diffrl_amd/graph.py)"""
+        if getattr(self, "_pool", None) is None:
+            self._episode_io()
+        elif getattr(self, "stochastic_init", False):
+            q, qd = self._draw_start_states(self._pool[0].shape[0])
+            self._pool[0].copy_(q)
+            self._pool[1].copy_(qd)
 
     def _step_fused(self, actions, spec):
         actions = actions.view((self.num_envs, self.num_actions))

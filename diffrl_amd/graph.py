@@ -1,0 +1,98 @@
+"""Whole-trajectory submission: H x (policy -> env.step) plus the backward sweep captured
+once as a HIP graph and replayed as ONE submission per rollout.
+
+The reference drives the same loop from Python, one kernel launch at a time (algorithms/shac.py:184-251: actor MLP,
+env.step, reward bookkeeping per step, then loss.backward()).  With the simulation fused into one launch per env.step and
+the episode bookkeeping done in-kernel, nothing in `DFlexEnv.step` synchronises with the host any more, so the whole
+rollout -- including whatever torch modules the caller puts in the loop -- is capturable: the launches made through the
+C ABI go to torch's current stream, which is the capturing stream during `torch.cuda.graph`.
+
+    roll = GraphedRollout(env, body)      # body(env) -> scalar loss; runs H x env.step, policy in the loop
+    loss = roll.replay()                  # forward + backward, one hipGraphLaunch; .grad of the leaves is refreshed
+
+`body` must be capturable: no `.item()`, no `nonzero()`, no Python branching on device data (`done` has to be used as a
+mask, not as an index list).  The leaves whose `.grad` the caller reads (actor parameters, an action tensor) keep their
+identity; their `.grad` tensors live in the graph's memory pool and are overwritten by every replay.
+"""
+import torch
+
+
+class GraphedRollout:
+    def __init__(self, env, body, leaves=(), carry_state=True, warmup=3, backward=True):
+        """env: a fused DFlexEnv on a GPU; body(env) -> loss (0-dim tensor).
+        leaves: the tensors / parameters whose .grad the caller reads; their .grad is reset to None before the capture
+        so that every replay ASSIGNS fresh gradients (in the graph's memory pool) instead of accumulating.
+        carry_state: a replay starts where the previous one ended (as consecutive SHAC rollouts do); False: every replay
+        restarts from the state the environment had at construction (deterministic benchmark).
+        backward: also capture loss.backward()."""
+        if torch.device(env.device).type != "cuda":
+            raise RuntimeError("GraphedRollout needs a GPU environment")
+        self.env, self.body, self.carry, self.backward = env, body, carry_state, backward
+        with torch.no_grad():
+            self._q = env.state.joint_q.detach().clone()
+            self._qd = env.state.joint_qd.detach().clone()
+            self._act = env.actions.detach().clone()
+            self._progress = env.progress_buf.clone()
+        self._frames_per_replay = None
+        # The environments' reset_state() (reference-style indexed writes) is not capturable, so the pool of start states
+        # that finished environments restart from is drawn eagerly, in place, before every replay instead of inside the
+        # body's clear_grad(); the captured kernels read it from fixed addresses.
+        env.redraw_start_states()
+        env._pool_frozen = True
+        self._stochastic = bool(getattr(env, "stochastic_init", False))
+        # warm-up on a side stream (lazy initialisation, allocator pools), as torch.cuda.graph requires
+        side = torch.cuda.Stream(device=env.device)
+        side.wait_stream(torch.cuda.current_stream(env.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._run_once(write_back=False)
+        torch.cuda.current_stream(env.device).wait_stream(side)
+        torch.cuda.synchronize(env.device)
+        self.leaves = list(leaves)
+        for t in self.leaves:
+            t.grad = None
+        f0 = env.num_frames
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._run_once(write_back=carry_state)
+        self._frames_per_replay = env.num_frames - f0
+        torch.cuda.synchronize(env.device)
+
+    def _run_once(self, write_back):
+        env = self.env
+        # start from the static copies (fresh tensors: the body builds a new autograd graph on them)
+        st = type(env.state)(act_like=env.model.joint_qd)
+        st.joint_q, st.joint_qd = self._q.clone(), self._qd.clone()
+        env.state = st
+        env.actions = self._act.clone()
+        env.progress_buf = self._progress.clone()
+        loss = self.body(env)
+        if self.backward:
+            loss.backward()
+        if write_back:
+            with torch.no_grad():
+                self._q.copy_(env.state.joint_q.detach())
+                self._qd.copy_(env.state.joint_qd.detach())
+                self._act.copy_(env.actions.detach())
+                self._progress.copy_(env.progress_buf)
+        return loss.detach()
+
+    def replay(self):
+        """re-executes the captured rollout (forward + backward); returns the static loss tensor"""
+        if self._stochastic:
+            self.env.redraw_start_states()
+        self.graph.replay()
+        if self._frames_per_replay:
+            self.env.num_frames += self._frames_per_replay
+            self.env.sim_time += self._frames_per_replay * self.env.sim_dt
+        return self.loss
+
+    def sync_env(self):
+        """after replays with carry_state: point the environment object at the carried state (for eager use afterwards)"""
+        env = self.env
+        with torch.no_grad():
+            st = type(env.state)(act_like=env.model.joint_qd)
+            st.joint_q, st.joint_qd = self._q.clone(), self._qd.clone()
+            env.state = st
+            env.actions = self._act.clone()
+            env.progress_buf = self._progress.clone()
