@@ -99,7 +99,7 @@ def main():
 
     from diffrl_amd import sharding
     rank, local, world = sharding.world()
-    dist = world > 1
+    dist = world > 1 or "RANK" in os.environ   # launched by torch.distributed.run: RCCL process group even for one rank
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     if dist:

@@ -53,7 +53,8 @@ class GraphedRollout:
             t.grad = None
         f0 = env.num_frames
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread-local capture mode: other threads (e.g. the RCCL watchdog of a torch.distributed job) may keep making HIP calls
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = self._run_once(write_back=carry_state)
         self._frames_per_replay = env.num_frames - f0
         torch.cuda.synchronize(env.device)
