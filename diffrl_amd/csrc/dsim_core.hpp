@@ -522,7 +522,26 @@ DSIM_FN void dsim_sim_step_forward(const Ctx& c, Exec& ex, int substeps, int mm_
 // Postconditions: aq/aqd = cotangents of the substep inputs; aact/amact/aH accumulated.
 
 // integrate^T, solve^T (matnn.h:310-336), tau^T
-template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c, Exec& ex) {
+// Cotangent of the mass matrix, accumulated over the substeps of one mass-matrix group.  In the specialised kernels
+// every lane keeps its nd*nd/64 entries in REGISTERS across the group's substeps (lane-private accumulation: entry
+// `lane + 64 m` never leaves its lane) and writes them to LDS once, at the refresh substep, for the mass-matrix adjoint.
+// The LDS read-modify-write it replaces was a chain of dependent round trips in every substep.
+#define DSIM_HACC_MAX 12
+template <class Ctx> struct DsimHaccRegs {
+    static constexpr bool value = DsimIsStatic<Ctx>::value;
+};
+template <class Ctx, class Exec> DSIM_FN void dsim_hacc_zero(const Ctx& c, Exec& ex, int lane) {
+    if constexpr (DsimIsStatic<Ctx>::value) {
+        constexpr int NN = decltype(c.d)::nd * decltype(c.d)::nd, ACC = (NN + DSIM_NL - 1) / DSIM_NL;
+        if constexpr (ACC <= DSIM_HACC_MAX) {
+            float* acc = ex.hacc(lane);
+#pragma unroll
+            for (int m = 0; m < ACC; ++m) acc[m] = 0.f;
+        }
+    }
+}
+
+template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c, Exec& ex, bool update_mass) {
     ex.mark(7);
     const int nd = c.d.nd;
     ex.run([&](int lane) {
@@ -575,9 +594,28 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
         }
     });
     ex.run([&](int lane) {
-        for (int it = lane; it < nd * nd; it += DSIM_NL) {
-            const int i = it / nd, j = it - nd * i;
-            WF(aH)[it] -= WF(atau)[i] * WF(qdd)[j];
+        bool in_regs = false;
+        if constexpr (DsimIsStatic<Ctx>::value) {
+            constexpr int NN = decltype(c.d)::nd * decltype(c.d)::nd, ACC = (NN + DSIM_NL - 1) / DSIM_NL;
+            if constexpr (ACC <= DSIM_HACC_MAX) {
+                in_regs = true;
+                float* acc = ex.hacc(lane);
+#pragma unroll
+                for (int m = 0; m < ACC; ++m) {
+                    const int it = lane + DSIM_NL * m;
+                    if (it < NN) {
+                        const int i = it / decltype(c.d)::nd, j = it - decltype(c.d)::nd * i;
+                        acc[m] -= WF(atau)[i] * WF(qdd)[j];
+                        if (update_mass) WF(aH)[it] = acc[m];
+                    }
+                }
+            }
+        }
+        if (!in_regs) {
+            for (int it = lane; it < nd * nd; it += DSIM_NL) {
+                const int i = it / nd, j = it - nd * i;
+                WF(aH)[it] -= WF(atau)[i] * WF(qdd)[j];
+            }
         }
         for (int d = lane; d < nd; d += DSIM_NL) {
             const int i = CI(dof_link)[d], type = CI(jtype)[i];
@@ -1004,7 +1042,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
 }
 
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_substep(const Ctx& c, Exec& ex, bool update_mass) {
-    dsim_bwd_joint_space(c, ex);
+    dsim_bwd_joint_space(c, ex, update_mass);
     if (update_mass) dsim_bwd_mass(c, ex);
     dsim_bwd_bodies(c, ex, update_mass);
 }
@@ -1040,11 +1078,13 @@ DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
             if (s == substeps - 1) ex.prefetch(g_ckpt + (size_t)s * c.o.save_words, c.o.save_words);
             ex.run([&](int lane) {
                 ex.commit(WF(q), c.o.save_words, lane);
-                if (hv)
+                if (hv) {
                     for (int k = lane; k < nd * nd; k += DSIM_NL) {
                         WF(hinv)[k] = hv[k];
                         WF(aH)[k] = 0.f;
                     }
+                    dsim_hacc_zero(c, ex, lane);
+                }
             });
             if (s > 0) ex.prefetch(g_ckpt + (size_t)(s - 1) * c.o.save_words, c.o.save_words);
             if (s == s0) dsim_fwd_composite(c, ex);
@@ -1481,11 +1521,13 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
             if (s == substeps - 1) ex.prefetch(g_ckpt + (size_t)s * c.o.save_words, c.o.save_words);
             ex.run([&](int lane) {
                 ex.commit(WF(q), c.o.save_words, lane);
-                if (hv)
+                if (hv) {
                     for (int k = lane; k < nd * nd; k += DSIM_NL) {
                         WF(hinv)[k] = hv[k];
                         WF(aH)[k] = 0.f;
                     }
+                    dsim_hacc_zero(c, ex, lane);
+                }
             });
             if (s > 0) ex.prefetch(g_ckpt + (size_t)(s - 1) * c.o.save_words, c.o.save_words);
             if (s == s0) dsim_fwd_composite(c, ex);

@@ -44,6 +44,9 @@ struct DevExec {
     // phase that only writes global memory nobody in this launch reads back: no barrier, no vmcnt wait
     template <class F> __device__ __forceinline__ void fire(F&& f) { f((int)threadIdx.x); }
     __device__ __forceinline__ void mark(int) {}
+    // lane-private accumulators of the mass-matrix cotangent (dsim_core.hpp: DSIM_HACC_MAX registers per lane)
+    float hacc_[DSIM_HACC_MAX];
+    __device__ __forceinline__ float* hacc(int) { return hacc_; }
     // software prefetch of one checkpoint row: global loads are issued here and stay in flight (registers) until
     // commit() stores them to LDS one adjoint substep later; rows longer than 64*DSIM_PF lanes*regs are read at commit
     float pf[DSIM_PF];
@@ -203,6 +206,8 @@ struct TimingExec {
         ++idx;
     }
     template <class F> __device__ __forceinline__ void fire(F&& f) { f((int)threadIdx.x); }
+    float hacc_[DSIM_HACC_MAX];
+    __device__ __forceinline__ float* hacc(int) { return hacc_; }
     const float* pf_src;
     __device__ __forceinline__ void prefetch(const float* row, int) { pf_src = row; }
     __device__ __forceinline__ void commit(float* dst, int words, int lane) {

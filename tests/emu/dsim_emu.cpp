@@ -17,6 +17,8 @@ struct HostExec {
     }
     template <class F> void fire(F&& f) { run(f); }
     void mark(int) {}
+    float hacc_[DSIM_NL][DSIM_HACC_MAX];  // what a lane keeps in registers across phases on the GPU
+    float* hacc(int lane) { return hacc_[lane]; }
     const float* pf_src = nullptr;
     void prefetch(const float* row, int) { pf_src = row; }
     void commit(float* dst, int words, int lane) {
