@@ -5,6 +5,10 @@ actions, loss = -sum(reward), one backward through all H steps (what algorithms/
 shac.py:411 do, minus the actor network).  N GPUs = N processes (torch.distributed.run), each with its own
 shard of environments; no collective touches the data path (the all_reduce below only combines timings).
 
+The timed submission is a HIP-graph replay of that rollout (captured once through DFlexEnv.step with
+diffrl_amd/graph.py, checked bit for bit against the eager loop; every replay re-executes all launches); the same
+rollouts driven step by step from Python are reported as `eager_env_steps_per_s` (`--eager` times those instead).
+
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the adjoint kernel), `cpu_baseline`
 times the scalar CPU oracle on a bounded sample of the same workload on the box's host cores.
 """
@@ -36,7 +40,7 @@ def make_env(name, n, device):
     return cls(**kw)
 
 
-def rollout(env, actions, kernel_events=None):
+def rollout(env, actions):
     """one SHAC-style trajectory: H x env.step on fresh environments, loss = -sum of rewards, one backward"""
     env.clear_grad()
     env.reset()
