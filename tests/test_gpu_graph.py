@@ -118,3 +118,14 @@ def test_stochastic_restarts_inside_a_graph():
     assert int(e.progress_buf.sum()) == 0          # every environment was restarted at the end of the rollout
     assert not torch.equal(q1, q2)                 # ... from a freshly drawn start state
     assert torch.isfinite(a.grad).all()
+
+
+def test_policy_learns_through_graph_replays():
+    """examples/shac_lite.py: 40 Adam steps on the actor through H=32 graph-replayed rollouts (stochastic restarts, policy in
+    the loop) raise the mean reward -- the gradients that come out of the replays are the useful ones"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import shac_lite
+    hist = shac_lite.main(["--iters", "40", "--envs", "128", "--graph", "--seed", "1"])
+    assert sum(hist[-6:]) / 6 > sum(hist[:6]) / 6 + 0.15
