@@ -211,6 +211,9 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": t_bwd * 1e3, "alg_bytes_per_launch": bwd_bytes,
                          "note": "fused kernel is VALU/latency-bound by construction (SURVEY 8d); see DESIGN.md"},
+            # fp32 vector-ALU view of the same launch pair (SURVEY 8d asks for it next to the HBM fraction): ~1.2 MFLOP per
+            # Ant env-step fwd+adjoint (SURVEY's op-count estimate) against the 157.3 TFLOP/s fp32 vector peak
+            "fp32_valu_frac_est": (1.2e6 * n / (t_bwd * (1.0 + 0.105 / 0.160))) / 157.3e12 if a.env == "ant" else None,
         }
         # forward-only serving path (dflex.config.no_grad: no checkpoint traffic), SURVEY.md 8(f).4 -- informational
         with torch.no_grad():
