@@ -138,7 +138,7 @@ DSIM_FN float dsim_dot_n(const float* a, const float* b, int n) {
 // forward
 // ================================================================================================
 
-// FK + motion subspace + velocities + world inertia + body force, level by level.
+// FK + motion subspace + velocities + world inertia + body force (one lane per link, see dsim_fwd_kinematics).
 // constant parts of the work arrays (written once per launch): the motion subspace of a free joint is the identity
 template <class Ctx, class Exec> DSIM_FN void dsim_init_static(const Ctx& c, Exec& ex) {
     ex.run([&](int lane) {
