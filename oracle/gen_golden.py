@@ -13,6 +13,13 @@ path, so parity is pinned by these files instead:
                      intermediate tensor of the first substep
   <env>_rollout.npz  DFlexEnv level: H env.step() calls + backward of
                      -sum(rew) w.r.t. the actions (envs/<env>.py)
+  ant_rollout_h32.npz  the same at BASELINE.json's horizon (H = 32, 8 envs)
+  ant_episode.npz    H = 24 steps WITH the reference's episode handling active:
+                     early termination on, episode_length = 10, so every env is
+                     reset (envs/ant.py:176-234) at least twice inside the
+                     rollout; records done / obs_before_reset per step and the
+                     gradient of a loss that also reads obs_before_reset
+                     (`python oracle/gen_golden.py ant_extra`)
 
 Usage:  python oracle/gen_golden.py [ant humanoid snu cartpole hopper cheetah]
 """
@@ -215,10 +222,54 @@ def rollout_golden(df, envs, name):
                 loss=np.float64(loss.item()))
 
 
+def ant_extra_goldens(df, envs):
+    """H = 32 rollout, and a rollout through the reference's own reset logic (see module docstring)"""
+    out = {}
+    # (a) BASELINE horizon
+    n, H = 8, 32
+    CONFIGS["ant"] = ("AntEnv", 16, n, H, True)
+    out["ant_rollout_h32"] = rollout_golden(df, envs, "ant")
+    CONFIGS["ant"] = ("AntEnv", 16, 4, 6, True)
+    # (b) episode handling
+    n, H, L = 8, 24, 10
+    torch.manual_seed(0)
+    np.random.seed(0)
+    env = envs.AntEnv(num_envs=n, device="cpu", render=False, seed=0, episode_length=L, no_grad=False,
+                      stochastic_init=False, MM_caching_frequency=16, early_termination=True)
+    env.clear_grad()
+    env.reset()
+    env.progress_buf[: n // 2] = 3          # half of the environments finish three steps earlier
+    g = torch.Generator().manual_seed(11)
+    q0, qd0 = env.get_state()
+    prog0 = t2n(env.progress_buf)
+    obs0 = env.initialize_trajectory()
+    acts = torch.tanh(3.0 * (2.0 * torch.rand((H, n, env.num_actions), generator=g) - 1.0)).clone().requires_grad_(True)
+    w = torch.randn((n, env.num_obs), generator=g)
+    rec = dict(obs=[], rew=[], done=[], obs_before=[], progress=[])
+    loss = 0.0
+    for t in range(H):
+        obs, rew, done, info = env.step(acts[t])
+        loss = loss - rew.sum() + 0.01 * (w * info["obs_before_reset"]).sum() + 0.01 * (w * obs).sum()
+        rec["obs"].append(t2n(obs)); rec["rew"].append(t2n(rew)); rec["done"].append(t2n(done))
+        rec["obs_before"].append(t2n(info["obs_before_reset"])); rec["progress"].append(t2n(env.progress_buf))
+    loss.backward()
+    assert sum(int(d.sum()) for d in rec["done"]) >= 2 * n
+    out["ant_episode"] = dict(q0=t2n(q0).reshape(n, -1), qd0=t2n(qd0).reshape(n, -1), progress0=prog0, obs0=t2n(obs0),
+                              actions=t2n(acts), w=t2n(w), grad_actions=t2n(acts.grad), loss=np.float64(loss.item()),
+                              episode_length=L, mm_freq=16, q_final=t2n(env.state.joint_q).reshape(n, -1),
+                              **{k: np.stack(v) for k, v in rec.items()})
+    return out
+
+
 def main():
     names = sys.argv[1:] or ["cartpole", "ant", "humanoid", "snu"]
     df, envs = ref_harness.load_reference()
     os.makedirs(OUT, exist_ok=True)
+    if "ant_extra" in names:
+        names.remove("ant_extra")
+        for k, v in ant_extra_goldens(df, envs).items():
+            np.savez_compressed(os.path.join(OUT, k + ".npz"), **v)
+            print("golden written:", k)
     for name in names:
         cls, mmf, n, H, _ = CONFIGS[name]
         env = make_env(envs, name, 2, no_grad=True, stochastic=False)

@@ -1,0 +1,128 @@
+"""Rollouts recorded from the REAL reference at BASELINE.json's horizon (H = 32) and through the reference's own episode
+handling (early termination + episode_length resets inside the rollout, envs/ant.py:176-234), against
+  * the fused step + in-kernel episode bookkeeping, executed lane-serially on the host (CPU),
+  * the HIP kernels behind DFlexEnv.step (GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle_lib import golden, relerr, template_from_golden
+
+DT, S, MM = 1.0 / 60.0, 16, 16
+
+
+def _emu_episode_rollout(g):
+    from emu_lib import emu_env_backward, emu_env_forward, env_spec_for, make_episode
+    t = template_from_golden("ant")
+    spec, keep = env_spec_for("ant", t)
+    H, n = g["actions"].shape[:2]
+    q, qd = g["q0"].copy(), g["qd0"].copy()
+    pool_q, pool_qd = g["q0"][None].copy(), np.zeros_like(g["qd0"])[None]   # deterministic reset: back to the start state
+    prog, cnt = g["progress0"].astype(np.int64).copy(), np.zeros(n, np.int32)
+    tape, rec = [], dict(obs=[], rew=[], done=[], obs_before=[], progress=[])
+    for s in range(H):
+        done, ob = np.zeros(n, np.int64), np.zeros((n, spec.n_obs), np.float32)
+        ep = make_episode(prog, done, ob, pool_q, pool_qd, cnt, int(g["episode_length"]), True, False)
+        q, qd, obs, rew, ck = emu_env_forward(t, spec, q, qd, g["actions"][s], DT, S, MM, episode=ep)
+        tape.append(ck)
+        for k, v in (("obs", obs), ("rew", rew), ("done", done), ("obs_before", ob), ("progress", prog)):
+            rec[k].append(v.copy())
+    gq, gqd = np.zeros_like(q), np.zeros_like(qd)
+    ga = np.zeros_like(g["actions"])
+    w = (0.01 * g["w"]).astype(np.float32)
+    for s in reversed(range(H)):
+        gq, gqd, ga[s] = emu_env_backward(t, spec, tape[s], g["actions"][s], DT, S, MM, gq, gqd, w,
+                                          -np.ones(n, np.float32), w)
+    return {k: np.stack(v) for k, v in rec.items()}, ga, q
+
+
+def _check_episode(rec, ga, q_final, g):
+    np.testing.assert_array_equal(rec["done"], g["done"])
+    np.testing.assert_array_equal(rec["progress"], g["progress"])
+    assert g["done"].sum() >= 2 * g["done"].shape[1]
+    for k in ("obs", "obs_before"):
+        assert relerr(rec[k], g[k]) < 1e-3, k
+    assert np.abs(rec["rew"] - g["rew"]).max() < 1e-3 * max(1.0, np.abs(g["rew"]).max())
+    assert relerr(q_final, g["q_final"]) < 1e-3
+    a, r = ga.astype(np.float64), g["grad_actions"].astype(np.float64)
+    assert (a * r).sum() / (np.linalg.norm(a) * np.linalg.norm(r)) > 0.9999
+    assert relerr(a, r) < 2e-3
+
+
+def test_emu_episode_rollout_vs_reference():
+    g = golden("ant_episode")
+    rec, ga, q = _emu_episode_rollout(g)
+    _check_episode(rec, ga, q, g)
+
+
+def test_emu_h32_rollout_vs_reference():
+    from emu_lib import emu_env_backward, emu_env_forward, env_spec_for
+    g = golden("ant_rollout_h32")
+    t = template_from_golden("ant")
+    spec, keep = env_spec_for("ant", t)
+    H, n = g["actions"].shape[:2]
+    assert H == 32
+    q, qd, tape = g["q0"], g["qd0"], []
+    for s in range(H):
+        q, qd, obs, rew, ck = emu_env_forward(t, spec, q, qd, g["actions"][s], DT, S, MM)
+        assert relerr(obs, g["obs"][s]) < 1e-3, s
+        tape.append(ck)
+    gq, gqd, ga = np.zeros_like(q), np.zeros_like(qd), np.zeros_like(g["actions"])
+    for s in reversed(range(H)):
+        gq, gqd, ga[s] = emu_env_backward(t, spec, tape[s], g["actions"][s], DT, S, MM, gq, gqd, None,
+                                          -np.ones(n, np.float32))
+    a, r = ga.astype(np.float64), g["grad_actions"].astype(np.float64)
+    assert (a * r).sum() / (np.linalg.norm(a) * np.linalg.norm(r)) > 0.9999
+    assert relerr(a, r) < 1e-3          # BASELINE.md tolerance for an H = 32 trajectory
+    assert relerr(q, g["q_final"]) < 1e-3
+
+
+@pytest.mark.gpu
+def test_gpu_episode_rollout_vs_reference():
+    from diffrl_amd import envs
+    g = golden("ant_episode")
+    H, n = g["actions"].shape[:2]
+    dev = torch.device("cuda:0")
+    e = envs.AntEnv(num_envs=n, device="cuda:0", no_grad=False, stochastic_init=False, MM_caching_frequency=16,
+                    early_termination=True, episode_length=int(g["episode_length"]))
+    e.reset()
+    assert relerr(e.state.joint_q.view(n, -1).cpu().numpy(), g["q0"]) < 1e-6
+    e.progress_buf[:] = torch.tensor(g["progress0"], device=dev)
+    e.initialize_trajectory()
+    acts = torch.tensor(g["actions"], device=dev, requires_grad=True)
+    w = torch.tensor(g["w"], device=dev)
+    rec = dict(obs=[], rew=[], done=[], obs_before=[], progress=[])
+    loss = 0.0
+    for t in range(H):
+        obs, rew, done, info = e.step(acts[t])
+        loss = loss - rew.sum() + 0.01 * (w * info["obs_before_reset"]).sum() + 0.01 * (w * obs).sum()
+        for k, v in (("obs", obs), ("rew", rew), ("done", done), ("obs_before", info["obs_before_reset"]),
+                     ("progress", e.progress_buf)):
+            rec[k].append(v.detach().cpu().numpy().copy())
+    loss.backward()
+    _check_episode({k: np.stack(v) for k, v in rec.items()}, acts.grad.cpu().numpy(),
+                   e.state.joint_q.detach().view(n, -1).cpu().numpy(), g)
+
+
+@pytest.mark.gpu
+def test_gpu_h32_rollout_vs_reference():
+    from diffrl_amd import envs
+    g = golden("ant_rollout_h32")
+    H, n = g["actions"].shape[:2]
+    dev = torch.device("cuda:0")
+    e = envs.AntEnv(num_envs=n, device="cuda:0", no_grad=False, stochastic_init=False, MM_caching_frequency=16,
+                    early_termination=False, episode_length=1000)
+    e.reset()
+    e.reset_with_state(torch.tensor(g["q0"], device=dev).reshape(-1), torch.tensor(g["qd0"], device=dev).reshape(-1))
+    e.initialize_trajectory()
+    acts = torch.tensor(g["actions"], device=dev, requires_grad=True)
+    loss = 0.0
+    for t in range(H):
+        obs, rew, done, info = e.step(acts[t])
+        assert relerr(obs.detach().cpu().numpy(), g["obs"][t]) < 1e-3, t
+        loss = loss - rew.sum()
+    loss.backward()
+    a, r = acts.grad.cpu().numpy().astype(np.float64), g["grad_actions"].astype(np.float64)
+    assert (a * r).sum() / (np.linalg.norm(a) * np.linalg.norm(r)) > 0.9999
+    assert relerr(a, r) < 1e-3
+    assert relerr(e.state.joint_q.detach().view(n, -1).cpu().numpy(), g["q_final"]) < 1e-3
