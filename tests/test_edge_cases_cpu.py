@@ -127,3 +127,72 @@ def test_degenerate_inputs_stay_finite():
         assert np.isfinite(a).all()
     assert relerr(qo, o["q_out"]) < 2e-5
     assert relerr(r["gact"], o["gact"]) < 1e-3
+
+
+def _random_tree(seed, floating):
+    """random articulation: branching tree numbered breadth-first (NOT pre-order, so subtrees / contact sets are not
+    contiguous ranges and the CSR-list code paths run), mixed revolute / prismatic / ball joints, rotated joint frames,
+    spheres / capsules / boxes with ground contacts"""
+    rng = np.random.default_rng(seed)
+    L = int(rng.integers(6, 10))
+    b = df.sim.ModelBuilder()
+    b.add_articulation()
+    parents = [-1] + [int(rng.integers(0, max(1, (i + 1) // 2))) for i in range(1, L)]   # breadth-first-ish: small parent ids
+    for i in range(L):
+        if i == 0:
+            kind = df.JOINT_FREE if floating else df.JOINT_REVOLUTE
+        else:
+            kind = [df.JOINT_REVOLUTE, df.JOINT_PRISMATIC, df.JOINT_BALL, df.JOINT_REVOLUTE][int(rng.integers(0, 4))]
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        rot = rng.normal(size=4)
+        rot /= np.linalg.norm(rot)
+        pos = (0.0, 0.0, 0.0) if i == 0 else tuple(rng.uniform(-0.3, 0.3, 3))
+        link = b.add_link(parents[i], df.transform(pos, tuple(rot)), tuple(axis), kind, stiffness=float(rng.uniform(0, 2)),
+                          damping=float(rng.uniform(0.05, 0.5)), limit_lower=-0.8, limit_upper=0.8, armature=0.02)
+        shape = int(rng.integers(0, 3))
+        kw = dict(ke=1e4, kd=1e3, kf=1e3, mu=float(rng.uniform(0.3, 1.0)))
+        if shape == 0:
+            b.add_shape_sphere(link, pos=tuple(rng.uniform(-0.1, 0.1, 3)), radius=0.08, **kw)
+        elif shape == 1:
+            b.add_shape_capsule(link, pos=(0.1, 0.0, 0.0), radius=0.05, half_width=0.12, **kw)
+        else:
+            b.add_shape_box(link, pos=(0.0, 0.05, 0.0), hx=0.08, hy=0.05, hz=0.06, **kw)
+    if floating:
+        b.joint_q[0:3] = [0.0, 0.25, 0.0]
+    m = b.finalize("cpu")
+    m.ground = True
+    m.gravity = (0.0, -9.81, 0.0)
+    m.collide()
+    return m.template(), parents
+
+
+def _tree_states(t, rng, n):
+    q = np.tile(t.joint_q0, (n, 1)) + rng.normal(0, 0.15, (n, t.n_q)).astype(np.float32)
+    for i in range(t.n_links):
+        ty, cs = int(t.joint_type[i]), int(t.joint_q_start[i])
+        sl = slice(cs + 3, cs + 7) if ty == df.JOINT_FREE else (slice(cs, cs + 4) if ty == df.JOINT_BALL else None)
+        if sl is not None:
+            q[:, sl] /= np.linalg.norm(q[:, sl], axis=1, keepdims=True)
+    qd = rng.normal(0, 0.5, (n, t.n_qd)).astype(np.float32)
+    act = rng.normal(0, 1.0, (n, t.n_qd)).astype(np.float32)
+    return q.astype(np.float32), qd, act
+
+
+@pytest.mark.parametrize("seed,floating", [(0, True), (1, False), (2, True), (3, True), (4, False)])
+def test_random_trees_emulated_kernels_vs_oracle(seed, floating):
+    t, parents = _random_tree(seed, floating)
+    off, dims = layout(t)
+    if seed in (0, 2):
+        assert dims["flags"] & 1 == 0, "these trees are meant to exercise the non-contiguous (CSR list) code paths"
+    rng = np.random.default_rng(100 + seed)
+    q, qd, act = _tree_states(t, rng, 3)
+    gq, gqd = rng.normal(0, 1, q.shape).astype(np.float32), rng.normal(0, 1, qd.shape).astype(np.float32)
+    for S, mm in [(4, 2), (3, 3)]:
+        dt = S / 960.0
+        o = oracle_backward(t, q, qd, act, None, dt, S, mm, gq, gqd)
+        qo, qdo, ck = emu_forward(t, q, qd, act, None, dt, S, mm, want_ckpt=True)
+        r = emu_backward(t, ck, act, None, dt, S, mm, gq, gqd)
+        assert relerr(qo, o["q_out"]) < 5e-5 and relerr(qdo, o["qd_out"]) < 5e-4
+        assert relerr(project_tangent(t, q, r["gq"]), project_tangent(t, q, o["gq"])) < 2e-3
+        assert relerr(r["gqd"], o["gqd"]) < 2e-3 and relerr(r["gact"], o["gact"]) < 2e-3

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle_lib import golden, oracle_backward, project_tangent, relerr, template_from_golden
-from test_edge_cases_cpu import _chain
+from test_edge_cases_cpu import _chain, _random_tree, _tree_states
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -43,6 +43,25 @@ def test_generic_kernels_on_user_models(n_links, shapes, floating):
         assert relerr(qo, o["q_out"]) < 1e-4 and relerr(qdo, o["qd_out"]) < 1e-3
         assert relerr(project_tangent(t, q, g_q), project_tangent(t, q, o["gq"])) < 1e-3
         assert relerr(g_qd, o["gqd"]) < 1e-3 and relerr(g_a, o["gact"]) < 1e-3
+
+
+@pytest.mark.parametrize("seed,floating", [(0, True), (1, False), (2, True), (3, True), (4, False)])
+def test_generic_kernels_on_random_trees(seed, floating):
+    """branching trees numbered breadth-first (CSR-list code paths), revolute / prismatic / ball joints, mixed shapes"""
+    from diffrl_amd.engine import Engine
+    t, parents = _random_tree(seed, floating)
+    eng = Engine(t, DEV)
+    assert eng.variant == 0
+    rng = np.random.default_rng(100 + seed)
+    q, qd, act = _tree_states(t, rng, 17)
+    gq, gqd = rng.normal(0, 1, q.shape).astype(np.float32), rng.normal(0, 1, qd.shape).astype(np.float32)
+    for S, mm in [(4, 2), (3, 3)]:
+        dt = S / 960.0
+        o = oracle_backward(t, q, qd, act, None, dt, S, mm, gq, gqd)
+        qo, qdo, g_q, g_qd, g_a = _run(eng, t, q, qd, act, dt, S, mm, gq, gqd)
+        assert relerr(qo, o["q_out"]) < 1e-4 and relerr(qdo, o["qd_out"]) < 1e-3
+        assert relerr(project_tangent(t, q, g_q), project_tangent(t, q, o["gq"])) < 2e-3
+        assert relerr(g_qd, o["gqd"]) < 2e-3 and relerr(g_a, o["gact"]) < 2e-3
 
 
 @pytest.mark.parametrize("n", [1, 3, 100003])
