@@ -129,7 +129,7 @@ def test_degenerate_inputs_stay_finite():
     assert relerr(r["gact"], o["gact"]) < 1e-3
 
 
-def _random_tree(seed, floating):
+def _random_tree(seed, floating, muscles=0):
     """random articulation: branching tree numbered breadth-first (NOT pre-order, so subtrees / contact sets are not
     contiguous ranges and the CSR-list code paths run), mixed revolute / prismatic / ball joints, rotated joint frames,
     spheres / capsules / boxes with ground contacts"""
@@ -158,6 +158,11 @@ def _random_tree(seed, floating):
             b.add_shape_capsule(link, pos=(0.1, 0.0, 0.0), radius=0.05, half_width=0.12, **kw)
         else:
             b.add_shape_box(link, pos=(0.0, 0.05, 0.0), hx=0.08, hy=0.05, hz=0.06, **kw)
+    for _ in range(muscles):
+        # way-points on random links, consecutive ones sometimes on the SAME link (such segments exert no force)
+        k = int(rng.integers(3, 6))
+        links = [int(x) for x in rng.integers(0, L, k)]
+        b.add_muscle(links, [tuple(rng.uniform(-0.1, 0.1, 3)) for _ in range(k)], 1.0, 0.1, 0.1, 0.2, 0.0)
     if floating:
         b.joint_q[0:3] = [0.0, 0.25, 0.0]
     m = b.finalize("cpu")
@@ -196,3 +201,23 @@ def test_random_trees_emulated_kernels_vs_oracle(seed, floating):
         assert relerr(qo, o["q_out"]) < 5e-5 and relerr(qdo, o["qd_out"]) < 5e-4
         assert relerr(project_tangent(t, q, r["gq"]), project_tangent(t, q, o["gq"])) < 2e-3
         assert relerr(r["gqd"], o["gqd"]) < 2e-3 and relerr(r["gact"], o["gact"]) < 2e-3
+
+
+@pytest.mark.parametrize("seed,floating", [(5, True), (6, False)])
+def test_random_trees_with_muscles(seed, floating):
+    """line-of-action muscles (eval_muscles, sim.py:1209-1265) routed over random links of a breadth-first-numbered tree"""
+    t, parents = _random_tree(seed, floating, muscles=4)
+    assert t.n_muscles == 4
+    rng = np.random.default_rng(200 + seed)
+    q, qd, act = _tree_states(t, rng, 3)
+    mact = rng.uniform(0.0, 30.0, (3, t.n_muscles)).astype(np.float32)
+    gq, gqd = rng.normal(0, 1, q.shape).astype(np.float32), rng.normal(0, 1, qd.shape).astype(np.float32)
+    S, mm = 4, 2
+    dt = S / 960.0
+    o = oracle_backward(t, q, qd, act, mact, dt, S, mm, gq, gqd)
+    qo, qdo, ck = emu_forward(t, q, qd, act, mact, dt, S, mm, want_ckpt=True)
+    r = emu_backward(t, ck, act, mact, dt, S, mm, gq, gqd)
+    assert relerr(qo, o["q_out"]) < 5e-5 and relerr(qdo, o["qd_out"]) < 5e-4
+    assert relerr(project_tangent(t, q, r["gq"]), project_tangent(t, q, o["gq"])) < 2e-3
+    assert relerr(r["gqd"], o["gqd"]) < 2e-3 and relerr(r["gact"], o["gact"]) < 2e-3
+    assert np.abs(o["gmact"]).max() > 0 and relerr(r["gmact"], o["gmact"]) < 2e-3

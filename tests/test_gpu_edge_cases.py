@@ -64,6 +64,31 @@ def test_generic_kernels_on_random_trees(seed, floating):
         assert relerr(g_qd, o["gqd"]) < 2e-3 and relerr(g_a, o["gact"]) < 2e-3
 
 
+@pytest.mark.parametrize("seed,floating", [(5, True), (6, False)])
+def test_generic_kernels_on_random_trees_with_muscles(seed, floating):
+    from diffrl_amd.engine import Engine
+    t, parents = _random_tree(seed, floating, muscles=4)
+    eng = Engine(t, DEV)
+    dev = torch.device(DEV)
+    rng = np.random.default_rng(200 + seed)
+    n = 9
+    q, qd, act = _tree_states(t, rng, n)
+    mact = rng.uniform(0.0, 30.0, (n, t.n_muscles)).astype(np.float32)
+    gq, gqd = rng.normal(0, 1, q.shape).astype(np.float32), rng.normal(0, 1, qd.shape).astype(np.float32)
+    S, mm = 4, 2
+    dt = S / 960.0
+    o = oracle_backward(t, q, qd, act, mact, dt, S, mm, gq, gqd)
+    T = lambda a: torch.tensor(a, device=dev).reshape(-1)  # noqa: E731
+    qo, qdo, ck = eng.forward(T(q), T(qd), T(act), T(mact), dt, S, mm, True)
+    r = eng.backward(ck, T(act), T(mact), dt, S, mm, T(gq), T(gqd))
+    torch.cuda.synchronize()
+    N = lambda x: x.cpu().numpy().reshape(n, -1)  # noqa: E731
+    assert relerr(N(qo), o["q_out"]) < 1e-4 and relerr(N(qdo), o["qd_out"]) < 1e-3
+    assert relerr(project_tangent(t, q, N(r[0])), project_tangent(t, q, o["gq"])) < 2e-3
+    assert relerr(N(r[1]), o["gqd"]) < 2e-3 and relerr(N(r[2]), o["gact"]) < 2e-3
+    assert relerr(N(r[3]), o["gmact"]) < 2e-3
+
+
 @pytest.mark.parametrize("n", [1, 3, 100003])
 def test_env_count_extremes(n):
     """one env, a prime-ish count and ~1e5 envs: every env of a replicated batch gives the same answer"""
