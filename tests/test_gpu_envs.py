@@ -211,3 +211,29 @@ def test_gradients_are_useful(env, H, iters):
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0] - 1e-3, losses
+
+
+@pytest.mark.parametrize("name", ["ant", "humanoid", "snu", "hopper", "cheetah", "cartpole"])
+def test_long_stochastic_rollouts_stay_finite(name):
+    """300 steps of random actions with stochastic restarts on every environment class: finite observations and rewards,
+    episodes end and restart (in-kernel), progress counters stay inside [0, episode_length)"""
+    from diffrl_amd import envs
+    cls = {"ant": envs.AntEnv, "humanoid": envs.HumanoidEnv, "snu": envs.SNUHumanoidEnv, "hopper": envs.HopperEnv,
+           "cheetah": envs.CheetahEnv, "cartpole": envs.CartPoleSwingUpEnv}[name]
+    mm = {"ant": 16, "humanoid": 48, "snu": 8, "hopper": 16, "cheetah": 16, "cartpole": 4}[name]
+    n, L = 64, 120
+    e = cls(num_envs=n, device="cuda:0", no_grad=True, stochastic_init=True, MM_caching_frequency=mm, episode_length=L)
+    e.reset()
+    gen = torch.Generator().manual_seed(5)
+    dones = 0
+    for t in range(300):
+        a = (2.0 * torch.rand((n, e.num_actions), generator=gen) - 1.0).to("cuda:0")
+        obs, rew, done, _ = e.step(a)
+        dones += int(done.sum())
+        if t % 50 == 49:
+            e.clear_grad()          # redraws the pool of start states
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert dones >= 2 * n                              # at least the two length-based resets of every environment
+    assert int(e.progress_buf.min()) >= 0 and int(e.progress_buf.max()) < L
+    assert torch.isfinite(e.state.joint_q).all() and torch.isfinite(e.state.joint_qd).all()
