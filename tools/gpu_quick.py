@@ -8,7 +8,10 @@ from diffrl_amd.engine import Engine
 
 dev = torch.device("cuda:0")
 print(torch.cuda.get_device_name(0), "devices:", torch.cuda.device_count(), "cpus:", os.cpu_count())
-for env, N in [("ant", 1024), ("ant", 8192), ("humanoid", 1024), ("snu", 512), ("cartpole", 1024)]:
+CASES = [("ant", 1024), ("ant", 8192), ("humanoid", 1024), ("snu", 512), ("cartpole", 1024)]
+if len(sys.argv) > 2:   # python tools/gpu_quick.py ant 64,256,512,1024,2048
+    CASES = [(sys.argv[1], int(x)) for x in sys.argv[2].split(",")]
+for env, N in CASES:
     t = template_from_golden(env); g = golden(env + "_step")
     S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
     reps = N // g["q_in"].shape[0] + 1
