@@ -108,9 +108,9 @@ template <class Ctx> DSIM_FN DsimLinkInfo dsim_link_info(const Ctx& c, int i) {
     return DsimLinkInfo{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 }
 // subtree sum of a per-link array: contiguous range when the model is numbered in pre-order, CSR list otherwise
-template <class Ctx> DSIM_FN float dsim_subtree_sum(const Ctx& c, const float* data, int stride, int comp, int i) {
+template <class Ctx> DSIM_FN float dsim_subtree_sum(const Ctx& c, const float* data, int stride, int comp, int i, int n_known = -1) {
     if (c.d.flags & DSIM_F_RANGES) {
-        const int n = reinterpret_cast<const dsim_int_a*>(c.s)[c.o.linfo + 8 * i + 5];
+        const int n = n_known >= 0 ? n_known : reinterpret_cast<const dsim_int_a*>(c.s)[c.o.linfo + 8 * i + 5];
         if constexpr (DsimIsStatic<Ctx>::value)
             return dsim_range_sum_b<dsim_cap_links<decltype(c.d)>()>(data, stride, comp, i, n, 0.f);
         else
@@ -151,6 +151,109 @@ template <class Ctx, class Exec> DSIM_FN void dsim_init_static(const Ctx& c, Exe
     });
 }
 
+// Chain records of the flat forward kinematics kept in REGISTERS (specialised kernels, trees of depth <= DSIM_CHAIN_MAX):
+// the ancestors of a lane's link never change, so (link, type, q start, qd start) of every chain position is read from the
+// LDS tables once per launch (dsim_topo_init) instead of as an index -> record -> data chain of three dependent LDS round
+// trips per position in every substep.
+#define DSIM_CHAIN_MAX 10
+// Per-lane topology records kept in REGISTERS by the specialised kernels (the executor owns one per lane).  A lane plays
+// the same roles in every substep -- link `lane`, dof `lane`, contact `lane` (forward) or `63 - lane` (adjoint) -- and the
+// index records of those roles never change, so they are read from the LDS tables once per launch (dsim_topo_init)
+// instead of being the first of two or three DEPENDENT LDS round trips of a phase in every substep.  Fields a kernel
+// does not use cost nothing (dead registers).
+struct DsimTopoRegs {
+    int chain[4 * DSIM_CHAIN_MAX + 1];       // ancestors of link `lane`, root first: (link, type, q start, qd start); [last] = length
+    int own_type, own_cs, own_ds, own_nd;    // joint of link `lane`
+    int own_parent, own_level, own_ch0, own_ch1;  // its parent, tree level and child-list range
+    int dof_link, dof_type, dof_cs, dof_ds;  // joint that dof `lane` belongs to
+    int cbody_f, cbody_b;                    // body of contact `lane` / of contact `63 - lane`
+    int six_n, six_c0, six_nc;               // link `lane / 6` (the (link, component) phases): subtree size, subtree contact range
+    int adof[16], adof_n;                    // dofs of the ancestors-or-self of link `(63 - lane) / 6` (adjoint of tau)
+};
+template <class Ctx> struct DsimChainRegs {
+    static constexpr bool value = []() {
+        if constexpr (std::is_empty<decltype(Ctx::d)>::value) return decltype(Ctx::d)::D <= DSIM_CHAIN_MAX;
+        else return false;
+    }();
+};
+// (link, component) items, one per lane, with pre-order (range) numbering
+template <class Ctx> struct DsimSixRegs {
+    static constexpr bool value = []() {
+        if constexpr (std::is_empty<decltype(Ctx::d)>::value)
+            return 6 * decltype(Ctx::d)::L <= DSIM_NL && (decltype(Ctx::d)::flags & DSIM_F_RANGES) != 0;
+        else return false;
+    }();
+};
+template <class Ctx> struct DsimAdofRegs {  // ... and few enough dofs for the ancestor-dof list of an item to sit in registers
+    static constexpr bool value = []() {
+        if constexpr (std::is_empty<decltype(Ctx::d)>::value)
+            return 6 * decltype(Ctx::d)::L <= DSIM_NL && (decltype(Ctx::d)::flags & DSIM_F_RANGES) != 0 && decltype(Ctx::d)::nd <= 16;
+        else return false;
+    }();
+};
+// roles are "item index == lane": needs every loop of that role to be a single pass
+template <class Ctx> struct DsimRoleRegs {
+    static constexpr bool value = []() {
+        if constexpr (std::is_empty<decltype(Ctx::d)>::value)
+            return decltype(Ctx::d)::L <= DSIM_NL && decltype(Ctx::d)::nd <= DSIM_NL && decltype(Ctx::d)::C <= DSIM_NL;
+        else return false;
+    }();
+};
+template <class Ctx, class Exec> DSIM_FN void dsim_topo_init(const Ctx& c, Exec& ex, int lane) {
+    if constexpr (DsimChainRegs<Ctx>::value) {
+        constexpr int DEPTH = decltype(c.d)::D;
+        int* ch = ex.topo(lane).chain;
+        const int i = lane < c.d.L ? lane : 0;
+        const int e0 = CI(anc_start)[i], n = lane < c.d.L ? CI(anc_start)[i + 1] - e0 : 0;
+#pragma unroll
+        for (int p = 0; p < DEPTH; ++p) {
+            const DsimLinkInfo li = dsim_link_info(c, CI(anc_list)[e0 + (p < n ? p : 0)]);
+            ch[4 * p] = CI(anc_list)[e0 + (p < n ? p : 0)];
+            ch[4 * p + 1] = li.type;
+            ch[4 * p + 2] = li.cs;
+            ch[4 * p + 3] = li.ds;
+        }
+        ch[4 * DSIM_CHAIN_MAX] = n;
+    }
+    if constexpr (DsimRoleRegs<Ctx>::value) {
+        DsimTopoRegs& tp = ex.topo(lane);
+        const int i = lane < c.d.L ? lane : 0;
+        tp.own_type = CI(jtype)[i];
+        tp.own_cs = CI(qstart)[i];
+        tp.own_ds = CI(qdstart)[i];
+        tp.own_nd = CI(qdstart)[i + 1] - tp.own_ds;
+        const DsimLinkInfo own = dsim_link_info(c, i);
+        tp.own_parent = own.parent;
+        tp.own_level = own.level;
+        tp.own_ch0 = CI(child_start)[i];
+        tp.own_ch1 = CI(child_start)[i + 1];
+        const int d = lane < c.d.nd ? lane : 0;
+        const int l = c.d.nd > 0 ? CI(dof_link)[d] : 0;
+        tp.dof_link = l;
+        tp.dof_type = CI(jtype)[l];
+        tp.dof_cs = CI(qstart)[l];
+        tp.dof_ds = CI(qdstart)[l];
+        const int kf = lane < c.d.C ? lane : 0, kb = (DSIM_NL - 1 - lane) < c.d.C ? (DSIM_NL - 1 - lane) : 0;
+        tp.cbody_f = c.d.C > 0 ? CI(cbody)[kf] : 0;
+        tp.cbody_b = c.d.C > 0 ? CI(cbody)[kb] : 0;
+    }
+    if constexpr (DsimSixRegs<Ctx>::value) {
+        DsimTopoRegs& tp = ex.topo(lane);
+        const DsimLinkInfo li = dsim_link_info(c, lane < 6 * c.d.L ? lane / 6 : 0);
+        tp.six_n = li.nsub;
+        tp.six_c0 = li.c0;
+        tp.six_nc = li.nc;
+        if constexpr (DsimAdofRegs<Ctx>::value) {
+            const int it = DSIM_NL - 1 - lane;
+            const int j = it < 6 * c.d.L ? it / 6 : 0;
+            const int e0 = CI(adof_start)[j], cnt = CI(adof_start)[j + 1] - e0;
+            tp.adof_n = cnt;
+#pragma unroll
+            for (int u = 0; u < decltype(c.d)::nd; ++u) tp.adof[u] = CI(adof_list)[e0 + (u < cnt ? u : 0)];
+        }
+    }
+}
+
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, Exec& ex) {
     ex.mark(1);
     // "Flat" forward kinematics: every link's lane walks its own ancestor chain from the root and recomputes the
@@ -164,12 +267,8 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
             v3 psp = zero3();
             q4 rsp = mkq(0.f, 0.f, 0.f, 1.f);
             sv6 v = zerosv(), a = zerosv();
-            const int e0 = CI(anc_start)[i], e1 = CI(anc_start)[i + 1];
-            for (int e = e0; e < e1; ++e) {
-                const int j = CI(anc_list)[e];
-                const DsimLinkInfo li = dsim_link_info(c, j);
-                const int type = li.type, cs = li.cs, ds = li.ds;
-                const bool own = (e == e1 - 1);  // j == i: this lane owns the outputs of link i
+            // one chain position: link j (joint type, coordinate / dof offsets); own: j == i, this lane owns its outputs
+            auto position = [&](int j, int type, int cs, int ds, bool own) {
                 const v3 ppj = ld3(CF(xpj) + 7 * j);
                 const q4 rpj = ldq(CF(xpj) + 7 * j + 3);
                 const v3 pj = rotate(rsp, ppj) + psp;
@@ -218,6 +317,24 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
                 }
                 psp = pc;
                 rsp = rc;
+            };
+            bool walked = false;
+            if constexpr (DsimChainRegs<Ctx>::value) {
+                constexpr int DEPTH = decltype(c.d)::D;
+                const int* ch = ex.topo(lane).chain;
+                const int n = ch[4 * DSIM_CHAIN_MAX];
+#pragma unroll
+                for (int p = 0; p < DEPTH; ++p)
+                    if (p < n) position(ch[4 * p], ch[4 * p + 1], ch[4 * p + 2], ch[4 * p + 3], p == n - 1);
+                walked = true;
+            }
+            if (!walked) {
+                const int e0 = CI(anc_start)[i], e1 = CI(anc_start)[i + 1];
+                for (int e = e0; e < e1; ++e) {
+                    const int j = CI(anc_list)[e];
+                    const DsimLinkInfo li = dsim_link_info(c, j);
+                    position(j, li.type, li.cs, li.ds, e == e1 - 1);
+                }
             }
             // same lane, same phase: COM, world inertia and body force of link i from the values still in registers
             const v3 pc = psp;
@@ -258,7 +375,9 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Ex
     if (c.d.C == 0 && c.d.NS == 0) return;
     ex.run([&](int lane) {
         for (int k = lane; k < c.d.C; k += DSIM_NL) {
-            const int b = CI(cbody)[k];
+            int b;
+            if constexpr (DsimRoleRegs<Ctx>::value) b = ex.topo(lane).cbody_f;
+            else b = CI(cbody)[k];
             const v3 xp = ld3(WF(xsc) + 7 * b);
             const q4 xq = ldq(WF(xsc) + 7 * b + 3);
             const sv6 vb = ldsv(WF(v) + 6 * b);
@@ -320,7 +439,13 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_tau(const Ctx& c, Exec& e
             const int i = it / 6, k = it - 6 * i;
             float acc;
             if (c.d.flags & DSIM_F_RANGES) {
-                const DsimLinkInfo li = dsim_link_info(c, i);
+                DsimLinkInfo li;
+                if constexpr (DsimSixRegs<Ctx>::value) {
+                    const DsimTopoRegs& tp = ex.topo(lane);
+                    li.nsub = tp.six_n; li.c0 = tp.six_c0; li.nc = tp.six_nc;
+                } else {
+                    li = dsim_link_info(c, i);
+                }
                 if constexpr (DsimIsStatic<Ctx>::value) {
                     acc = dsim_range_sum_b<dsim_cap_links<decltype(c.d)>()>(WF(f), 6, k, i, li.nsub, 0.f);
                     acc = dsim_range_sum_b<dsim_cap_subtree_contacts<decltype(c.d)>()>(WF(cw), 6, k, li.c0, li.nc, acc);
@@ -337,8 +462,13 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_tau(const Ctx& c, Exec& e
     });
     ex.run([&](int lane) {
         for (int d = lane; d < c.d.nd; d += DSIM_NL) {
-            const int i = CI(dof_link)[d], type = CI(jtype)[i];
-            const int cs = CI(qstart)[i], ds = CI(qdstart)[i];
+            int i, type, cs, ds;
+            if constexpr (DsimRoleRegs<Ctx>::value) {
+                const DsimTopoRegs& tp = ex.topo(lane);
+                i = tp.dof_link; type = tp.dof_type; cs = tp.dof_cs; ds = tp.dof_ds;
+            } else {
+                i = CI(dof_link)[d]; type = CI(jtype)[i]; cs = CI(qstart)[i]; ds = CI(qdstart)[i];
+            }
             float t = 0.0f - sdot(ldsv(WF(S) + 6 * d), ldsv(WF(ftot) + 6 * i));
             if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
                 const float q = WF(q)[cs], qd = WF(qd)[d];
@@ -423,7 +553,13 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_integrate(const Ctx& c, E
     ex.run([&](int lane) {
         const float h = c.h;
         for (int i = lane; i < c.d.L; i += DSIM_NL) {
-            const int type = CI(jtype)[i], cs = CI(qstart)[i], ds = CI(qdstart)[i];
+            int type, cs, ds;
+            if constexpr (DsimRoleRegs<Ctx>::value) {
+                const DsimTopoRegs& tp = ex.topo(lane);
+                type = tp.own_type; cs = tp.own_cs; ds = tp.own_ds;
+            } else {
+                type = CI(jtype)[i]; cs = CI(qstart)[i]; ds = CI(qdstart)[i];
+            }
             float *q = WF(q), *qd = WF(qd);
             const float* qdd = WF(qdd);
             if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
@@ -496,6 +632,7 @@ DSIM_FN void dsim_sim_step_forward(const Ctx& c, Exec& ex, int substeps, int mm_
     const int nq = c.d.nq, nd = c.d.nd, M = c.d.M;
     dsim_init_static(c, ex);
     ex.run([&](int lane) {
+        dsim_topo_init(c, ex, lane);
         for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = g_q[k];
         for (int k = lane; k < nd; k += DSIM_NL) {
             WF(qd)[k] = g_qd[k];
@@ -547,7 +684,13 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
     ex.run([&](int lane) {
         const float h = c.h;
         for (int i = lane; i < c.d.L; i += DSIM_NL) {
-            const int type = CI(jtype)[i], cs = CI(qstart)[i], ds = CI(qdstart)[i];
+            int type, cs, ds;
+            if constexpr (DsimRoleRegs<Ctx>::value) {
+                const DsimTopoRegs& tp = ex.topo(lane);
+                type = tp.own_type; cs = tp.own_cs; ds = tp.own_ds;
+            } else {
+                type = CI(jtype)[i]; cs = CI(qstart)[i]; ds = CI(qdstart)[i];
+            }
             const float *q = WF(q), *qd = WF(qd), *qdd = WF(qdd), *aqn = WF(aqn), *aqdn = WF(aqdn);
             float *aq = WF(aq), *aqd = WF(aqd), *aqdd = WF(aqdd);
             if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
@@ -618,8 +761,13 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
             }
         }
         for (int d = lane; d < nd; d += DSIM_NL) {
-            const int i = CI(dof_link)[d], type = CI(jtype)[i];
-            const int cs = CI(qstart)[i], ds = CI(qdstart)[i];
+            int i, type, cs, ds;
+            if constexpr (DsimRoleRegs<Ctx>::value) {
+                const DsimTopoRegs& tp = ex.topo(lane);
+                i = tp.dof_link; type = tp.dof_type; cs = tp.dof_cs; ds = tp.dof_ds;
+            } else {
+                i = CI(dof_link)[d]; type = CI(jtype)[i]; cs = CI(qstart)[i]; ds = CI(qdstart)[i];
+            }
             const float at = WF(atau)[d];
             stsv(WF(aS) + 6 * d, ldsv(WF(ftot) + 6 * i) * (-at));
             if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
@@ -641,6 +789,21 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
         for (int it = DSIM_NL - 1 - lane; it < 6 * c.d.L; it += DSIM_NL) {
             const int j = it / 6, k = it - 6 * j;
             float acc = 0.f;
+            if constexpr (DsimAdofRegs<Ctx>::value) {
+                // the dof list of this lane's item is in registers: operands in ONE round trip
+                constexpr int B = decltype(c.d)::nd;
+                const DsimTopoRegs& tp = ex.topo(lane);
+                float sv[B], tv[B];
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    sv[u] = WF(S)[6 * tp.adof[u] + k];
+                    tv[u] = WF(atau)[tp.adof[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < B; ++u) acc -= (u < tp.adof_n) ? sv[u] * tv[u] : 0.f;
+                WF(af)[it] = acc;
+                continue;
+            }
             const dsim_int_a* lst = CI(adof_list);
             int e = CI(adof_start)[j];
             const int e1 = CI(adof_start)[j + 1];
@@ -677,13 +840,16 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
 }
 
 // contacts^T and muscles^T: per-item cotangents of (X_sc, v_s) / (X_sc, activation).  Runs inside the first body-level
-// phase (both only need af); `lane` is counted from the top of the wavefront there.
-template <class Ctx> DSIM_FN void dsim_bwd_external_items(const Ctx& c, int lane) {
+// phase (both only need af); items are dealt from the top lane of the wavefront down.
+template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external_items(const Ctx& c, Exec& ex, int real_lane) {
+    const int lane = DSIM_NL - 1 - real_lane;
     {
         for (int k = lane; k < c.d.C; k += DSIM_NL) {
             float* o = WF(acx) + 13 * k;
             for (int r = 0; r < 13; ++r) o[r] = 0.f;
-            const int b = CI(cbody)[k];
+            int b;
+            if constexpr (DsimRoleRegs<Ctx>::value) b = ex.topo(real_lane).cbody_b;
+            else b = CI(cbody)[k];
             const v3 xp = ld3(WF(xsc) + 7 * b);
             const q4 xq = ldq(WF(xsc) + 7 * b + 3);
             const sv6 vb = ldsv(WF(v) + 6 * b);
@@ -894,7 +1060,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             st3(WF(ac) + 3 * i, cross(r.w, ld3(CF(grav)) * I.m));
             stsv(WF(av) + 6 * i, a_v);  // contact cotangents are added by the item-parallel gather below
         }
-        dsim_bwd_external_items(c, DSIM_NL - 1 - lane);
+        dsim_bwd_external_items(c, ex, lane);
     });
     ex.run([&](int lane) {
         for (int m = lane; m < c.d.M; m += DSIM_NL) {
@@ -904,7 +1070,9 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
         }
         for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
             const int i = it / 6, k = it - 6 * i;
-            WF(aatot)[it] = dsim_subtree_sum(c, WF(aa), 6, k, i);
+            int n_known = -1;
+            if constexpr (DsimSixRegs<Ctx>::value) n_known = ex.topo(lane).six_n;
+            WF(aatot)[it] = dsim_subtree_sum(c, WF(aa), 6, k, i, n_known);
         }
         // per-body gather of the contact (13 floats: X_sc 7, v_s 6) and muscle (7 floats: X_sc) cotangents
         for (int it = lane; it < 13 * c.d.L; it += DSIM_NL) {
@@ -941,12 +1109,24 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
     ex.run([&](int lane) {
         for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
             const int i = it / 6, k = it - 6 * i;
-            WF(avtot)[it] = dsim_subtree_sum(c, WF(av), 6, k, i);
+            int n_known = -1;
+            if constexpr (DsimSixRegs<Ctx>::value) n_known = ex.topo(lane).six_n;
+            WF(avtot)[it] = dsim_subtree_sum(c, WF(av), 6, k, i, n_known);
         }
     });
     ex.run([&](int lane) {
         for (int i = lane; i < c.d.L; i += DSIM_NL) {
-            const int type = CI(jtype)[i], ds = CI(qdstart)[i];
+            int type, ds, d_end, leaf;
+            DsimLinkInfo own;
+            if constexpr (DsimRoleRegs<Ctx>::value) {
+                const DsimTopoRegs& tp = ex.topo(lane);
+                type = tp.own_type; ds = tp.own_ds; d_end = ds + tp.own_nd; leaf = tp.own_ch0 == tp.own_ch1;
+                own = DsimLinkInfo{tp.own_parent, type, tp.own_cs, ds, tp.own_level, 0, 0, 0};
+            } else {
+                type = CI(jtype)[i]; ds = CI(qdstart)[i]; d_end = CI(qdstart)[i + 1];
+                leaf = CI(child_start)[i] == CI(child_start)[i + 1];
+                own = dsim_link_info(c, i);
+            }
             const sv6 a_vj = ldsv(WF(avj) + 6 * i) + ldsv(WF(avtot) + 6 * i);
             const float* qd = WF(qd);
             // vj = S qd
@@ -954,7 +1134,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
                 add3(WF(aqd) + ds, a_vj.w);
                 add3(WF(aqd) + ds + 3, a_vj.v);
             } else {
-                for (int d = ds; d < CI(qdstart)[i + 1]; ++d) {
+                for (int d = ds; d < d_end; ++d) {
                     WF(aqd)[d] += sdot(ldsv(WF(S) + 6 * d), a_vj);
                     float* o = WF(aS) + 6 * d;
                     add3(o, a_vj.w * qd[d]);
@@ -999,7 +1179,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             if (type == DSIM_JOINT_PRISMATIC) {
                 a_rj = rotate_adj_q(rj, ld3(CF(axis) + 3 * i), ld3(WF(aS) + 6 * ds + 3));
             } else if (type == DSIM_JOINT_REVOLUTE || type == DSIM_JOINT_BALL) {
-                for (int d = ds; d < CI(qdstart)[i + 1]; ++d) {
+                for (int d = ds; d < d_end; ++d) {
                     const int k = d - ds;
                     const v3 ax = type == DSIM_JOINT_REVOLUTE
                                       ? ld3(CF(axis) + 3 * i)
@@ -1010,9 +1190,9 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
                     a_rj += rotate_adj_q(rj, ax, sw - cross(pj, sv_));
                 }
             }
-            if (CI(child_start)[i] == CI(child_start)[i + 1]) {
+            if (leaf) {
                 // leaf: nothing will be added to its X_sc cotangent, finish its FK^T here (saves a tree-level phase)
-                dsim_fk_adjoint_link(c, i, dsim_link_info(c, i), ld3(WF(agx) + 13 * i) + a_c, ldq(WF(agx) + 13 * i + 3) + a_rc,
+                dsim_fk_adjoint_link(c, i, own, ld3(WF(agx) + 13 * i) + a_c, ldq(WF(agx) + 13 * i + 3) + a_rc,
                                      a_pj, a_rj);
             } else {
                 st3(WF(axsj) + 7 * i, a_pj);
@@ -1025,8 +1205,16 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
     for (int lv = c.d.Dinner - 1; lv >= 0; --lv) {
         ex.run([&](int lane) {
             for (int i = lane; i < c.d.L; i += DSIM_NL) {
-                const DsimLinkInfo li = dsim_link_info(c, i);
-                const int ch0 = CI(child_start)[i], ch1 = CI(child_start)[i + 1];
+                DsimLinkInfo li;
+                int ch0, ch1;
+                if constexpr (DsimRoleRegs<Ctx>::value) {
+                    const DsimTopoRegs& tp = ex.topo(lane);
+                    li = DsimLinkInfo{tp.own_parent, tp.own_type, tp.own_cs, tp.own_ds, tp.own_level, 0, 0, 0};
+                    ch0 = tp.own_ch0; ch1 = tp.own_ch1;
+                } else {
+                    li = dsim_link_info(c, i);
+                    ch0 = CI(child_start)[i]; ch1 = CI(child_start)[i + 1];
+                }
                 if (li.level != lv || ch0 == ch1) continue;
                 v3 a_pc = ld3(WF(axsc) + 7 * i);
                 q4 a_rc = ldq(WF(axsc) + 7 * i + 3);
@@ -1056,6 +1244,7 @@ DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
     const int nq = c.d.nq, nd = c.d.nd, M = c.d.M;
     dsim_init_static(c, ex);
     ex.run([&](int lane) {
+        dsim_topo_init(c, ex, lane);
         for (int k = lane; k < nq; k += DSIM_NL) WF(aqn)[k] = g_gq_out[k];
         for (int k = lane; k < nd; k += DSIM_NL) {
             WF(aqdn)[k] = g_gqd_out[k];
@@ -1387,6 +1576,7 @@ DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& s
     const int cnt = ep.progress ? ep.reset_count[e] : 0;
     dsim_init_static(c, ex);
     ex.run([&](int lane) {
+        dsim_topo_init(c, ex, lane);
         for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = g_q[k];
         for (int k = lane; k < nd; k += DSIM_NL) WF(qd)[k] = g_qd[k];
         if (lane == 0) WF(epf)[0] = 0.f;
@@ -1497,6 +1687,7 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
     }
     dsim_init_static(c, ex);
     ex.run([&](int lane) {
+        dsim_topo_init(c, ex, lane);
         for (int k = lane; k < nq; k += DSIM_NL) {
             WF(q)[k] = tail[k];
             WF(aqn)[k] = (live && g_gq_out) ? g_gq_out[k] : 0.f;

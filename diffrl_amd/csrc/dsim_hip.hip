@@ -47,6 +47,9 @@ struct DevExec {
     // lane-private accumulators of the mass-matrix cotangent (dsim_core.hpp: DSIM_HACC_MAX registers per lane)
     float hacc_[DSIM_HACC_MAX];
     __device__ __forceinline__ float* hacc(int) { return hacc_; }
+    // per-lane topology records (dsim_core.hpp: DsimTopoRegs, dsim_topo_init)
+    DsimTopoRegs topo_;
+    __device__ __forceinline__ DsimTopoRegs& topo(int) { return topo_; }
     // software prefetch of one checkpoint row: global loads are issued here and stay in flight (registers) until
     // commit() stores them to LDS one adjoint substep later; rows longer than 64*DSIM_PF lanes*regs are read at commit
     float pf[DSIM_PF];
@@ -208,6 +211,8 @@ struct TimingExec {
     template <class F> __device__ __forceinline__ void fire(F&& f) { f((int)threadIdx.x); }
     float hacc_[DSIM_HACC_MAX];
     __device__ __forceinline__ float* hacc(int) { return hacc_; }
+    DsimTopoRegs topo_;
+    __device__ __forceinline__ DsimTopoRegs& topo(int) { return topo_; }
     const float* pf_src;
     __device__ __forceinline__ void prefetch(const float* row, int) { pf_src = row; }
     __device__ __forceinline__ void commit(float* dst, int words, int lane) {

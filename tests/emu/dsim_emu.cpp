@@ -19,6 +19,8 @@ struct HostExec {
     void mark(int) {}
     float hacc_[DSIM_NL][DSIM_HACC_MAX];  // what a lane keeps in registers across phases on the GPU
     float* hacc(int lane) { return hacc_[lane]; }
+    DsimTopoRegs topo_[DSIM_NL];
+    DsimTopoRegs& topo(int lane) { return topo_[lane]; }
     const float* pf_src = nullptr;
     void prefetch(const float* row, int) { pf_src = row; }
     void commit(float* dst, int words, int lane) {
