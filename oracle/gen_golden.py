@@ -14,6 +14,7 @@ path, so parity is pinned by these files instead:
   <env>_rollout.npz  DFlexEnv level: H env.step() calls + backward of
                      -sum(rew) w.r.t. the actions (envs/<env>.py)
   ant_rollout_h32.npz  the same at BASELINE.json's horizon (H = 32, 8 envs)
+  humanoid_rollout_h32.npz, snu_rollout_h32.npz   H = 32, 2 envs (`python oracle/gen_golden.py h32_extra`)
   ant_episode.npz    H = 24 steps WITH the reference's episode handling active:
                      early termination on, episode_length = 10, so every env is
                      reset (envs/ant.py:176-234) at least twice inside the
@@ -265,6 +266,16 @@ def main():
     names = sys.argv[1:] or ["cartpole", "ant", "humanoid", "snu"]
     df, envs = ref_harness.load_reference()
     os.makedirs(OUT, exist_ok=True)
+    if "h32_extra" in names:
+        # BASELINE.json's horizon for the two humanoid configurations (2 environments each: the reference CPU path does
+        # ~15-40 env-steps/s on them)
+        names.remove("h32_extra")
+        for name in ("humanoid", "snu"):
+            saved = CONFIGS[name]
+            CONFIGS[name] = (saved[0], saved[1], 2, 32, saved[4])
+            np.savez_compressed(os.path.join(OUT, name + "_rollout_h32.npz"), **rollout_golden(df, envs, name))
+            CONFIGS[name] = saved
+            print("golden written:", name + "_rollout_h32")
     if "ant_extra" in names:
         names.remove("ant_extra")
         for k, v in ant_extra_goldens(df, envs).items():
