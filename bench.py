@@ -50,9 +50,23 @@ def rollout(env, actions):
     for a_t in acts.unbind(0):
         obs, rew, done, info = env.step(a_t)
         rews.append(rew)
-    loss = -torch.stack(rews).sum()
+    loss = reward_loss(rews)
     loss.backward()
     return acts.grad
+
+
+_W = {}
+
+
+def reward_loss(rews):
+    """-sum_t sum_env w[t, env] * rew[t, env] with w = 1 (SHAC weights the steps by gamma^t, algorithms/shac.py:215-216).
+    Written with an explicit weight tensor so that every step receives a contiguous reward cotangent (a bare .sum()
+    hands autograd a stride-0 broadcast that each of the H backward steps would first have to materialise)."""
+    r = torch.stack(rews)
+    key = (r.shape, r.device)
+    if key not in _W:
+        _W[key] = torch.ones_like(r)
+    return -(r * _W[key]).sum()
 
 
 def time_backward_kernel(env, name, n, H, reps, device):
@@ -135,7 +149,7 @@ def main():
             def body(e):
                 e.initialize_trajectory()
                 rews = [e.step(a_t)[1] for a_t in acts.unbind(0)]
-                return -torch.stack(rews).sum()
+                return reward_loss(rews)
 
             env.clear_grad()
             env.reset()
