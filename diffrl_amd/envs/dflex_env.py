@@ -15,7 +15,6 @@ import os
 import numpy as np
 import torch
 
-from .. import capi
 from .. import dflex as df
 from ..engine import EnvStep
 

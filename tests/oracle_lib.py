@@ -5,7 +5,7 @@ import subprocess
 
 import numpy as np
 
-from diffrl_amd.capi import ModelDesc, make_desc
+from diffrl_amd.capi import make_desc
 from diffrl_amd.template import ArticulationTemplate
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

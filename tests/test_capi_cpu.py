@@ -59,8 +59,6 @@ def test_envspec_and_episode_match_header_field_order():
 
 
 def test_engine_refuses_cpu():
-    import numpy as np
-
     from diffrl_amd.engine import Engine
     from oracle_lib import template_from_golden
     with pytest.raises(capi.DsimError):

@@ -1,6 +1,5 @@
 """CPU-only edge cases: model validation in the C-ABI library (runs before any HIP call, so it works without a
 GPU), layout limits, ragged / degenerate articulations through the oracle and the lane-serial phase harness."""
-import copy
 import ctypes as C
 
 import numpy as np
@@ -9,7 +8,7 @@ import pytest
 from diffrl_amd import capi
 from diffrl_amd import dflex as df
 from emu_lib import emu_backward, emu_forward, layout
-from oracle_lib import golden, oracle_backward, oracle_forward, project_tangent, relerr, template_from_golden
+from oracle_lib import golden, oracle_backward, project_tangent, relerr, template_from_golden
 
 
 def _create(t):

@@ -2,7 +2,6 @@
 (tests/emu), against the reference goldens and the CPU oracle.  This checks the restructured
 algorithm (tree-parallel kinematics, 10-parameter inertias, composite-body mass matrix, explicit
 inverse) and the hand-derived adjoint; the real HIP build is checked by the -m gpu tests."""
-import numpy as np
 import pytest
 
 from emu_lib import emu_backward, emu_forward, layout

@@ -1,6 +1,5 @@
 """GPU: whole-trajectory HIP-graph submission (diffrl_amd/graph.py): the captured rollout replays to
 the same losses and gradients as the eager DFlexEnv.step loop."""
-import numpy as np
 import pytest
 import torch
 

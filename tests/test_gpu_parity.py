@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle_lib import golden, oracle_backward, oracle_forward, project_tangent, relerr, template_from_golden
+from oracle_lib import golden, oracle_backward, project_tangent, relerr, template_from_golden
 
 pytestmark = pytest.mark.gpu
 ENVS = ["cartpole", "ant", "humanoid", "snu", "hopper", "cheetah"]
@@ -152,7 +152,6 @@ def test_error_paths(dev):
 @pytest.mark.parametrize("env", ENVS)
 def test_specialised_kernels_match_generic(env, dev, monkeypatch):
     """the per-model specialised kernel set (compile-time layout) and the generic one agree"""
-    import os
     from diffrl_amd.engine import Engine
     t = template_from_golden(env)
     g = golden(env + "_step")

@@ -1,7 +1,6 @@
 """CPU-only: diffrl_amd's own asset loaders + ModelBuilder reproduce the reference's model constants
 (tests/golden/<env>_model.npz, dumped from the reference's builder) -- from the original asset files
 when they are available and from the compiled assets (.npz builder snapshots) always."""
-import os
 
 import numpy as np
 import pytest

@@ -1,5 +1,5 @@
 """Quick GPU sanity/timing probe (developer tool, not part of the product or the tests)."""
-import sys, os, time
+import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
