@@ -224,7 +224,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "dsim_env_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": t_bwd * 1e3, "alg_bytes_per_launch": bwd_bytes,
-                         "note": "fused kernel is VALU/latency-bound by construction (SURVEY 8d); see DESIGN.md"},
+                         "note": "fused kernel is VALU/latency-bound by construction (SURVEY 8d); traffic >> algorithmic bytes on purpose: "
+                                 "39.3 MB of it is the saved forward block the adjoint reads back instead of recomputing "
+                                 "(measured 19 % faster; HBM is at ~3 % of peak either way), see DESIGN.md section 4"},
             # fp32 vector-ALU view of the same launch pair (SURVEY 8d asks for it next to the HBM fraction): ~1.2 MFLOP per
             # Ant env-step fwd+adjoint (SURVEY's op-count estimate) against the 157.3 TFLOP/s fp32 vector peak
             "fp32_valu_frac_est": (1.2e6 * n / (t_bwd * (1.0 + 0.105 / 0.160))) / 157.3e12 if a.env == "ant" else None,
