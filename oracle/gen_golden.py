@@ -14,6 +14,7 @@ path, so parity is pinned by these files instead:
   <env>_rollout.npz  DFlexEnv level: H env.step() calls + backward of
                      -sum(rew) w.r.t. the actions (envs/<env>.py)
   ant_rollout_h32.npz  the same at BASELINE.json's horizon (H = 32, 8 envs)
+  cartpole_rollout_64x16.npz   BASELINE.json configs[0] literally: 64 envs, H = 16 (`... cartpole_64x16`)
   humanoid_rollout_h32.npz, snu_rollout_h32.npz   H = 32, 2 envs (`python oracle/gen_golden.py h32_extra`)
   ant_episode.npz    H = 24 steps WITH the reference's episode handling active:
                      early termination on, episode_length = 10, so every env is
@@ -276,6 +277,14 @@ def main():
             np.savez_compressed(os.path.join(OUT, name + "_rollout_h32.npz"), **rollout_golden(df, envs, name))
             CONFIGS[name] = saved
             print("golden written:", name + "_rollout_h32")
+    if "cartpole_64x16" in names:
+        # BASELINE.json configs[0] literally: CartPoleSwingUp, 64 environments, H = 16
+        names.remove("cartpole_64x16")
+        saved = CONFIGS["cartpole"]
+        CONFIGS["cartpole"] = (saved[0], saved[1], 64, 16, saved[4])
+        np.savez_compressed(os.path.join(OUT, "cartpole_rollout_64x16.npz"), **rollout_golden(df, envs, "cartpole"))
+        CONFIGS["cartpole"] = saved
+        print("golden written: cartpole_rollout_64x16")
     if "ant_extra" in names:
         names.remove("ant_extra")
         for k, v in ant_extra_goldens(df, envs).items():

@@ -55,7 +55,9 @@ def test_emu_episode_rollout_vs_reference():
     _check_episode(rec, ga, q, g)
 
 
-SUBSTEPS = {"ant": 16, "humanoid": 48, "snu": 48}
+SUBSTEPS = {"ant": 16, "humanoid": 48, "snu": 48, "cartpole": 4}
+GOLDEN = {"ant": "ant_rollout_h32", "humanoid": "humanoid_rollout_h32", "snu": "snu_rollout_h32",
+          "cartpole": "cartpole_rollout_64x16"}   # cartpole: BASELINE.json configs[0] literally (64 envs, H = 16)
 
 
 def _grad_tolerance(env, g, measured):
@@ -72,14 +74,14 @@ def _grad_tolerance(env, g, measured):
     return tol
 
 
-@pytest.mark.parametrize("env", ["ant", "humanoid", "snu"])
+@pytest.mark.parametrize("env", ["ant", "humanoid", "snu", "cartpole"])
 def test_emu_h32_rollout_vs_reference(env):
     from emu_lib import emu_env_backward, emu_env_forward, env_spec_for
-    g = golden(env + "_rollout_h32")
+    g = golden(GOLDEN[env])
     t = template_from_golden(env)
     spec, keep = env_spec_for(env, t)
     H, n = g["actions"].shape[:2]
-    assert H == 32
+    assert (H, n) == ((16, 64) if env == "cartpole" else (32, n))
     S, mm = SUBSTEPS[env], int(g["mm_freq"])
     q, qd, tape = g["q0"], g["qd0"], []
     for s in range(H):
@@ -124,16 +126,17 @@ def test_gpu_episode_rollout_vs_reference():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["ant", "humanoid", "snu"])
+@pytest.mark.parametrize("env", ["ant", "humanoid", "snu", "cartpole"])
 def test_gpu_h32_rollout_vs_reference(env):
     from diffrl_amd import envs
-    g = golden(env + "_rollout_h32")
+    g = golden(GOLDEN[env])
     H, n = g["actions"].shape[:2]
     dev = torch.device("cuda:0")
-    cls = {"ant": envs.AntEnv, "humanoid": envs.HumanoidEnv, "snu": envs.SNUHumanoidEnv}[env]
+    cls = {"ant": envs.AntEnv, "humanoid": envs.HumanoidEnv, "snu": envs.SNUHumanoidEnv,
+           "cartpole": envs.CartPoleSwingUpEnv}[env]
     kw = dict(num_envs=n, device="cuda:0", no_grad=False, stochastic_init=False, MM_caching_frequency=int(g["mm_freq"]),
               episode_length=1000)
-    if env == "ant":
+    if env in ("ant", "cartpole"):
         kw["early_termination"] = False
     e = cls(**kw)
     e.reset()
