@@ -14,6 +14,7 @@ path, so parity is pinned by these files instead:
   <env>_rollout.npz  DFlexEnv level: H env.step() calls + backward of
                      -sum(rew) w.r.t. the actions (envs/<env>.py)
   ant_rollout_h32.npz  the same at BASELINE.json's horizon (H = 32, 8 envs)
+  ant_1024x32.npz    BASELINE.json configs[1] literally: 1024 envs, H = 32 (slimmed, see main; `... ant_1024x32`)
   cartpole_rollout_64x16.npz   BASELINE.json configs[0] literally: 64 envs, H = 16 (`... cartpole_64x16`)
   humanoid_rollout_h32.npz, snu_rollout_h32.npz   H = 32, 2 envs (`python oracle/gen_golden.py h32_extra`)
   ant_episode.npz    H = 24 steps WITH the reference's episode handling active:
@@ -285,6 +286,20 @@ def main():
         np.savez_compressed(os.path.join(OUT, "cartpole_rollout_64x16.npz"), **rollout_golden(df, envs, "cartpole"))
         CONFIGS["cartpole"] = saved
         print("golden written: cartpole_rollout_64x16")
+    if "ant_1024x32" in names:
+        # BASELINE.json configs[1] literally (Ant, 1024 environments, H = 32) through the reference: ~1 min of its CPU path.
+        # Kept small: the actions are regenerated from their seed by the tests (same CPU generator), observations are dropped,
+        # action gradients are kept for every 8th environment (all environments are independent), rewards for all.
+        names.remove("ant_1024x32")
+        saved = CONFIGS["ant"]
+        CONFIGS["ant"] = (saved[0], saved[1], 1024, 32, saved[4])
+        g = rollout_golden(df, envs, "ant")
+        CONFIGS["ant"] = saved
+        slim = dict(q0=g["q0"], qd0=g["qd0"], rew=g["rew"], q_final=g["q_final"], mm_freq=g["mm_freq"], loss=g["loss"],
+                    grad_actions_every8=g["grad_actions"][:, ::8], actions_check=g["actions"][:, :4],
+                    action_seed=np.int64(3), preroll=np.int64(20))
+        np.savez_compressed(os.path.join(OUT, "ant_1024x32.npz"), **slim)
+        print("golden written: ant_1024x32")
     if "ant_extra" in names:
         names.remove("ant_extra")
         for k, v in ant_extra_goldens(df, envs).items():

@@ -154,3 +154,68 @@ def test_gpu_h32_rollout_vs_reference(env):
     assert (a * r).sum() / (np.linalg.norm(a) * np.linalg.norm(r)) > 0.9999
     assert relerr(a, r) < _grad_tolerance(env, g, relerr(a, r))
     assert relerr(e.state.joint_q.detach().view(n, -1).cpu().numpy(), g["q_final"]) < 1e-3
+
+
+def _ant_1024x32_actions(g):
+    """the action tensor of tests/golden/ant_1024x32.npz, regenerated from its seed exactly as oracle/gen_golden.py drew it
+    (CPU generator: 20 pre-roll draws, then the [H, N, 8] block)"""
+    gen = torch.Generator().manual_seed(int(g["action_seed"]))
+    n = g["q0"].shape[0]
+    for _ in range(int(g["preroll"])):
+        torch.rand((n, 8), generator=gen)
+    acts = torch.tanh(2.0 * torch.rand((32, n, 8), generator=gen) - 1.0)
+    # identical random stream; tanh may differ in the last bit between host CPUs (vectorised libm paths)
+    assert np.abs(acts[:, :4].numpy() - g["actions_check"]).max() < 5e-7, "torch CPU generator stream differs from the recording"
+    return acts
+
+
+def test_emu_baseline_config_subset_vs_reference():
+    """first 64 of the 1024 environments of BASELINE.json configs[1] (Ant 1024 x H=32) on the host harness"""
+    from emu_lib import emu_env_backward, emu_env_forward, env_spec_for
+    g = golden("ant_1024x32")
+    acts = _ant_1024x32_actions(g).numpy()[:, :64]
+    t = template_from_golden("ant")
+    spec, keep = env_spec_for("ant", t)
+    q, qd, tape = g["q0"][:64], g["qd0"][:64], []
+    for s in range(32):
+        q, qd, obs, rew, ck = emu_env_forward(t, spec, q, qd, acts[s], DT, 16, 16)
+        assert np.abs(rew - g["rew"][s][:64]).max() < 1e-3 * max(1.0, np.abs(g["rew"]).max()), s
+        tape.append(ck)
+    assert relerr(q, g["q_final"][:64]) < 1e-3
+    gq, gqd, ga = np.zeros_like(q), np.zeros_like(qd), np.zeros_like(acts)
+    for s in reversed(range(32)):
+        gq, gqd, ga[s] = emu_env_backward(t, spec, tape[s], acts[s], DT, 16, 16, gq, gqd, None, -np.ones(64, np.float32))
+    a, r = ga[:, ::8].astype(np.float64), g["grad_actions_every8"][:, :8].astype(np.float64)
+    assert (a * r).sum() / (np.linalg.norm(a) * np.linalg.norm(r)) > 0.9999
+    assert relerr(a, r) < 1e-3
+
+
+@pytest.mark.gpu
+def test_gpu_baseline_config_vs_reference():
+    """BASELINE.json configs[1] literally -- Ant, 1024 environments, H = 32, forward + adjoint -- against the recording of
+    the reference's CPU path: rewards of all environments and steps, final states, action gradients of every 8th one"""
+    from diffrl_amd import envs
+    g = golden("ant_1024x32")
+    n, H = g["q0"].shape[0], 32
+    assert n == 1024
+    dev = torch.device("cuda:0")
+    e = envs.AntEnv(num_envs=n, device="cuda:0", no_grad=False, stochastic_init=False, MM_caching_frequency=16,
+                    early_termination=False, episode_length=1000)
+    e.reset()
+    e.reset_with_state(torch.tensor(g["q0"], device=dev).reshape(-1), torch.tensor(g["qd0"], device=dev).reshape(-1))
+    e.initialize_trajectory()
+    acts = _ant_1024x32_actions(g).to(dev).requires_grad_(True)
+    rews = []
+    for t in range(H):
+        obs, rew, done, info = e.step(acts[t])
+        rews.append(rew)
+    loss = -torch.stack(rews).sum()
+    loss.backward()
+    R = torch.stack(rews).detach().cpu().numpy()
+    assert np.abs(R - g["rew"]).max() < 1e-3 * max(1.0, np.abs(g["rew"]).max())
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    assert relerr(e.state.joint_q.detach().view(n, -1).cpu().numpy(), g["q_final"]) < 1e-3
+    a = acts.grad[:, ::8].cpu().numpy().astype(np.float64)
+    r = g["grad_actions_every8"].astype(np.float64)
+    assert (a * r).sum() / (np.linalg.norm(a) * np.linalg.norm(r)) > 0.9999
+    assert relerr(a, r) < 1e-3
