@@ -335,6 +335,17 @@ class DFlexEnv:
                 self.state.joint_act = act
             self._pool_stale = True
 
+    def detach_buffers(self):
+        """drops every reference this object holds into an autograd graph (observation / reward buffers, extras, state):
+        clear_grad() for the state plus the output buffers of the last step"""
+        self.clear_grad()
+        with torch.no_grad():
+            self.obs_buf = self.obs_buf.detach()
+            self.rew_buf = self.rew_buf.detach()
+            if getattr(self, "obs_buf_before_reset", None) is not None:
+                self.obs_buf_before_reset = self.obs_buf_before_reset.detach()
+            self.extras = {}
+
     def initialize_trajectory(self):
         self.clear_grad()
         return self._refresh_obs()

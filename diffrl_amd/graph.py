@@ -11,7 +11,8 @@ C ABI go to torch's current stream, which is the capturing stream during `torch.
     loss = roll.replay()                  # forward + backward, one hipGraphLaunch; .grad of the leaves is refreshed
 
 `body` must be capturable: no `.item()`, no `nonzero()`, no Python branching on device data (`done` has to be used as a
-mask, not as an index list).  The leaves whose `.grad` the caller reads (actor parameters, an action tensor) keep their
+mask, not as an index list).  If the same leaves took part in an EAGER backward before, drop every tensor of that rollout
+(losses, observations, rewards) first: live autograd nodes bound to the default stream break the capture.  The leaves whose `.grad` the caller reads (actor parameters, an action tensor) keep their
 identity; their `.grad` tensors live in the graph's memory pool and are overwritten by every replay.
 """
 import torch
@@ -28,6 +29,13 @@ class GraphedRollout:
         if torch.device(env.device).type != "cuda":
             raise RuntimeError("GraphedRollout needs a GPU environment")
         self.env, self.body, self.carry, self.backward = env, body, carry_state, backward
+        # Autograd nodes of an earlier eager rollout that are still alive (kept by the environment's observation / reward
+        # buffers, or by a loss the caller still holds) carry AccumulateGrad nodes bound to the DEFAULT stream; re-using
+        # those inside a capture is fatal on this stack (segfault in hipStreamEndCapture).  Drop the environment's
+        # references; the caller must not keep losses / observations of earlier rollouts either.
+        import gc
+        env.detach_buffers()
+        gc.collect()
         with torch.no_grad():
             self._q = env.state.joint_q.detach().clone()
             self._qd = env.state.joint_qd.detach().clone()

@@ -128,3 +128,29 @@ def test_policy_learns_through_graph_replays():
     import shac_lite
     hist = shac_lite.main(["--iters", "40", "--envs", "128", "--graph", "--seed", "1"])
     assert sum(hist[-6:]) / 6 > sum(hist[:6]) / 6 + 0.15
+
+
+def test_capture_after_an_eager_rollout_with_the_same_parameters():
+    """regression: an eager rollout + backward on the default stream leaves autograd nodes alive through the environment's
+    observation / reward buffers; GraphedRollout has to drop them before capturing (it used to segfault in capture_end)"""
+    from diffrl_amd.graph import GraphedRollout
+    dev, n = torch.device("cuda:0"), 64
+    torch.manual_seed(0)
+    e = _ant(n, stochastic_init=True)
+    actor = torch.nn.Sequential(torch.nn.Linear(37, 32), torch.nn.ELU(), torch.nn.Linear(32, 8)).to(dev)
+
+    def body(env):
+        obs, loss = env.initialize_trajectory(), 0.0
+        for _ in range(8):
+            obs, rew, done, info = env.step(torch.tanh(actor(obs)))
+            loss = loss - rew.sum()
+        return loss / (8 * n)
+
+    e.reset()
+    body(e).backward()                     # eager, default stream
+    g_eager = [p.grad.clone() for p in actor.parameters()]
+    roll = GraphedRollout(e, body, leaves=list(actor.parameters()))
+    roll.replay()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p.grad).all() for p in actor.parameters())
+    assert all(p.grad.shape == g.shape for p, g in zip(actor.parameters(), g_eager))
