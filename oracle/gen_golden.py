@@ -17,7 +17,7 @@ path, so parity is pinned by these files instead:
   ant_1024x32.npz    BASELINE.json configs[1] literally: 1024 envs, H = 32 (slimmed, see main; `... ant_1024x32`)
   cartpole_rollout_64x16.npz   BASELINE.json configs[0] literally: 64 envs, H = 16 (`... cartpole_64x16`)
   humanoid_rollout_h32.npz, snu_rollout_h32.npz   H = 32, 2 envs (`python oracle/gen_golden.py h32_extra`)
-  ant_episode.npz    H = 24 steps WITH the reference's episode handling active:
+  <env>_episode.npz  (`... ant_extra`, `... episodes_extra`)  H steps WITH the reference's episode handling active:
                      early termination on, episode_length = 10, so every env is
                      reset (envs/ant.py:176-234) at least twice inside the
                      rollout; records done / obs_before_reset per step and the
@@ -225,28 +225,27 @@ def rollout_golden(df, envs, name):
                 loss=np.float64(loss.item()))
 
 
-def ant_extra_goldens(df, envs):
-    """H = 32 rollout, and a rollout through the reference's own reset logic (see module docstring)"""
-    out = {}
-    # (a) BASELINE horizon
-    n, H = 8, 32
-    CONFIGS["ant"] = ("AntEnv", 16, n, H, True)
-    out["ant_rollout_h32"] = rollout_golden(df, envs, "ant")
-    CONFIGS["ant"] = ("AntEnv", 16, 4, 6, True)
-    # (b) episode handling
-    n, H, L = 8, 24, 10
+def episode_golden(envs, name, n, H, L, act_gain=3.0):
+    """rollout THROUGH the reference's episode handling: the environment's own termination rules are active and
+    episode_length = L, stochastic_init off (restarts are deterministic), half of the environments start their episode three
+    steps late; records done / progress / obs_before_reset per step and the gradient of a loss that reads obs,
+    obs_before_reset and the rewards"""
+    cls, mmf, _, _, has_et = CONFIGS[name]
     torch.manual_seed(0)
     np.random.seed(0)
-    env = envs.AntEnv(num_envs=n, device="cpu", render=False, seed=0, episode_length=L, no_grad=False,
-                      stochastic_init=False, MM_caching_frequency=16, early_termination=True)
+    kw = dict(num_envs=n, device="cpu", render=False, seed=0, episode_length=L, no_grad=False, stochastic_init=False,
+              MM_caching_frequency=mmf)
+    if has_et:
+        kw["early_termination"] = True
+    env = getattr(envs, cls)(**kw)
     env.clear_grad()
     env.reset()
-    env.progress_buf[: n // 2] = 3          # half of the environments finish three steps earlier
+    env.progress_buf[: n // 2] = 3
     g = torch.Generator().manual_seed(11)
     q0, qd0 = env.get_state()
     prog0 = t2n(env.progress_buf)
     obs0 = env.initialize_trajectory()
-    acts = torch.tanh(3.0 * (2.0 * torch.rand((H, n, env.num_actions), generator=g) - 1.0)).clone().requires_grad_(True)
+    acts = torch.tanh(act_gain * (2.0 * torch.rand((H, n, env.num_actions), generator=g) - 1.0)).clone().requires_grad_(True)
     w = torch.randn((n, env.num_obs), generator=g)
     rec = dict(obs=[], rew=[], done=[], obs_before=[], progress=[])
     loss = 0.0
@@ -257,10 +256,22 @@ def ant_extra_goldens(df, envs):
         rec["obs_before"].append(t2n(info["obs_before_reset"])); rec["progress"].append(t2n(env.progress_buf))
     loss.backward()
     assert sum(int(d.sum()) for d in rec["done"]) >= 2 * n
-    out["ant_episode"] = dict(q0=t2n(q0).reshape(n, -1), qd0=t2n(qd0).reshape(n, -1), progress0=prog0, obs0=t2n(obs0),
-                              actions=t2n(acts), w=t2n(w), grad_actions=t2n(acts.grad), loss=np.float64(loss.item()),
-                              episode_length=L, mm_freq=16, q_final=t2n(env.state.joint_q).reshape(n, -1),
-                              **{k: np.stack(v) for k, v in rec.items()})
+    return dict(q0=t2n(q0).reshape(n, -1), qd0=t2n(qd0).reshape(n, -1), progress0=prog0, obs0=t2n(obs0),
+                actions=t2n(acts), w=t2n(w), grad_actions=t2n(acts.grad), loss=np.float64(loss.item()),
+                episode_length=L, mm_freq=mmf, q_final=t2n(env.state.joint_q).reshape(n, -1),
+                **{k: np.stack(v) for k, v in rec.items()})
+
+
+def ant_extra_goldens(df, envs):
+    """H = 32 rollout, and a rollout through the reference's own reset logic (see module docstring)"""
+    out = {}
+    # (a) BASELINE horizon
+    n, H = 8, 32
+    CONFIGS["ant"] = ("AntEnv", 16, n, H, True)
+    out["ant_rollout_h32"] = rollout_golden(df, envs, "ant")
+    CONFIGS["ant"] = ("AntEnv", 16, 4, 6, True)
+    # (b) episode handling
+    out["ant_episode"] = episode_golden(envs, "ant", n=8, H=24, L=10)
     return out
 
 
@@ -300,6 +311,14 @@ def main():
                     action_seed=np.int64(3), preroll=np.int64(20))
         np.savez_compressed(os.path.join(OUT, "ant_1024x32.npz"), **slim)
         print("golden written: ant_1024x32")
+    if "episodes_extra" in names:
+        # the other environments' termination rules through the reference (humanoid: height + invalid-state checks,
+        # humanoid.py:340-356; hopper: height, hopper.py:288-293; cartpole / cheetah: episode length only)
+        names.remove("episodes_extra")
+        for name, n, H, L in (("humanoid", 4, 14, 6), ("snu", 4, 14, 6), ("hopper", 8, 24, 10), ("cheetah", 8, 24, 10),
+                              ("cartpole", 8, 24, 10)):
+            np.savez_compressed(os.path.join(OUT, name + "_episode.npz"), **episode_golden(envs, name, n, H, L))
+            print("golden written:", name + "_episode")
     if "ant_extra" in names:
         names.remove("ant_extra")
         for k, v in ant_extra_goldens(df, envs).items():

@@ -11,19 +11,27 @@ from oracle_lib import golden, relerr, template_from_golden
 DT, S, MM = 1.0 / 60.0, 16, 16
 
 
-def _emu_episode_rollout(g):
+EP_SUBSTEPS = {"ant": 16, "humanoid": 48, "snu": 48, "hopper": 16, "cheetah": 16, "cartpole": 4}
+# termination rules of the reference's environments: (height termination, invalid-state checks)
+EP_RULES = {"ant": (True, False), "humanoid": (True, True), "snu": (True, True), "hopper": (True, False),
+            "cheetah": (False, False), "cartpole": (False, False)}
+TERM_H = {"ant": 0.27, "humanoid": 0.74, "snu": 0.46, "hopper": -0.45}
+
+
+def _emu_episode_rollout(g, env):
     from emu_lib import emu_env_backward, emu_env_forward, env_spec_for, make_episode
-    t = template_from_golden("ant")
-    spec, keep = env_spec_for("ant", t)
+    t = template_from_golden(env)
+    spec, keep = env_spec_for(env, t)
     H, n = g["actions"].shape[:2]
+    S, mm = EP_SUBSTEPS[env], int(g["mm_freq"])
     q, qd = g["q0"].copy(), g["qd0"].copy()
-    pool_q, pool_qd = g["q0"][None].copy(), np.zeros_like(g["qd0"])[None]   # deterministic reset: back to the start state
+    pool_q, pool_qd = g["q0"][None].copy(), g["qd0"][None].copy()   # deterministic reset: back to the start state
     prog, cnt = g["progress0"].astype(np.int64).copy(), np.zeros(n, np.int32)
     tape, rec = [], dict(obs=[], rew=[], done=[], obs_before=[], progress=[])
     for s in range(H):
         done, ob = np.zeros(n, np.int64), np.zeros((n, spec.n_obs), np.float32)
-        ep = make_episode(prog, done, ob, pool_q, pool_qd, cnt, int(g["episode_length"]), True, False)
-        q, qd, obs, rew, ck = emu_env_forward(t, spec, q, qd, g["actions"][s], DT, S, MM, episode=ep)
+        ep = make_episode(prog, done, ob, pool_q, pool_qd, cnt, int(g["episode_length"]), *EP_RULES[env])
+        q, qd, obs, rew, ck = emu_env_forward(t, spec, q, qd, g["actions"][s], DT, S, mm, episode=ep)
         tape.append(ck)
         for k, v in (("obs", obs), ("rew", rew), ("done", done), ("obs_before", ob), ("progress", prog)):
             rec[k].append(v.copy())
@@ -31,12 +39,12 @@ def _emu_episode_rollout(g):
     ga = np.zeros_like(g["actions"])
     w = (0.01 * g["w"]).astype(np.float32)
     for s in reversed(range(H)):
-        gq, gqd, ga[s] = emu_env_backward(t, spec, tape[s], g["actions"][s], DT, S, MM, gq, gqd, w,
+        gq, gqd, ga[s] = emu_env_backward(t, spec, tape[s], g["actions"][s], DT, S, mm, gq, gqd, w,
                                           -np.ones(n, np.float32), w)
     return {k: np.stack(v) for k, v in rec.items()}, ga, q
 
 
-def _check_episode(rec, ga, q_final, g):
+def _check_episode(rec, ga, q_final, g, env="ant"):
     np.testing.assert_array_equal(rec["done"], g["done"])
     np.testing.assert_array_equal(rec["progress"], g["progress"])
     assert g["done"].sum() >= 2 * g["done"].shape[1]
@@ -46,13 +54,17 @@ def _check_episode(rec, ga, q_final, g):
     assert relerr(q_final, g["q_final"]) < 1e-3
     a, r = ga.astype(np.float64), g["grad_actions"].astype(np.float64)
     assert (a * r).sum() / (np.linalg.norm(a) * np.linalg.norm(r)) > 0.9999
-    assert relerr(a, r) < 2e-3
+    assert relerr(a, r) < (2e-3 if env == "ant" else 5e-3)
 
 
-def test_emu_episode_rollout_vs_reference():
-    g = golden("ant_episode")
-    rec, ga, q = _emu_episode_rollout(g)
-    _check_episode(rec, ga, q, g)
+EP_ENVS = ["ant", "humanoid", "snu", "hopper", "cheetah", "cartpole"]
+
+
+@pytest.mark.parametrize("env", EP_ENVS)
+def test_emu_episode_rollout_vs_reference(env):
+    g = golden(env + "_episode")
+    rec, ga, q = _emu_episode_rollout(g, env)
+    _check_episode(rec, ga, q, g, env)
 
 
 SUBSTEPS = {"ant": 16, "humanoid": 48, "snu": 48, "cartpole": 4}
@@ -99,13 +111,20 @@ def test_emu_h32_rollout_vs_reference(env):
 
 
 @pytest.mark.gpu
-def test_gpu_episode_rollout_vs_reference():
+@pytest.mark.parametrize("env", EP_ENVS)
+def test_gpu_episode_rollout_vs_reference(env):
     from diffrl_amd import envs
-    g = golden("ant_episode")
+    g = golden(env + "_episode")
     H, n = g["actions"].shape[:2]
     dev = torch.device("cuda:0")
-    e = envs.AntEnv(num_envs=n, device="cuda:0", no_grad=False, stochastic_init=False, MM_caching_frequency=16,
-                    early_termination=True, episode_length=int(g["episode_length"]))
+    cls = {"ant": envs.AntEnv, "humanoid": envs.HumanoidEnv, "snu": envs.SNUHumanoidEnv, "hopper": envs.HopperEnv,
+           "cheetah": envs.CheetahEnv, "cartpole": envs.CartPoleSwingUpEnv}[env]
+    kw = dict(num_envs=n, device="cuda:0", no_grad=False, stochastic_init=False, MM_caching_frequency=int(g["mm_freq"]),
+              episode_length=int(g["episode_length"]))
+    if env in ("ant", "hopper", "cheetah", "cartpole"):
+        kw["early_termination"] = True
+    e = cls(**kw)
+    assert (bool(e.height_terminate), bool(e.check_invalid)) == EP_RULES[env]
     e.reset()
     assert relerr(e.state.joint_q.view(n, -1).cpu().numpy(), g["q0"]) < 1e-6
     e.progress_buf[:] = torch.tensor(g["progress0"], device=dev)
@@ -122,7 +141,7 @@ def test_gpu_episode_rollout_vs_reference():
             rec[k].append(v.detach().cpu().numpy().copy())
     loss.backward()
     _check_episode({k: np.stack(v) for k, v in rec.items()}, acts.grad.cpu().numpy(),
-                   e.state.joint_q.detach().view(n, -1).cpu().numpy(), g)
+                   e.state.joint_q.detach().view(n, -1).cpu().numpy(), g, env)
 
 
 @pytest.mark.gpu
@@ -213,7 +232,7 @@ def test_gpu_baseline_config_vs_reference():
     loss.backward()
     R = torch.stack(rews).detach().cpu().numpy()
     assert np.abs(R - g["rew"]).max() < 1e-3 * max(1.0, np.abs(g["rew"]).max())
-    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
     assert relerr(e.state.joint_q.detach().view(n, -1).cpu().numpy(), g["q_final"]) < 1e-3
     a = acts.grad[:, ::8].cpu().numpy().astype(np.float64)
     r = g["grad_actions_every8"].astype(np.float64)
