@@ -225,7 +225,7 @@ def rollout_golden(df, envs, name):
                 loss=np.float64(loss.item()))
 
 
-def episode_golden(envs, name, n, H, L, act_gain=3.0):
+def episode_golden(envs, name, n, H, L, act_gain=3.0, min_done=None):
     """rollout THROUGH the reference's episode handling: the environment's own termination rules are active and
     episode_length = L, stochastic_init off (restarts are deterministic), half of the environments start their episode three
     steps late; records done / progress / obs_before_reset per step and the gradient of a loss that reads obs,
@@ -255,7 +255,7 @@ def episode_golden(envs, name, n, H, L, act_gain=3.0):
         rec["obs"].append(t2n(obs)); rec["rew"].append(t2n(rew)); rec["done"].append(t2n(done))
         rec["obs_before"].append(t2n(info["obs_before_reset"])); rec["progress"].append(t2n(env.progress_buf))
     loss.backward()
-    assert sum(int(d.sum()) for d in rec["done"]) >= 2 * n
+    assert sum(int(d.sum()) for d in rec["done"]) >= (2 * n if min_done is None else min_done)
     return dict(q0=t2n(q0).reshape(n, -1), qd0=t2n(qd0).reshape(n, -1), progress0=prog0, obs0=t2n(obs0),
                 actions=t2n(acts), w=t2n(w), grad_actions=t2n(acts.grad), loss=np.float64(loss.item()),
                 episode_length=L, mm_freq=mmf, q_final=t2n(env.state.joint_q).reshape(n, -1),
@@ -311,6 +311,20 @@ def main():
                     action_seed=np.int64(3), preroll=np.int64(20))
         np.savez_compressed(os.path.join(OUT, "ant_1024x32.npz"), **slim)
         print("golden written: ant_1024x32")
+    for tag, name, n, stride in (("humanoid_1024x32", "humanoid", 1024, 8), ("snu_512x32", "snu", 512, 16)):
+        if tag in names:
+            # BASELINE.json configs[2] / configs[3] literally, through the reference with its termination rules active
+            # (random actions make humanoids fall: restarts are part of the recording).  Slimmed like ant_1024x32: actions and
+            # loss weights are regenerated from the seed by the tests, observations dropped, gradients for every `stride`-th env.
+            names.remove(tag)
+            g = episode_golden(envs, name, n=n, H=32, L=1000, act_gain=1.0, min_done=0)
+            slim = dict(q0=g["q0"][:1], qd0=g["qd0"][:1], progress0=g["progress0"], rew=g["rew"], done=g["done"].astype(np.int8),
+                        progress=g["progress"].astype(np.int16), q_final=g["q_final"], loss=g["loss"], mm_freq=g["mm_freq"],
+                        episode_length=g["episode_length"], grad_actions_strided=g["grad_actions"][:, ::stride],
+                        actions_check=g["actions"][:, :2], w_check=g["w"][:2], stride=np.int64(stride), act_gain=np.float64(1.0),
+                        seed=np.int64(11))
+            np.savez_compressed(os.path.join(OUT, tag + ".npz"), **slim)
+            print("golden written:", tag, "restarts recorded:", int(g["done"].sum()))
     if "episodes_extra" in names:
         # the other environments' termination rules through the reference (humanoid: height + invalid-state checks,
         # humanoid.py:340-356; hopper: height, hopper.py:288-293; cartpole / cheetah: episode length only)
