@@ -300,7 +300,8 @@ class DFlexEnv:
             if full and self.fused and not getattr(self, "stochastic_init", False) and torch.device(self.device).type == "cuda":
                 # every environment back to the (deterministic) start state: two copies from the start-state pool
                 # instead of ~25 indexed writes
-                pool_q, pool_qd = self._episode_io().reset_q, self._episode_io().reset_qd
+                epi = self._episode_io()
+                pool_q, pool_qd = epi.reset_q, epi.reset_qd
                 self.state.joint_q, self.state.joint_qd = pool_q[0].reshape(-1).clone(), pool_qd[0].reshape(-1).clone()
                 self.actions = torch.zeros_like(self.actions)
             else:
