@@ -192,10 +192,16 @@ template <class Ctx> struct DsimAdofRegs {  // ... and few enough dofs for the a
     }();
 };
 // roles are "item index == lane": needs every loop of that role to be a single pass
-template <class Ctx> struct DsimRoleRegs {
+template <class Ctx> struct DsimRoleRegs {  // link `lane` and dof `lane`
     static constexpr bool value = []() {
         if constexpr (std::is_empty<decltype(Ctx::d)>::value)
-            return decltype(Ctx::d)::L <= DSIM_NL && decltype(Ctx::d)::nd <= DSIM_NL && decltype(Ctx::d)::C <= DSIM_NL;
+            return decltype(Ctx::d)::L <= DSIM_NL && decltype(Ctx::d)::nd <= DSIM_NL;
+        else return false;
+    }();
+};
+template <class Ctx> struct DsimContactRegs {  // contact `lane` / `63 - lane`
+    static constexpr bool value = []() {
+        if constexpr (std::is_empty<decltype(Ctx::d)>::value) return decltype(Ctx::d)::C <= DSIM_NL;
         else return false;
     }();
 };
@@ -233,6 +239,9 @@ template <class Ctx, class Exec> DSIM_FN void dsim_topo_init(const Ctx& c, Exec&
         tp.dof_type = CI(jtype)[l];
         tp.dof_cs = CI(qstart)[l];
         tp.dof_ds = CI(qdstart)[l];
+    }
+    if constexpr (DsimContactRegs<Ctx>::value) {
+        DsimTopoRegs& tp = ex.topo(lane);
         const int kf = lane < c.d.C ? lane : 0, kb = (DSIM_NL - 1 - lane) < c.d.C ? (DSIM_NL - 1 - lane) : 0;
         tp.cbody_f = c.d.C > 0 ? CI(cbody)[kf] : 0;
         tp.cbody_b = c.d.C > 0 ? CI(cbody)[kb] : 0;
@@ -376,7 +385,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Ex
     ex.run([&](int lane) {
         for (int k = lane; k < c.d.C; k += DSIM_NL) {
             int b;
-            if constexpr (DsimRoleRegs<Ctx>::value) b = ex.topo(lane).cbody_f;
+            if constexpr (DsimContactRegs<Ctx>::value) b = ex.topo(lane).cbody_f;
             else b = CI(cbody)[k];
             const v3 xp = ld3(WF(xsc) + 7 * b);
             const q4 xq = ldq(WF(xsc) + 7 * b + 3);
@@ -848,7 +857,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external_items(const Ctx&
             float* o = WF(acx) + 13 * k;
             for (int r = 0; r < 13; ++r) o[r] = 0.f;
             int b;
-            if constexpr (DsimRoleRegs<Ctx>::value) b = ex.topo(real_lane).cbody_b;
+            if constexpr (DsimContactRegs<Ctx>::value) b = ex.topo(real_lane).cbody_b;
             else b = CI(cbody)[k];
             const v3 xp = ld3(WF(xsc) + 7 * b);
             const q4 xq = ldq(WF(xsc) + 7 * b + 3);
