@@ -88,7 +88,18 @@ def time_backward_kernel(env, name, n, H, reps, device):
         eng.env_backward(spec, ck, acts, env.sim_dt, S, mm, gq, gqd, go, gr)
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e-3
+    t_bwd = e0.elapsed_time(e1) / reps * 1e-3
+    # the forward launch with checkpoint, same shapes (reported next to the adjoint's figure)
+    for _ in range(3):
+        eng.env_forward(spec, q, qd, acts, env.sim_dt, S, mm, True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        eng.env_forward(spec, q, qd, acts, env.sim_dt, S, mm, True)
+    e1.record()
+    torch.cuda.synchronize()
+    time_backward_kernel.fwd_s = e0.elapsed_time(e1) / reps * 1e-3
+    return t_bwd
 
 
 def cpu_baseline(name, budget_s=12.0):
@@ -223,13 +234,14 @@ def main():
             "eager_env_steps_per_s": eager_value,
             "roofline": {"bound": "hbm", "kernel": "dsim_env_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": t_bwd * 1e3, "alg_bytes_per_launch": bwd_bytes,
+                         "kernel_ms": t_bwd * 1e3, "fwd_kernel_ms": time_backward_kernel.fwd_s * 1e3,
+                         "alg_bytes_per_launch": bwd_bytes,
                          "note": "fused kernel is VALU/latency-bound by construction (SURVEY 8d); traffic >> algorithmic bytes on purpose: "
                                  "39.3 MB of it is the saved forward block the adjoint reads back instead of recomputing "
                                  "(measured 19 % faster; HBM is at ~3 % of peak either way), see DESIGN.md section 4"},
             # fp32 vector-ALU view of the same launch pair (SURVEY 8d asks for it next to the HBM fraction): ~1.2 MFLOP per
             # Ant env-step fwd+adjoint (SURVEY's op-count estimate) against the 157.3 TFLOP/s fp32 vector peak
-            "fp32_valu_frac_est": (1.2e6 * n / (t_bwd * (1.0 + 0.105 / 0.160))) / 157.3e12 if a.env == "ant" else None,
+            "fp32_valu_frac_est": (1.2e6 * n / (t_bwd + time_backward_kernel.fwd_s)) / 157.3e12 if a.env == "ant" else None,
         }
         # forward-only serving path (dflex.config.no_grad: no checkpoint traffic), SURVEY.md 8(f).4 -- informational
         with torch.no_grad():
