@@ -259,6 +259,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.env)
         print(json.dumps(out))
     if dist:
+        td.barrier()   # rank 0 is still measuring its extras (eager loop, CPU baseline): tear the group down together
         td.destroy_process_group()
 
 
