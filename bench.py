@@ -103,18 +103,30 @@ def time_backward_kernel(env, name, n, H, reps, device):
 
 
 def cpu_baseline(name, budget_s=12.0):
-    """scalar CPU oracle (oracle/dsim_oracle.cpp, a port of the reference's CPU path) on a bounded sample, one process
-    per host core (up to 32); run as a subprocess so that nothing GPU-related is forked"""
+    """CPU baseline beside the GPU number (oracle/cpu_baseline.py, a subprocess so that nothing GPU-related is forked):
+    the reference's own CPU path when its checkout is present (kind "reference"), otherwise the multi-threaded scalar
+    port oracle/dsim_oracle.cpp (kind "port") with the recorded reference figure attached."""
     import subprocess
     out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), name, str(budget_s)],
-                         capture_output=True, text=True, timeout=300)
+                         capture_output=True, text=True, timeout=600)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if not line:
         return {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": "failed: " + out.stderr[-200:]}
     return json.loads(line[-1])
 
 
-def main():
+def csrc_hash():
+    """identifies the kernel sources a measured figure belongs to (roofline.traffic is read from a committed PMC file)"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "diffrl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -122,34 +134,111 @@ def main():
     ap.add_argument("--env", default="ant")
     ap.add_argument("--envs-per-gpu", type=int, default=1024)
     ap.add_argument("--horizon", type=int, default=32)
+    ap.add_argument("--mm-freq", type=int, default=0, help="MM_caching_frequency (0: the examples/cfg/shac value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="time the Python-driven step loop instead of the graph replay")
-    a = ap.parse_args()
+    ap.add_argument("--strict", action="store_true", help="exit non-zero if the graph capture fell back to the eager loop")
+    ap.add_argument("--launcher", action="store_true",
+                    help="go through torch.distributed.run even for --gpus 1 (an RCCL group of one rank)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch the ranks, rendezvous, exchange the timing all-reduce and print the JSON skeleton, "
+                         "without touching the GPU engine (CPU test of the launcher; backend gloo when no GPU is visible)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N` run directly (no torch.distributed.run around it): become the launcher.
+    One process per GPU, rendezvous on 127.0.0.1; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    if not a.dry_run or torch.cuda.is_available():
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < a.gpus:
+            sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible on this node; refusing to "
+                             "report a smaller job under the requested label\n" % (a.gpus, have))
+            return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    a = parse_args(argv)
+    if a.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        return 2
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not under_launcher and (a.gpus > 1 or a.launcher or a.dry_run):
+        return launch_ranks(a, argv)
 
     from diffrl_amd import sharding
     rank, local, world = sharding.world()
-    dist = world > 1 or "RANK" in os.environ   # launched by torch.distributed.run: RCCL process group even for one rank
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
+    if world != a.gpus:
+        sys.stderr.write("bench.py: launched with WORLD_SIZE=%d but --gpus %d; the label must match the job\n" % (world, a.gpus))
+        return 2
+    dist = under_launcher   # launched by torch.distributed.run: RCCL process group even for one rank
+    use_gpu = torch.cuda.is_available()
+    if not use_gpu and not a.dry_run:
+        sys.stderr.write("bench.py: no GPU visible; this benchmark has no CPU path\n")
+        return 2
+    if use_gpu:
+        if torch.cuda.device_count() <= local:
+            sys.stderr.write("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d visible)\n" % (rank, local, torch.cuda.device_count()))
+            return 2
+        device = torch.device("cuda", local)
+        torch.cuda.set_device(device)
+    else:
+        device = torch.device("cpu")
+    rccl_ranks = 1
     if dist:
         import torch.distributed as td
-        sharding.init("nccl", device)
-
-    n, H = a.envs_per_gpu, a.horizon
-    env = make_env(a.env, n, str(device))
-    gen = torch.Generator().manual_seed(1 + rank)
-    actions = torch.tanh(2.0 * torch.rand((H, n, env.num_actions), generator=gen) - 1.0).to(device)
+        sharding.init("nccl" if use_gpu else "gloo", device if use_gpu else None)
+        rccl_ranks = td.get_world_size()
+        assert rccl_ranks == a.gpus
 
     def barrier():
         if dist:
             td.barrier()
-        torch.cuda.synchronize()
+        if use_gpu:
+            torch.cuda.synchronize()
+
+    n, H = a.envs_per_gpu, a.horizon
+    mm = a.mm_freq or MM_FREQ[a.env]
+    lo, hi = sharding.shard_range(n * world, rank, world)   # this rank's env-index range of the whole job
+    if a.dry_run:
+        barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (1 + rank))
+        barrier()
+        el = sharding.max_over_ranks(time.perf_counter() - t0, device)
+        owned = sharding.sum_over_ranks(hi - lo, device)
+        if rank == 0:
+            print(json.dumps({"metric": "fwd+adjoint env-steps/sec", "dry_run": True, "value": None, "unit": "env-steps/s",
+                              "n_gpus": world, "rccl_ranks": rccl_ranks, "backend": "nccl" if use_gpu else "gloo",
+                              "steps": a.steps, "warmup": a.warmup, "scaling": "weak", "envs_total": int(owned),
+                              "slowest_rank_s": el,
+                              "config": {"workload": "%s %d envs/GPU x H=%d" % (a.env, n, H), "envs_per_gpu": n}}))
+        if dist:
+            td.barrier()
+            td.destroy_process_group()
+        return 0
+
+    MM_FREQ[a.env] = mm
+    env = make_env(a.env, n, str(device))
+    gen = torch.Generator().manual_seed(1 + rank)
+    actions = torch.tanh(2.0 * torch.rand((H, n, env.num_actions), generator=gen) - 1.0).to(device)
 
     import gc
-    ap_eager = a.eager
     submission = "eager: one launch per env.step each way, issued from the Python loop"
+    fallback = False
     roll = None
-    if not ap_eager:
+    if not a.eager:
         # whole rollout (32 x DFlexEnv.step + the backward sweep) captured once as a HIP graph, replayed as one submission
         # (SURVEY.md 8(f).2, diffrl_amd/graph.py).  Every replay re-executes all 64 launches on the same inputs.
         try:
@@ -168,10 +257,12 @@ def main():
             roll.replay()
             torch.cuda.synchronize()
             assert torch.equal(acts.grad, g_eager), "graph replay and eager rollout disagree"
-            submission = "one HIP graph per rollout: the 32 forward + 32 adjoint launches captured through DFlexEnv.step"
-        except Exception as ex:  # capture unsupported on this stack: measure the eager loop instead, and say so
+            submission = "one HIP graph per rollout: the %d forward + %d adjoint launches captured through DFlexEnv.step" % (H, H)
+        except Exception as ex:  # capture unsupported on this stack: measure the eager loop instead, and say so LOUDLY
             roll = None
+            fallback = True
             submission = "eager (graph capture failed: %s)" % str(ex)[:120]
+            sys.stderr.write("bench.py: WARNING graph capture failed, timing the eager loop instead: %s\n" % str(ex)[:300])
 
     def one():
         if roll is not None:
@@ -216,43 +307,56 @@ def main():
         na_in = env.model.muscles_per_articulation if env.model.muscle_count else nd
         bwd_bytes = 4 * n * ((nq + nd + na_in) + (nq + nd) + (nq + nd + na_in))
         achieved = bwd_bytes / t_bwd / 1e9
-        traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
+        # HBM bytes of one adjoint launch.  Measured: the committed PMC passes (rocprofv3 cannot run inside this process),
+        # valid only for the kernel sources they were taken at (csrc hash) and for that env / N.  Otherwise the analytic
+        # figure: the adjoint reads its whole checkpoint (dsim_ckpt_floats_mm floats per environment) plus the boundary tensors.
+        eng = env.model.engine()
+        ckpt_floats = int(eng._lib.dsim_ckpt_floats_mm(eng._h, env.sim_substeps, mm))
+        traffic_analytic = 4 * n * ckpt_floats + bwd_bytes
+        traffic, traffic_src = traffic_analytic, "analytic: checkpoint words x N x 4 + boundary tensors"
         try:
-            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_final_pmc.json"))
-            pmc = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
-            if a.env == "ant" and n == 1024 and pmc.get("kernel") in ("dsim_bwd_kernel", "dsim_env_bwd_kernel"):
-                traffic = pmc["traffic_bytes_per_launch"]
+            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
+            for f in reversed(pmcs):
+                pmc = json.load(open(os.path.join(ROOT, "profiles", f)))
+                if (pmc.get("env", "ant") == a.env and pmc.get("n_envs", 1024) == n and pmc.get("mm_freq", MM_FREQ[a.env]) == mm
+                        and pmc.get("csrc_hash") == csrc_hash()):
+                    traffic, traffic_src = pmc["traffic_bytes_per_launch"], "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/" + f
+                    break
         except Exception:
-            traffic = None
+            pass
         out = {
             "metric": "fwd+adjoint env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
+            "rccl_ranks": rccl_ranks,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %d envs/GPU x H=%d through DFlexEnv.step, loss=-sum(rew), 1 backward"
-                                   % (a.env, n, H), "envs_per_gpu": n, "horizon": H, "substeps": env.sim_substeps,
-                       "mm_freq": MM_FREQ[a.env], "sharding": "envs by index, no collective", "submission": submission},
+                                   % (a.env, n, H), "envs_per_gpu": n, "envs_total": n * world, "horizon": H,
+                       "substeps": env.sim_substeps,
+                       "mm_freq": mm, "sharding": "envs by index, no collective", "submission": submission,
+                       "submission_fallback": fallback},
             "eager_env_steps_per_s": eager_value,
             "roofline": {"bound": "hbm", "kernel": "dsim_env_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "csrc_hash": csrc_hash(), "ckpt_bytes_per_env_step": 4 * ckpt_floats,
+                         "ckpt_bytes_per_rollout": 4 * ckpt_floats * n * H,
                          "kernel_ms": t_bwd * 1e3, "fwd_kernel_ms": time_backward_kernel.fwd_s * 1e3,
                          "alg_bytes_per_launch": bwd_bytes,
                          "note": "fused kernel is VALU/latency-bound by construction (SURVEY 8d); traffic >> algorithmic bytes on purpose: "
-                                 "39.3 MB of it is the saved forward block the adjoint reads back instead of recomputing "
-                                 "(measured 19 % faster; HBM is at ~3 % of peak either way), see DESIGN.md section 4"},
+                                 "the saved forward block the adjoint reads back instead of recomputing, see DESIGN.md section 4"},
             # fp32 vector-ALU view of the same launch pair (SURVEY 8d asks for it next to the HBM fraction): ~1.2 MFLOP per
             # Ant env-step fwd+adjoint (SURVEY's op-count estimate) against the 157.3 TFLOP/s fp32 vector peak
             "fp32_valu_frac_est": (1.2e6 * n / (t_bwd + time_backward_kernel.fwd_s)) / 157.3e12 if a.env == "ant" else None,
         }
         # forward-only serving path (dflex.config.no_grad: no checkpoint traffic), SURVEY.md 8(f).4 -- informational
         with torch.no_grad():
-            eng, spec = env.model.engine(), env._spec()
+            spec = env._spec()
             q, qd = env.state.joint_q.detach().clone(), env.state.joint_qd.detach().clone()
             for _ in range(5):
-                eng.env_forward(spec, q, qd, actions[0], env.sim_dt, env.sim_substeps, MM_FREQ[a.env], False)
+                eng.env_forward(spec, q, qd, actions[0], env.sim_dt, env.sim_substeps, mm, False)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for t in range(100):
-                q, qd, _, _, _ = eng.env_forward(spec, q, qd, actions[t % H], env.sim_dt, env.sim_substeps, MM_FREQ[a.env], False)
+                q, qd, _, _, _ = eng.env_forward(spec, q, qd, actions[t % H], env.sim_dt, env.sim_substeps, mm, False)
             torch.cuda.synchronize()
             out["no_grad_forward_env_steps_per_s"] = 100 * n / (time.perf_counter() - t0)
         if not a.no_cpu_baseline:
@@ -261,7 +365,11 @@ def main():
     if dist:
         td.barrier()   # rank 0 is still measuring its extras (eager loop, CPU baseline): tear the group down together
         td.destroy_process_group()
+    if fallback and a.strict:
+        sys.stderr.write("bench.py: --strict and the graph capture fell back to the eager loop\n")
+        return 3
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -108,6 +108,7 @@ class DsimError(RuntimeError):
 
 
 _lib = None
+EXPECTED_ABI = 103   # dsim_version() of the library this binding was written against (argument lists of include/dsim.h)
 
 
 def lib():
@@ -122,6 +123,10 @@ def lib():
     vp = C.c_void_p
     L.dsim_last_error.restype = C.c_char_p
     L.dsim_version.restype = C.c_int
+    if int(L.dsim_version()) != EXPECTED_ABI:
+        raise DsimError("%s reports ABI version %d, this binding expects %d: stale build or a DSIM_LIB override built "
+                        "against other argument lists; rebuild (DSIM_FORCE_REBUILD=1 python __graft_entry__.py)"
+                        % (LIB_PATH, int(L.dsim_version()), EXPECTED_ABI))
     L.dsim_model_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp)]
     L.dsim_model_destroy.argtypes = [vp]
     L.dsim_model_variant.argtypes = [vp]

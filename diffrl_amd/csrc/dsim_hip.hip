@@ -366,7 +366,7 @@ int make_spec(const dsim_model* m, const dsim_env_spec* e, DsimEnvSpec& sp) {
 extern "C" {
 
 const char* dsim_last_error(void) { return g_err.c_str(); }
-int dsim_version(void) { return 102; }
+int dsim_version(void) { return 103; }
 
 int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
     if (!desc || !out) return fail(DSIM_ERR_INVALID, "null argument");
@@ -387,21 +387,19 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
     if (e == hipSuccess)
         e = hipMemcpy(m->d_cblob, m->lay.cblob.data(), sizeof(uint32_t) * m->lay.cblob.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess && (bytes > 64 * 1024 || fbytes > 64 * 1024)) {
-        // opt in to > 64 KiB of dynamic LDS for this model's kernel variant
+        // Opt in to > 64 KiB of dynamic LDS.  The attribute belongs to the kernel FUNCTION, not to this model: two models
+        // that share a kernel variant (e.g. two user models on the generic kernels) must not lower each other's limit,
+        // so it is set once to the hardware maximum (160 KiB); what a launch actually gets is its own byte count.
         dispatch(m, [&](auto o, auto d) {
             using O = decltype(o);
             using D = decltype(d);
-            const void* fns_bwd[] = {reinterpret_cast<const void*>(dsim_bwd_kernel<O, D>),
-                                     reinterpret_cast<const void*>(dsim_env_bwd_kernel<O, D>)};
-            const void* fns_fwd[] = {reinterpret_cast<const void*>(dsim_fwd_kernel<O, D>),
-                                     reinterpret_cast<const void*>(dsim_env_fwd_kernel<O, D>),
-                                     reinterpret_cast<const void*>(dsim_env_obs_kernel<O, D>)};
-            for (const void* fn : fns_bwd)
-                if (e == hipSuccess && bytes > 64 * 1024)
-                    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            for (const void* fn : fns_fwd)
-                if (e == hipSuccess && fbytes > 64 * 1024)
-                    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, fbytes);
+            const void* fns[] = {reinterpret_cast<const void*>(dsim_bwd_kernel<O, D>),
+                                 reinterpret_cast<const void*>(dsim_env_bwd_kernel<O, D>),
+                                 reinterpret_cast<const void*>(dsim_fwd_kernel<O, D>),
+                                 reinterpret_cast<const void*>(dsim_env_fwd_kernel<O, D>),
+                                 reinterpret_cast<const void*>(dsim_env_obs_kernel<O, D>)};
+            for (const void* fn : fns)
+                if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             return 0;
         });
     }

@@ -22,9 +22,10 @@ ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
 
 
 def find_asset(name):
-    """Original asset file if available ($DIFFRL_ASSETS, the package's assets/ dir, or a reference
-    checkout), else None -> the environment falls back to its compiled asset (.npz builder snapshot)."""
-    roots = [os.environ.get("DIFFRL_ASSETS"), ASSET_DIR, "/root/reference/envs/assets"]
+    """Original asset file if available ($DIFFRL_ASSETS or the package's assets/ dir), else None -> the
+    environment falls back to its compiled asset (.npz builder snapshot).  No other location is searched: what a
+    library call loads must not depend on what else happens to be on the box."""
+    roots = [os.environ.get("DIFFRL_ASSETS"), ASSET_DIR]
     for r in roots:
         if r and os.path.exists(os.path.join(r, name)):
             return os.path.join(r, name)

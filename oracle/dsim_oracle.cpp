@@ -36,6 +36,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../include/dsim.h"
@@ -728,15 +729,15 @@ int dsim_oracle_step_forward(const dsim_model_desc* m, int n_envs, const float* 
     return 0;
 }
 
-// Forward (taped) + reverse sweep.  Gradients are written (not accumulated).
-int dsim_oracle_step_backward(const dsim_model_desc* m, int n_envs, const float* q_in, const float* qd_in,
-                              const float* act, const float* muscle_act, float dt, int substeps, int mm_freq,
-                              const float* gq_out, const float* gqd_out, float* gq_in, float* gqd_in, float* gact,
-                              float* gmuscle_act, float* q_out, float* qd_out) {
+// Forward (taped) + reverse sweep of environments [e0, e1).  Gradients are written (not accumulated).
+static void backward_range(const dsim_model_desc* m, int e0, int e1, const float* q_in, const float* qd_in,
+                           const float* act, const float* muscle_act, float dt, int substeps, int mm_freq,
+                           const float* gq_out, const float* gqd_out, float* gq_in, float* gqd_in, float* gact,
+                           float* gmuscle_act, float* q_out, float* qd_out) {
     const int nq = m->n_q, nd = m->n_qd, M = m->n_muscles;
     Tape tape;
     g_tape = &tape;
-    for (int e = 0; e < n_envs; ++e) {
+    for (int e = e0; e < e1; ++e) {
         tape.clear();
         std::vector<Var> q(nq), qd(nd), a(nd), ma(M);
         for (int k = 0; k < nq; ++k) q[k] = leaf(q_in[(size_t)e * nq + k]);
@@ -763,6 +764,33 @@ int dsim_oracle_step_backward(const dsim_model_desc* m, int n_envs, const float*
             for (int k = 0; k < nd; ++k) qd_out[(size_t)e * nd + k] = qd[k].v;
     }
     g_tape = nullptr;
+}
+
+int dsim_oracle_step_backward(const dsim_model_desc* m, int n_envs, const float* q_in, const float* qd_in,
+                              const float* act, const float* muscle_act, float dt, int substeps, int mm_freq,
+                              const float* gq_out, const float* gqd_out, float* gq_in, float* gqd_in, float* gact,
+                              float* gmuscle_act, float* q_out, float* qd_out) {
+    backward_range(m, 0, n_envs, q_in, qd_in, act, muscle_act, dt, substeps, mm_freq, gq_out, gqd_out, gq_in, gqd_in,
+                   gact, gmuscle_act, q_out, qd_out);
+    return 0;
+}
+
+// The same over `n_threads` host threads (environments are independent: contiguous env ranges, one tape per
+// thread; results are identical to the single-threaded call).  Used by the CPU-baseline leg of bench.py, which
+// reports the thread count it ran with.
+int dsim_oracle_step_backward_mt(const dsim_model_desc* m, int n_envs, int n_threads, const float* q_in,
+                                 const float* qd_in, const float* act, const float* muscle_act, float dt, int substeps,
+                                 int mm_freq, const float* gq_out, const float* gqd_out, float* gq_in, float* gqd_in,
+                                 float* gact, float* gmuscle_act, float* q_out, float* qd_out) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > n_envs) n_threads = n_envs;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; ++t) {
+        const int e0 = (int)((long long)n_envs * t / n_threads), e1 = (int)((long long)n_envs * (t + 1) / n_threads);
+        pool.emplace_back(backward_range, m, e0, e1, q_in, qd_in, act, muscle_act, dt, substeps, mm_freq, gq_out, gqd_out,
+                          gq_in, gqd_in, gact, gmuscle_act, q_out, qd_out);
+    }
+    for (auto& th : pool) th.join();
     return 0;
 }
 

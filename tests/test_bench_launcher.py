@@ -1,0 +1,62 @@
+"""bench.py as its own launcher: `python bench.py --gpus N` run directly must produce N ranks
+(one process per GPU through torch.distributed.run, rendezvous on 127.0.0.1) or fail loudly -- never report a
+smaller job under the requested label.  CPU: the launcher path with `--dry-run` (gloo, stops before the GPU engine).
+GPU: the real benchmark through the launcher with an RCCL group of one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, timeout=600, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+
+
+def _json_line(out):
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line expected, got: %r / stderr %r" % (out.stdout[-500:], out.stderr[-500:])
+    return json.loads(lines[0])
+
+
+def test_dry_run_launches_two_ranks_on_cpu():
+    out = _run(["--gpus", "2", "--dry-run", "--envs-per-gpu", "1024"], env={"CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": ""})
+    assert out.returncode == 0, out.stderr[-800:]
+    j = _json_line(out)
+    assert j["dry_run"] is True and j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["backend"] == "gloo"
+    assert j["envs_total"] == 2048 and j["scaling"] == "weak"          # every env owned by exactly one rank
+    assert j["slowest_rank_s"] >= 0.02                                     # MAX over ranks (rank 1 sleeps longer)
+
+
+def test_more_gpus_than_visible_fails_loudly():
+    """a `--gpus 2` invocation on a box with fewer GPUs must not print `n_gpus: 1`"""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    out = _run(["--gpus", str(max(have + 1, 2)), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    assert out.returncode != 0
+    assert "GPU(s) are visible" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_world_size_must_match_label():
+    out = _run(["--gpus", "2", "--dry-run"], env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
+                                                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
+    assert out.returncode != 0 and "label must match" in out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_through_the_launcher_rccl_group_of_one():
+    out = _run(["--gpus", "1", "--launcher", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--strict"], timeout=900)
+    assert out.returncode == 0, out.stderr[-1500:]
+    j = _json_line(out)
+    assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1 and j["steps"] == 2
+    assert j["config"]["submission_fallback"] is False
+    assert j["value"] > 1e5 and j["roofline"]["traffic"] > j["roofline"]["alg_bytes_per_launch"]

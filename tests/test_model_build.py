@@ -2,6 +2,8 @@
 (tests/golden/<env>_model.npz, dumped from the reference's builder) -- from the original asset files
 when they are available and from the compiled assets (.npz builder snapshots) always."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -43,7 +45,11 @@ def test_compiled_asset_matches_reference_model(env, cls, monkeypatch):
 
 
 @pytest.mark.parametrize("env,cls", CASES)
-def test_loader_matches_reference_model(env, cls):
+def test_loader_matches_reference_model(env, cls, monkeypatch):
+    # the library only looks in $DIFFRL_ASSETS / its own assets dir: the test names the reference's asset dir explicitly
+    ref_assets = os.path.join(os.environ.get("DIFFRL_REFERENCE", "/root/reference"), "envs", "assets")
+    if os.path.isdir(ref_assets) and not os.environ.get("DIFFRL_ASSETS"):
+        monkeypatch.setenv("DIFFRL_ASSETS", ref_assets)
     probe = {"ant": "ant.xml", "humanoid": "humanoid.xml", "snu": "snu/human.xml", "cartpole": "cartpole.urdf",
              "hopper": "hopper.xml", "cheetah": "half_cheetah.xml"}[env]
     if de.find_asset(probe) is None:
