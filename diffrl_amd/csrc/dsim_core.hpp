@@ -92,10 +92,13 @@ DSIM_FN float dsim_range_sum_b(const float* data, int stride, int comp, int firs
 // Bounds: whole lists for small trees (each lane makes one pass over its items); 8 for larger models, where the lanes
 // loop over several items and loading a long mostly-unused tail per item costs more issue slots than it saves latency.
 template <class D> constexpr int dsim_cap_links() { return D::L <= 10 ? D::L : 8; }
-template <class D> constexpr int dsim_cap_subtree_contacts() { return D::C >= 8 ? 8 : (D::C > 0 ? D::C : 1); }
+template <class D> constexpr int dsim_cap_subtree_contacts() { return D::C > 32 ? 8 : (D::C > 0 ? D::C : 1); }
 template <class D> constexpr int dsim_cap_body_contacts() { return D::C >= 8 ? 8 : (D::C > 0 ? D::C : 1); }
 struct __attribute__((aligned(16), may_alias)) dsim_i4 {
     int x, y, z, w;
+};
+struct __attribute__((aligned(16), may_alias)) dsim_f4 {
+    float x, y, z, w;
 };
 
 // packed per-link record (dsim_layout.hpp: linfo): two 16-byte LDS reads instead of a chain of dependent 4-byte reads
@@ -263,102 +266,154 @@ template <class Ctx, class Exec> DSIM_FN void dsim_topo_init(const Ctx& c, Exec&
     }
 }
 
+// compile-time loop with a constexpr index (per-position joint-type masks of the specialised kernels)
+template <int I, int N, class F> DSIM_FN void dsim_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        dsim_static_for<I + 1, N>(f);
+    }
+}
+// joint types that can occur at chain position P (specialised kernels: a compile-time constant, so the branches of
+// types that do not occur there -- and their loads -- are not even compiled)
+template <class D, int P> constexpr int dsim_pos_mask() { return P < DSIM_PMASK_N ? D::pmask[P] : D::tmask; }
+// number of joint coordinates / dofs a lane must fetch for a joint whose type is in `mask`
+DSIM_FN constexpr int dsim_mask_nq(int mask) {
+    return (mask & DSIM_TM(DSIM_JOINT_FREE)) ? 7 : (mask & DSIM_TM(DSIM_JOINT_BALL)) ? 4
+           : (mask & (DSIM_TM(DSIM_JOINT_PRISMATIC) | DSIM_TM(DSIM_JOINT_REVOLUTE))) ? 1 : 0;
+}
+DSIM_FN constexpr int dsim_mask_nd(int mask) {
+    return (mask & DSIM_TM(DSIM_JOINT_FREE)) ? 6 : (mask & DSIM_TM(DSIM_JOINT_BALL)) ? 3
+           : (mask & (DSIM_TM(DSIM_JOINT_PRISMATIC) | DSIM_TM(DSIM_JOINT_REVOLUTE))) ? 1 : 0;
+}
+
+// What a link's lane carries along its ancestor chain, and what it keeps of its OWN (last) position.
+struct DsimFkWalk {
+    v3 psp;   // pose of the previous chain position (parent link)
+    q4 rsp;
+    sv6 v, a;
+    // own joint (valid after the last position)
+    v3 pj;
+    q4 rj;
+    sv6 s0, s1, s2;  // motion subspace columns of the own joint (prismatic / revolute: s0; ball: s0..s2; free: identity, not stored)
+};
+
+// One chain position: joint `j` of type `type` (coordinates at cs, dofs at ds) on top of the pose in w.  MASK: joint
+// types that can occur here.  Everything the position needs is LOADED FIRST (one LDS round trip; the words past a
+// joint's own coordinates are fetched but never used), then it is pure register arithmetic: no stores -- the lane
+// writes its results once, after the walk, so that no load of a later position has to wait behind a store.
+template <int MASK, class Ctx> DSIM_FN void dsim_fk_position(const Ctx& c, DsimFkWalk& w, int j, int type, int cs, int ds) {
+    constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
+    const float *q = WF(q), *qd = WF(qd);
+    const v3 ppj = ld3(CF(xpj) + 7 * j);
+    const q4 rpj = ldq(CF(xpj) + 7 * j + 3);
+    const v3 axis = ld3(CF(axis) + 3 * j);
+    float qv[NQ > 0 ? NQ : 1], qdv[NDF > 0 ? NDF : 1];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) qv[k] = q[cs + k];
+#pragma unroll
+    for (int k = 0; k < NDF; ++k) qdv[k] = qd[ds + k];
+    const v3 pj = rotate(w.rsp, ppj) + w.psp;
+    const q4 rj = qmul(w.rsp, rpj);
+    v3 pc = pj;
+    q4 rc = rj;
+    sv6 vj = zerosv();
+    if constexpr ((MASK & DSIM_TM(DSIM_JOINT_PRISMATIC)) != 0) {
+        if (type == DSIM_JOINT_PRISMATIC) {
+            const v3 u = rotate(rj, axis);
+            pc = pj + u * qv[0];
+            w.s0 = mksv(zero3(), u);
+            vj = w.s0 * qdv[0];
+        }
+    }
+    if constexpr ((MASK & DSIM_TM(DSIM_JOINT_REVOLUTE)) != 0) {
+        if (type == DSIM_JOINT_REVOLUTE) {
+            rc = qmul(rj, quat_axis_angle(axis, qv[0]));
+            const v3 u = rotate(rj, axis);
+            w.s0 = mksv(u, cross(pj, u));
+            vj = w.s0 * qdv[0];
+        }
+    }
+    if constexpr ((MASK & DSIM_TM(DSIM_JOINT_BALL)) != 0) {
+        if (type == DSIM_JOINT_BALL) {
+            rc = qmul(rj, mkq(qv[0], qv[1], qv[2], qv[3]));
+            const v3 u0 = rotate(rj, mk3(1.f, 0.f, 0.f)), u1 = rotate(rj, mk3(0.f, 1.f, 0.f)), u2 = rotate(rj, mk3(0.f, 0.f, 1.f));
+            w.s0 = mksv(u0, cross(pj, u0));
+            w.s1 = mksv(u1, cross(pj, u1));
+            w.s2 = mksv(u2, cross(pj, u2));
+            vj += w.s0 * qdv[0];
+            vj += w.s1 * qdv[1];
+            vj += w.s2 * qdv[2];
+        }
+    }
+    if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
+        if (type == DSIM_JOINT_FREE) {
+            pc = rotate(rj, mk3(qv[0], qv[1], qv[2])) + pj;
+            rc = qmul(rj, mkq(qv[3], qv[4], qv[5], qv[6]));
+            vj = mksv(mk3(qdv[0], qdv[1], qdv[2]), mk3(qdv[3], qdv[4], qdv[5]));  // S = identity (dsim_init_static)
+        }
+    }
+    w.v = w.v + vj;
+    w.a = w.a + scross(w.v, vj);
+    w.pj = pj;
+    w.rj = rj;
+    w.psp = pc;
+    w.rsp = rc;
+}
+
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, Exec& ex) {
     ex.mark(1);
     // "Flat" forward kinematics: every link's lane walks its own ancestor chain from the root and recomputes the
-    // joint transforms / twists on the way, instead of one barrier-separated phase per tree level.  A phase costs
-    // ~2k cycles whatever it computes (LDS round trips of a single wavefront) and most lanes idle anyway, so the
-    // redundant arithmetic (depth x ~250 instructions) is cheaper than depth x phases; results are identical to the
-    // level-synchronous form (same operations in the same order along each chain).
+    // joint transforms / twists on the way, instead of one barrier-separated phase per tree level (redundant
+    // arithmetic, no per-level phase boundaries; same operations in the same order along each chain as the
+    // level-synchronous form), then goes straight on to the world inertia and the body force from registers.
+    // Nothing is stored before the end of the walk: LDS stores in between would serialise the next position's loads
+    // behind them (the compiler cannot prove that they do not alias).
     ex.run([&](int lane) {
         for (int i = lane; i < c.d.L; i += DSIM_NL) {
-            const float *q = WF(q), *qd = WF(qd);
-            v3 psp = zero3();
-            q4 rsp = mkq(0.f, 0.f, 0.f, 1.f);
-            sv6 v = zerosv(), a = zerosv();
-            // one chain position: link j (joint type, coordinate / dof offsets); own: j == i, this lane owns its outputs
-            auto position = [&](int j, int type, int cs, int ds, bool own) {
-                const v3 ppj = ld3(CF(xpj) + 7 * j);
-                const q4 rpj = ldq(CF(xpj) + 7 * j + 3);
-                const v3 pj = rotate(rsp, ppj) + psp;
-                const q4 rj = qmul(rsp, rpj);
-                const v3 axis = ld3(CF(axis) + 3 * j);
-                v3 pc = pj;
-                q4 rc = rj;
-                sv6 vj = zerosv();
-                float* S = WF(S);
-                if (type == DSIM_JOINT_PRISMATIC) {
-                    const v3 u = rotate(rj, axis);
-                    pc = pj + u * q[cs];
-                    const sv6 s = mksv(zero3(), u);
-                    if (own) stsv(S + 6 * ds, s);
-                    vj = s * qd[ds];
-                } else if (type == DSIM_JOINT_REVOLUTE) {
-                    rc = qmul(rj, quat_axis_angle(axis, q[cs]));
-                    const v3 w = rotate(rj, axis);
-                    const sv6 s = mksv(w, cross(pj, w));
-                    if (own) stsv(S + 6 * ds, s);
-                    vj = s * qd[ds];
-                } else if (type == DSIM_JOINT_BALL) {
-                    rc = qmul(rj, ldq(q + cs));
-                    for (int k = 0; k < 3; ++k) {
-                        const v3 ek = mk3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f);
-                        const v3 w = rotate(rj, ek);
-                        const sv6 s = mksv(w, cross(pj, w));
-                        if (own) stsv(S + 6 * (ds + k), s);
-                        vj += s * qd[ds + k];
-                    }
-                } else if (type == DSIM_JOINT_FREE) {
-                    pc = rotate(rj, ld3(q + cs)) + pj;
-                    rc = qmul(rj, ldq(q + cs + 3));
-                    vj = ldsv(qd + ds);  // S = identity, written once by dsim_init_static
-                }
-                v = v + vj;
-                a = a + scross(v, vj);
-                if (own) {
-                    st3(WF(xsj) + 7 * i, pj);
-                    stq(WF(xsj) + 7 * i + 3, rj);
-                    st3(WF(xsc) + 7 * i, pc);
-                    stq(WF(xsc) + 7 * i + 3, rc);
-                    stsv(WF(vj) + 6 * i, vj);
-                    stsv(WF(v) + 6 * i, v);
-                    stsv(WF(a) + 6 * i, a);
-                }
-                psp = pc;
-                rsp = rc;
-            };
-            bool walked = false;
+            DsimFkWalk w;
+            w.psp = zero3();
+            w.rsp = mkq(0.f, 0.f, 0.f, 1.f);
+            w.v = zerosv();
+            w.a = zerosv();
+            w.s0 = w.s1 = w.s2 = zerosv();
+            int own_type, own_ds;
             if constexpr (DsimChainRegs<Ctx>::value) {
-                constexpr int DEPTH = decltype(c.d)::D;
+                using D = decltype(c.d);
                 const int* ch = ex.topo(lane).chain;
                 const int n = ch[4 * DSIM_CHAIN_MAX];
-#pragma unroll
-                for (int p = 0; p < DEPTH; ++p)
-                    if (p < n) position(ch[4 * p], ch[4 * p + 1], ch[4 * p + 2], ch[4 * p + 3], p == n - 1);
-                walked = true;
-            }
-            if (!walked) {
+                dsim_static_for<0, D::D>([&](auto P) {
+                    constexpr int p = decltype(P)::value;
+                    if (p < n) dsim_fk_position<dsim_pos_mask<D, p>()>(c, w, ch[4 * p], ch[4 * p + 1], ch[4 * p + 2], ch[4 * p + 3]);
+                });
+                own_type = ex.topo(lane).own_type;
+                own_ds = ex.topo(lane).own_ds;
+            } else {
                 const int e0 = CI(anc_start)[i], e1 = CI(anc_start)[i + 1];
+                DsimLinkInfo li{};
                 for (int e = e0; e < e1; ++e) {
                     const int j = CI(anc_list)[e];
-                    const DsimLinkInfo li = dsim_link_info(c, j);
-                    position(j, li.type, li.cs, li.ds, e == e1 - 1);
+                    li = dsim_link_info(c, j);
+                    dsim_fk_position<0x1f>(c, w, j, li.type, li.cs, li.ds);
                 }
+                own_type = li.type;
+                own_ds = li.ds;
             }
-            // same lane, same phase: COM, world inertia and body force of link i from the values still in registers
-            const v3 pc = psp;
-            const q4 rc = rsp;
-            const v3 cm = rotate(rc, ld3(CF(com) + 3 * i)) + pc;
-            st3(WF(pm) + 3 * i, cm);
-            // world-frame inertia about the origin: Theta = R Ic R^T, A = Theta + m(c.c 1 - c c^T), h = m c
-            const float* ic = CF(ic6) + 6 * i;
+            // COM, world inertia and body force of link i from the values still in registers
+            const v3 pc = w.psp;
+            const q4 rc = w.rsp;
+            const v3 com = ld3(CF(com) + 3 * i);
+            const float* icp = CF(ic6) + 6 * i;
+            const float ic0 = icp[0], ic1 = icp[1], ic2 = icp[2], ic3 = icp[3], ic4 = icp[4], ic5 = icp[5];
             const float m = CF(mass)[i];
+            const v3 grav = ld3(CF(grav));
+            const v3 cm = rotate(rc, com) + pc;
+            // world-frame inertia about the origin: Theta = R Ic R^T, A = Theta + m(c.c 1 - c c^T), h = m c
             const v3 rx = rotate(rc, mk3(1.f, 0.f, 0.f)), ry = rotate(rc, mk3(0.f, 1.f, 0.f)),
                      rz = rotate(rc, mk3(0.f, 0.f, 1.f));
             // B = R * Ic (columns of R are rx, ry, rz)
-            const v3 b0 = rx * ic[0] + ry * ic[1] + rz * ic[2];
-            const v3 b1 = rx * ic[1] + ry * ic[3] + rz * ic[4];
-            const v3 b2 = rx * ic[2] + ry * ic[4] + rz * ic[5];
+            const v3 b0 = rx * ic0 + ry * ic1 + rz * ic2;
+            const v3 b1 = rx * ic1 + ry * ic3 + rz * ic4;
+            const v3 b2 = rx * ic2 + ry * ic4 + rz * ic5;
             inertia10 I;
             I.m = m;
             I.h = cm * m;
@@ -369,11 +424,24 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
             I.ayy = b0.y * rx.y + b1.y * ry.y + b2.y * rz.y + m * (cc - cm.y * cm.y);
             I.ayz = b0.y * rx.z + b1.y * ry.z + b2.y * rz.z - m * cm.y * cm.z;
             I.azz = b0.z * rx.z + b1.z * ry.z + b2.z * rz.z + m * (cc - cm.z * cm.z);
-            st_i10(WF(i10) + 10 * i, I);
-            const sv6 fb = inertia_mul(I, a) + scross_dual(v, inertia_mul(I, v));
-            const v3 mg = ld3(CF(grav)) * m;
+            const sv6 fb = inertia_mul(I, w.a) + scross_dual(w.v, inertia_mul(I, w.v));
+            const v3 mg = grav * m;
             const sv6 fg = mksv(cross(cm, mg), mg);
+            // ---- all stores of the phase
+            st3(WF(xsc) + 7 * i, pc);
+            stq(WF(xsc) + 7 * i + 3, rc);
+            stsv(WF(v) + 6 * i, w.v);
+            stsv(WF(a) + 6 * i, w.a);
+            st_i10(WF(i10) + 10 * i, I);
             stsv(WF(f) + 6 * i, fb - fg);
+            float* S = WF(S) + 6 * own_ds;
+            if (own_type == DSIM_JOINT_PRISMATIC || own_type == DSIM_JOINT_REVOLUTE) {
+                stsv(S, w.s0);
+            } else if (own_type == DSIM_JOINT_BALL) {
+                stsv(S, w.s0);
+                stsv(S + 6, w.s1);
+                stsv(S + 12, w.s2);
+            }
         }
     });
 }
@@ -556,10 +624,18 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_solve(const Ctx& c, Exec&
     });
 }
 
-// semi-implicit Euler (sim.py:1505-1636); in place on q, qd
+// joint-type mask of the whole model: a compile-time constant in the specialised kernels
+template <class Ctx> DSIM_FN constexpr int dsim_tmask_static() {
+    if constexpr (DsimIsStatic<Ctx>::value) return decltype(Ctx::d)::tmask;
+    else return 0x1f;
+}
+
+// semi-implicit Euler (sim.py:1505-1636); in place on q, qd.  Loads first, then arithmetic, then stores.
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_integrate(const Ctx& c, Exec& ex) {
     ex.mark(6);
     ex.run([&](int lane) {
+        constexpr int MASK = dsim_tmask_static<Ctx>();
+        constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
         const float h = c.h;
         for (int i = lane; i < c.d.L; i += DSIM_NL) {
             int type, cs, ds;
@@ -571,27 +647,49 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_integrate(const Ctx& c, E
             }
             float *q = WF(q), *qd = WF(qd);
             const float* qdd = WF(qdd);
+            float qv[NQ > 0 ? NQ : 1], qdv[NDF > 0 ? NDF : 1], av[NDF > 0 ? NDF : 1];
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) qv[k] = q[cs + k];
+#pragma unroll
+            for (int k = 0; k < NDF; ++k) {
+                qdv[k] = qd[ds + k];
+                av[k] = qdd[ds + k];
+            }
             if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
-                const float qdn = qd[ds] + qdd[ds] * h;
+                const float qdn = qdv[0] + av[0] * h;
                 qd[ds] = qdn;
-                q[cs] = q[cs] + qdn * h;
-            } else if (type == DSIM_JOINT_BALL || type == DSIM_JOINT_FREE) {
-                const int ro = type == DSIM_JOINT_FREE ? 3 : 0;  // offset of the quaternion in q
-                const v3 w = ld3(qd + ds) + ld3(qdd + ds) * h;
-                if (type == DSIM_JOINT_FREE) {
-                    const v3 v = ld3(qd + ds + 3) + ld3(qdd + ds + 3) * h;
-                    const v3 p = ld3(q + cs);
-                    st3(q + cs, p + (v + cross(w, p)) * h);
-                    st3(qd + ds + 3, v);
+                q[cs] = qv[0] + qdn * h;
+            }
+            if constexpr ((MASK & (DSIM_TM(DSIM_JOINT_BALL) | DSIM_TM(DSIM_JOINT_FREE))) != 0) {
+                if (type == DSIM_JOINT_BALL || type == DSIM_JOINT_FREE) {
+                    const bool fr = type == DSIM_JOINT_FREE;
+                    const v3 w = mk3(qdv[0], qdv[1], qdv[2]) + mk3(av[0], av[1], av[2]) * h;
+                    q4 r;
+                    v3 pn = zero3(), vn = zero3();
+                    if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
+                        if (fr) {
+                            vn = mk3(qdv[3], qdv[4], qdv[5]) + mk3(av[3], av[4], av[5]) * h;
+                            const v3 p = mk3(qv[0], qv[1], qv[2]);
+                            pn = p + (vn + cross(w, p)) * h;
+                            r = mkq(qv[3], qv[4], qv[5], qv[6]);
+                        } else {
+                            r = mkq(qv[0], qv[1], qv[2], qv[3]);
+                        }
+                    } else {
+                        r = mkq(qv[0], qv[1], qv[2], qv[3]);
+                    }
+                    const q4 dr = qmul(mkq(w.x, w.y, w.z, 0.f), r) * 0.5f;
+                    const q4 rt = r + dr * h;
+                    const float l = sqrtf(qdot(rt, rt));
+                    q4 rn = mkq(0.f, 0.f, 0.f, 1.f);
+                    if (l > 0.0f) rn = rt * (1.0f / l);
+                    if (fr) {
+                        st3(q + cs, pn);
+                        st3(qd + ds + 3, vn);
+                    }
+                    stq(q + cs + (fr ? 3 : 0), rn);
+                    st3(qd + ds, w);
                 }
-                const q4 r = ldq(q + cs + ro);
-                const q4 dr = qmul(mkq(w.x, w.y, w.z, 0.f), r) * 0.5f;
-                const q4 rt = r + dr * h;
-                const float l = sqrtf(qdot(rt, rt));
-                q4 rn = mkq(0.f, 0.f, 0.f, 1.f);
-                if (l > 0.0f) rn = rt * (1.0f / l);
-                stq(q + cs + ro, rn);
-                st3(qd + ds, w);
             }
         }
     });
@@ -621,9 +719,11 @@ DSIM_FN void dsim_fwd_substep(const Ctx& c, Exec& ex, bool update_mass, float* g
     dsim_fwd_solve(c, ex);
     if (g_row) {
         // global stores to this environment's private rows: no barrier, no wait -- they drain while the step goes on
+        // (16 bytes per lane and instruction: the saved block and a checkpoint row are 16-byte aligned multiples of 4 words)
         ex.fire([&](int lane) {
-            const float* src = WF(q);
-            for (int k = lane; k < c.o.save_words; k += DSIM_NL) g_row[k] = src[k];
+            const dsim_f4* src = reinterpret_cast<const dsim_f4*>(WF(q));
+            dsim_f4* dst = reinterpret_cast<dsim_f4*>(g_row);
+            for (int k = lane; k < c.o.save_words / 4; k += DSIM_NL) dst[k] = src[k];
             if (update_mass && g_hinv)
                 for (int k = lane; k < c.d.nd * c.d.nd; k += DSIM_NL) g_hinv[k] = WF(hinv)[k];
         });
@@ -690,7 +790,10 @@ template <class Ctx, class Exec> DSIM_FN void dsim_hacc_zero(const Ctx& c, Exec&
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c, Exec& ex, bool update_mass) {
     ex.mark(7);
     const int nd = c.d.nd;
+    // integrate^T per link: loads, arithmetic, stores (aq / aqd alias aqn / aqdn: every lane replaces its own link's words)
     ex.run([&](int lane) {
+        constexpr int MASK = dsim_tmask_static<Ctx>();
+        constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
         const float h = c.h;
         for (int i = lane; i < c.d.L; i += DSIM_NL) {
             int type, cs, ds;
@@ -700,43 +803,65 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
             } else {
                 type = CI(jtype)[i]; cs = CI(qstart)[i]; ds = CI(qdstart)[i];
             }
-            const float *q = WF(q), *qd = WF(qd), *qdd = WF(qdd), *aqn = WF(aqn), *aqdn = WF(aqdn);
+            const float *q = WF(q), *qd = WF(qd), *qdd = WF(qdd);
             float *aq = WF(aq), *aqd = WF(aqd), *aqdd = WF(aqdd);
+            float qv[NQ > 0 ? NQ : 1], gqn[NQ > 0 ? NQ : 1], qdv[NDF > 0 ? NDF : 1], av[NDF > 0 ? NDF : 1], gqdn[NDF > 0 ? NDF : 1];
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                qv[k] = q[cs + k];
+                gqn[k] = aq[cs + k];
+            }
+#pragma unroll
+            for (int k = 0; k < NDF; ++k) {
+                qdv[k] = qd[ds + k];
+                av[k] = qdd[ds + k];
+                gqdn[k] = aqd[ds + k];
+            }
             if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
-                const float g = aqdn[ds] + h * aqn[cs];
-                aq[cs] = aqn[cs];
+                const float g = gqdn[0] + h * gqn[0];
                 aqd[ds] = g;
                 aqdd[ds] = h * g;
-            } else if (type == DSIM_JOINT_BALL || type == DSIM_JOINT_FREE) {
-                const int ro = type == DSIM_JOINT_FREE ? 3 : 0;
-                const v3 w = ld3(qd + ds) + ld3(qdd + ds) * h;
-                const q4 r = ldq(q + cs + ro);
-                const q4 W = mkq(w.x, w.y, w.z, 0.f);
-                const q4 rt = r + qmul(W, r) * (0.5f * h);
-                const float l = sqrtf(qdot(rt, rt));
-                const q4 g_rn = ldq(aqn + cs + ro);
-                q4 g_rt = mkq(0.f, 0.f, 0.f, 0.f);
-                if (l > 0.0f) {
-                    const float il = 1.0f / l;
-                    const q4 rn = rt * il;
-                    g_rt = (g_rn + rn * (-qdot(rn, g_rn))) * il;
+            }
+            if constexpr ((MASK & (DSIM_TM(DSIM_JOINT_BALL) | DSIM_TM(DSIM_JOINT_FREE))) != 0) {
+                if (type == DSIM_JOINT_BALL || type == DSIM_JOINT_FREE) {
+                    const bool fr = type == DSIM_JOINT_FREE;
+                    const v3 w = mk3(qdv[0], qdv[1], qdv[2]) + mk3(av[0], av[1], av[2]) * h;
+                    q4 r, g_rn;
+                    if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
+                        r = fr ? mkq(qv[3], qv[4], qv[5], qv[6]) : mkq(qv[0], qv[1], qv[2], qv[3]);
+                        g_rn = fr ? mkq(gqn[3], gqn[4], gqn[5], gqn[6]) : mkq(gqn[0], gqn[1], gqn[2], gqn[3]);
+                    } else {
+                        r = mkq(qv[0], qv[1], qv[2], qv[3]);
+                        g_rn = mkq(gqn[0], gqn[1], gqn[2], gqn[3]);
+                    }
+                    const q4 W = mkq(w.x, w.y, w.z, 0.f);
+                    const q4 rt = r + qmul(W, r) * (0.5f * h);
+                    const float l = sqrtf(qdot(rt, rt));
+                    q4 g_rt = mkq(0.f, 0.f, 0.f, 0.f);
+                    if (l > 0.0f) {
+                        const float il = 1.0f / l;
+                        const q4 rn = rt * il;
+                        g_rt = (g_rn + rn * (-qdot(rn, g_rn))) * il;
+                    }
+                    const q4 g_r = g_rt + qmul_adj_b(W, g_rt) * (0.5f * h);
+                    const q4 g_W = qmul_adj_a(r, g_rt) * (0.5f * h);
+                    v3 g_w = qvec(g_W) + mk3(gqdn[0], gqdn[1], gqdn[2]);
+                    if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
+                        if (fr) {
+                            const v3 p = mk3(qv[0], qv[1], qv[2]);
+                            const v3 g_pn = mk3(gqn[0], gqn[1], gqn[2]);
+                            const v3 g_dp = g_pn * h;
+                            const v3 g_v = g_dp + mk3(gqdn[3], gqdn[4], gqdn[5]);
+                            g_w += cross(p, g_dp);
+                            st3(aq + cs, g_pn - cross(w, g_dp));
+                            st3(aqd + ds + 3, g_v);
+                            st3(aqdd + ds + 3, g_v * h);
+                        }
+                    }
+                    stq(aq + cs + (fr ? 3 : 0), g_r);
+                    st3(aqd + ds, g_w);
+                    st3(aqdd + ds, g_w * h);
                 }
-                const q4 g_r = g_rt + qmul_adj_b(W, g_rt) * (0.5f * h);
-                const q4 g_W = qmul_adj_a(r, g_rt) * (0.5f * h);
-                v3 g_w = qvec(g_W) + ld3(aqdn + ds);
-                if (type == DSIM_JOINT_FREE) {
-                    const v3 p = ld3(q + cs);
-                    const v3 g_pn = ld3(aqn + cs);
-                    const v3 g_dp = g_pn * h;
-                    const v3 g_v = g_dp + ld3(aqdn + ds + 3);
-                    g_w += cross(p, g_dp);
-                    st3(aq + cs, g_pn - cross(w, g_dp));
-                    st3(aqd + ds + 3, g_v);
-                    st3(aqdd + ds + 3, g_v * h);
-                }
-                stq(aq + cs + ro, g_r);
-                st3(aqd + ds, g_w);
-                st3(aqdd + ds, g_w * h);
             }
         }
     });
@@ -777,19 +902,27 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
             } else {
                 i = CI(dof_link)[d]; type = CI(jtype)[i]; cs = CI(qstart)[i]; ds = CI(qdstart)[i];
             }
+            // loads first (aq / aqd / aact are read-modify-write), stores last
             const float at = WF(atau)[d];
-            stsv(WF(aS) + 6 * d, ldsv(WF(ftot) + 6 * i) * (-at));
-            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
-                const float q = WF(q)[cs];
-                float dq = -CF(tke)[i];
-                if (q < CF(lower)[cs]) dq = -CF(tke)[i] - CF(lke)[i];
-                if (q > CF(upper)[cs]) dq = -CF(tke)[i] - CF(lke)[i];
-                WF(aq)[cs] += dq * at;
-                WF(aqd)[d] += (-CF(tkd)[i] - CF(lkd)[i]) * at;
-                WF(aact)[d] += at;
-            } else if (type == DSIM_JOINT_BALL) {
-                WF(aq)[cs + (d - ds)] += -CF(tke)[i] * at;
-                WF(aqd)[d] += -CF(tkd)[i] * at;
+            const sv6 ft = ldsv(WF(ftot) + 6 * i);
+            const bool hinge = type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE;
+            const bool ball = type == DSIM_JOINT_BALL;
+            const int qi = hinge ? cs : (ball ? cs + (d - ds) : 0);
+            const float q = WF(q)[qi];
+            const float tke = CF(tke)[i], tkd = CF(tkd)[i], lke = CF(lke)[i], lkd = CF(lkd)[i];
+            const float lower = CF(lower)[qi], upper = CF(upper)[qi];
+            const float g_q = WF(aq)[qi], g_qd = WF(aqd)[d], g_act = WF(aact)[d];
+            stsv(WF(aS) + 6 * d, ft * (-at));
+            if (hinge) {
+                float dq = -tke;
+                if (q < lower) dq = -tke - lke;
+                if (q > upper) dq = -tke - lke;
+                WF(aq)[qi] = g_q + dq * at;
+                WF(aqd)[d] = g_qd + (-tkd - lkd) * at;
+                WF(aact)[d] = g_act + at;
+            } else if (ball) {
+                WF(aq)[qi] = g_q + (-tke) * at;
+                WF(aqd)[d] = g_qd + (-tkd) * at;
             }
         }
         // cotangent of body_f_s[j]: f_tot of every ancestor-or-self i of j contains f[j] and tau_d = -S_d . f_tot[link(d)], so
@@ -848,101 +981,100 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
     });
 }
 
-// contacts^T and muscles^T: per-item cotangents of (X_sc, v_s) / (X_sc, activation).  Runs inside the first body-level
-// phase (both only need af); items are dealt from the top lane of the wavefront down.
+// contacts^T and muscles^T.  The cotangent with respect to the POSE of a body is kept as a world-frame wrench (torque
+// about the origin, force): a cotangent a_x of a body-fixed point at world position x is the wrench (x x a_x, a_x), and
+// wrenches of different points / different sources simply add (dsim_bwd_bodies).  Per contact: [wrench 6, cotangent of
+// the body's twist 6]; per muscle segment: [wrench on link 0, wrench on link 1, cotangent of the activation].
+// Runs inside the first body-level phase (both only need af); items are dealt from the top lane of the wavefront down.
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external_items(const Ctx& c, Exec& ex, int real_lane) {
     const int lane = DSIM_NL - 1 - real_lane;
-    {
-        for (int k = lane; k < c.d.C; k += DSIM_NL) {
-            float* o = WF(acx) + 13 * k;
-            for (int r = 0; r < 13; ++r) o[r] = 0.f;
-            int b;
-            if constexpr (DsimContactRegs<Ctx>::value) b = ex.topo(real_lane).cbody_b;
-            else b = CI(cbody)[k];
-            const v3 xp = ld3(WF(xsc) + 7 * b);
-            const q4 xq = ldq(WF(xsc) + 7 * b + 3);
-            const sv6 vb = ldsv(WF(v) + 6 * b);
-            const float* mat = CF(cmat) + 4 * k;
-            const float ke = mat[0], kd = mat[1], kf = mat[2], mu = mat[3];
-            const v3 cp = ld3(CF(cpoint) + 3 * k);
-            v3 p = xp + rotate(xq, cp);
-            p.y -= CF(cdist)[k];
-            const float cc = p.y;
-            if (cc < 0.0f) {
-                const v3 dpdt = vb.v + cross(vb.w, p);
-                const float vn = dpdt.y;
-                const v3 vt = mk3(dpdt.x, 0.f, dpdt.z);
-                const float fn = cc * ke;
-                const float vmin = vn < 0.0f ? vn : 0.0f;
-                const float fd = vmin * kd * (0.0f - cc);
-                const float lt = sqrtf(dot(vt, vt));
-                const float a1 = kf * lt, a2 = 0.0f - mu * cc * ke;
-                const bool first = a1 < a2;
-                const float smin = first ? a1 : a2;
-                v3 nhat = zero3();
-                if (lt > 0.0f) nhat = vt * (1.0f / lt);
-                const v3 ft = nhat * smin;
-                const v3 F = mk3(ft.x, fn + fd, ft.z);
-                const sv6 A = ldsv(WF(af) + 6 * b);  // cotangent of body_f_s[b]
-                v3 a_p = cross(F, A.w);
-                const v3 a_F = A.v + cross(A.w, p);
-                const float a_fnfd = a_F.y;
-                const v3 a_ft = a_F;  // ft.y == 0 and receives a_F.y too, but vt.y has no dependence (see below)
-                const float a_s = dot(nhat, a_ft);
-                const v3 a_nhat = a_ft * smin;
-                float a_lt = 0.f, a_c = 0.f, a_vn = 0.f;
-                if (first) a_lt += kf * a_s;
-                else a_c += -mu * ke * a_s;
-                v3 a_vt = zero3();
-                if (lt > 0.0f) a_vt = (a_nhat - nhat * dot(nhat, a_nhat)) * (1.0f / lt) + nhat * a_lt;
-                if (vn < 0.0f) a_vn += kd * (0.0f - cc) * a_fnfd;
-                a_c += -vmin * kd * a_fnfd;
-                a_c += ke * a_fnfd;
-                // vt = dpdt - n*vn ; vn = n.dpdt  (n = +y)
-                v3 a_dp = a_vt;
-                a_vn += -a_vt.y;
-                a_dp.y += a_vn;
-                a_p.y += a_c;
-                // dpdt = v + w x p
-                const v3 a_vv = a_dp;
-                const v3 a_vw = cross(p, a_dp);
-                a_p += cross(a_dp, vb.w);
-                st3(o, a_p);
-                stq(o + 3, rotate_adj_q(xq, cp, a_p));
-                st3(o + 7, a_vw);
-                st3(o + 10, a_vv);
-            }
+    for (int k = lane; k < c.d.C; k += DSIM_NL) {
+        int b;
+        if constexpr (DsimContactRegs<Ctx>::value) b = ex.topo(real_lane).cbody_b;
+        else b = CI(cbody)[k];
+        const v3 xp = ld3(WF(xsc) + 7 * b);
+        const q4 xq = ldq(WF(xsc) + 7 * b + 3);
+        const sv6 vb = ldsv(WF(v) + 6 * b);
+        const sv6 A = ldsv(WF(af) + 6 * b);  // cotangent of body_f_s[b]
+        const float* mat = CF(cmat) + 4 * k;
+        const float ke = mat[0], kd = mat[1], kf = mat[2], mu = mat[3];
+        const v3 cp = ld3(CF(cpoint) + 3 * k);
+        const float cdist = CF(cdist)[k];
+        const v3 x = xp + rotate(xq, cp);  // world position of the body-fixed contact point
+        v3 p = x;
+        p.y -= cdist;
+        const float cc = p.y;
+        sv6 wr = zerosv(), tw = zerosv();
+        if (cc < 0.0f) {
+            const v3 dpdt = vb.v + cross(vb.w, p);
+            const float vn = dpdt.y;
+            const v3 vt = mk3(dpdt.x, 0.f, dpdt.z);
+            const float fn = cc * ke;
+            const float vmin = vn < 0.0f ? vn : 0.0f;
+            const float fd = vmin * kd * (0.0f - cc);
+            const float lt = sqrtf(dot(vt, vt));
+            const float a1 = kf * lt, a2 = 0.0f - mu * cc * ke;
+            const bool first = a1 < a2;
+            const float smin = first ? a1 : a2;
+            v3 nhat = zero3();
+            if (lt > 0.0f) nhat = vt * (1.0f / lt);
+            const v3 ft = nhat * smin;
+            const v3 F = mk3(ft.x, fn + fd, ft.z);
+            v3 a_p = cross(F, A.w);
+            const v3 a_F = A.v + cross(A.w, p);
+            const float a_fnfd = a_F.y;
+            const v3 a_ft = a_F;  // ft.y == 0 and receives a_F.y too, but vt.y has no dependence (see below)
+            const float a_s = dot(nhat, a_ft);
+            const v3 a_nhat = a_ft * smin;
+            float a_lt = 0.f, a_c = 0.f, a_vn = 0.f;
+            if (first) a_lt += kf * a_s;
+            else a_c += -mu * ke * a_s;
+            v3 a_vt = zero3();
+            if (lt > 0.0f) a_vt = (a_nhat - nhat * dot(nhat, a_nhat)) * (1.0f / lt) + nhat * a_lt;
+            if (vn < 0.0f) a_vn += kd * (0.0f - cc) * a_fnfd;
+            a_c += -vmin * kd * a_fnfd;
+            a_c += ke * a_fnfd;
+            // vt = dpdt - n*vn ; vn = n.dpdt  (n = +y)
+            v3 a_dp = a_vt;
+            a_vn += -a_vt.y;
+            a_dp.y += a_vn;
+            a_p.y += a_c;
+            // dpdt = v + w x p
+            a_p += cross(a_dp, vb.w);
+            wr = mksv(cross(x, a_p), a_p);
+            tw = mksv(cross(p, a_dp), a_dp);
         }
-        for (int s = lane; s < c.d.NS; s += DSIM_NL) {
-            const int w = CI(seg_wp)[s];
-            const int l0 = CI(mlinks)[w], l1 = CI(mlinks)[w + 1];
-            const v3 pos0 = ld3(WF(xsc) + 7 * l0) + rotate(ldq(WF(xsc) + 7 * l0 + 3), ld3(CF(mpoints) + 3 * w));
-            const v3 pos1 = ld3(WF(xsc) + 7 * l1) + rotate(ldq(WF(xsc) + 7 * l1 + 3), ld3(CF(mpoints) + 3 * w + 3));
-            const float act = WF(mact)[CI(seg_m)[s]];
-            const v3 d = pos1 - pos0;
-            const float l = sqrtf(dot(d, d));
-            v3 f = zero3();
-            if (l > 0.0f) f = d * (act / l);
-            const sv6 A0 = ldsv(WF(af) + 6 * l0), A1 = ldsv(WF(af) + 6 * l1);
-            const v3 a_f = cross(A1.w, pos1) + A1.v - cross(A0.w, pos0) - A0.v;
-            v3 a_p0 = -cross(f, A0.w);
-            v3 a_p1 = cross(f, A1.w);
-            float a_act = 0.f;
-            if (l > 0.0f) {
-                const v3 n = d * (1.0f / l);
-                a_act = dot(n, a_f);
-                const v3 a_n = a_f * act;
-                const v3 a_d = (a_n - n * dot(n, a_n)) * (1.0f / l);
-                a_p1 += a_d;
-                a_p0 -= a_d;
-            }
-            float* o = WF(mus) + 15 * s;  // the forward wrench rows are dead by now: same buffer
-            st3(o, a_p0);
-            stq(o + 3, rotate_adj_q(ldq(WF(xsc) + 7 * l0 + 3), ld3(CF(mpoints) + 3 * w), a_p0));
-            st3(o + 7, a_p1);
-            stq(o + 10, rotate_adj_q(ldq(WF(xsc) + 7 * l1 + 3), ld3(CF(mpoints) + 3 * w + 3), a_p1));
-            o[14] = a_act;
+        float* o = WF(acx) + 12 * k;
+        stsv(o, wr);
+        stsv(o + 6, tw);
+    }
+    for (int s = lane; s < c.d.NS; s += DSIM_NL) {
+        const int w = CI(seg_wp)[s];
+        const int l0 = CI(mlinks)[w], l1 = CI(mlinks)[w + 1];
+        const v3 pos0 = ld3(WF(xsc) + 7 * l0) + rotate(ldq(WF(xsc) + 7 * l0 + 3), ld3(CF(mpoints) + 3 * w));
+        const v3 pos1 = ld3(WF(xsc) + 7 * l1) + rotate(ldq(WF(xsc) + 7 * l1 + 3), ld3(CF(mpoints) + 3 * w + 3));
+        const float act = WF(mact)[CI(seg_m)[s]];
+        const sv6 A0 = ldsv(WF(af) + 6 * l0), A1 = ldsv(WF(af) + 6 * l1);
+        const v3 d = pos1 - pos0;
+        const float l = sqrtf(dot(d, d));
+        v3 f = zero3();
+        if (l > 0.0f) f = d * (act / l);
+        const v3 a_f = cross(A1.w, pos1) + A1.v - cross(A0.w, pos0) - A0.v;
+        v3 a_p0 = -cross(f, A0.w);
+        v3 a_p1 = cross(f, A1.w);
+        float a_act = 0.f;
+        if (l > 0.0f) {
+            const v3 n = d * (1.0f / l);
+            a_act = dot(n, a_f);
+            const v3 a_n = a_f * act;
+            const v3 a_d = (a_n - n * dot(n, a_n)) * (1.0f / l);
+            a_p1 += a_d;
+            a_p0 -= a_d;
         }
+        float* o = WF(mus) + 13 * s;  // the forward wrench rows are dead by now: same buffer
+        stsv(o, mksv(cross(pos0, a_p0), a_p0));
+        stsv(o + 6, mksv(cross(pos1, a_p1), a_p1));
+        o[12] = a_act;
     }
 }
 
@@ -1001,58 +1133,45 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_mass(const Ctx& c, Exec& 
     });
 }
 
-// FK^T of one link: cotangent (a_pc, a_rc) of its X_sc plus axsj (cotangent of X_sj from the motion subspace) ->
-// joint coordinates (added into aq) and the cotangent handed to the parent's X_sc (topar[i]).  a_pj0 / a_rj0: axsj.
-template <class Ctx>
-DSIM_FN void dsim_fk_adjoint_link(const Ctx& c, int i, const DsimLinkInfo& li, v3 a_pc, q4 a_rc, v3 a_pj0, q4 a_rj0) {
-    const int par = li.parent, type = li.type, cs = li.cs;
-    const q4 rj = ldq(WF(xsj) + 7 * i + 3);
-    v3 a_pj = a_pj0 + a_pc;
-    q4 a_rj = a_rj0;
-    const v3 axis = ld3(CF(axis) + 3 * i);
-    const float* q = WF(q);
-    float* aq = WF(aq);
-    if (type == DSIM_JOINT_PRISMATIC) {
-        // pc = pj + rotate(rj, axis) q ; rc = rj
-        const v3 u = rotate(rj, axis);
-        aq[cs] += dot(u, a_pc);
-        a_rj += rotate_adj_q(rj, axis, a_pc * q[cs]);
-        a_rj += a_rc;
-    } else if (type == DSIM_JOINT_REVOLUTE) {
-        const q4 rjc = quat_axis_angle(axis, q[cs]);
-        aq[cs] += quat_axis_angle_adj(axis, q[cs], qmul_adj_b(rj, a_rc));
-        a_rj += qmul_adj_a(rjc, a_rc);
-    } else if (type == DSIM_JOINT_BALL) {
-        const q4 rjc = ldq(q + cs);
-        addq(aq + cs, qmul_adj_b(rj, a_rc));
-        a_rj += qmul_adj_a(rjc, a_rc);
-    } else if (type == DSIM_JOINT_FREE) {
-        const v3 pjc = ld3(q + cs);
-        const q4 rjc = ldq(q + cs + 3);
-        add3(aq + cs, rotate_inv(rj, a_pc));
-        addq(aq + cs + 3, qmul_adj_b(rj, a_rc));
-        a_rj += rotate_adj_q(rj, pjc, a_pc);
-        a_rj += qmul_adj_a(rjc, a_rc);
-    } else {
-        a_rj += a_rc;
-    }
-    if (par >= 0) {
-        const q4 rsp = ldq(WF(xsc) + 7 * par + 3);
-        const v3 ppj = ld3(CF(xpj) + 7 * i);
-        const q4 rpj = ldq(CF(xpj) + 7 * i + 3);
-        float* o = WF(topar) + 7 * i;
-        st3(o, a_pj);
-        stq(o + 3, rotate_adj_q(rsp, ppj, a_pj) + qmul_adj_a(rpj, a_rj));
-    }
+// Cotangent of a link's world inertia (10 parameters, g) as a pose wrench.  A rigid perturbation (dtheta about the world
+// origin, dp) of the body changes A by [dtheta]x A - A [dtheta]x + m(2 c.dp 1 - dp c^T - c dp^T) and h by dtheta x h + m dp;
+// contracting with g (g[5], g[6], g[8] are the derivatives with respect to the single stored off-diagonal parameters)
+// gives torque = axial(G2 A - A G2) + h x g_h, force = 2 tr(G) h - G2 h + m g_h with G2 = [[2gxx,gxy,gxz],[gxy,2gyy,gyz],[gxz,gyz,2gzz]].
+DSIM_FN sv6 inertia_pose_wrench(const inertia10& I, const float* g) {
+    const float gxx = g[4], gxy = g[5], gxz = g[6], gyy = g[7], gyz = g[8], gzz = g[9];
+    const v3 gh = mk3(g[1], g[2], g[3]);
+    // M = G2 * A, only the antisymmetric part is needed
+    const float m01 = 2.f * gxx * I.axy + gxy * I.ayy + gxz * I.ayz, m10 = gxy * I.axx + 2.f * gyy * I.axy + gyz * I.axz;
+    const float m02 = 2.f * gxx * I.axz + gxy * I.ayz + gxz * I.azz, m20 = gxz * I.axx + gyz * I.axy + 2.f * gzz * I.axz;
+    const float m12 = gxy * I.axz + 2.f * gyy * I.ayz + gyz * I.azz, m21 = gxz * I.axy + gyz * I.ayy + 2.f * gzz * I.ayz;
+    const v3 tA = mk3(m21 - m12, m02 - m20, m10 - m01);
+    const float tr2 = 2.f * (gxx + gyy + gzz);
+    const v3 g2h = mk3(2.f * gxx * I.h.x + gxy * I.h.y + gxz * I.h.z, gxy * I.h.x + 2.f * gyy * I.h.y + gyz * I.h.z,
+                       gxz * I.h.x + gyz * I.h.y + 2.f * gzz * I.h.z);
+    return mksv(tA + cross(I.h, gh), I.h * tr2 - g2h + gh * I.m);
 }
 
-// body level: f^T, velocity/acceleration recursions^T, joint motion^T, pose cotangents, FK^T
+// body level: f^T, velocity / acceleration recursions^T, joint motion^T, and the pose cotangents.
+//
+// Poses enter a substep through everything that is rigidly attached to a link: its world inertia, its centre of mass
+// (gravity), its contact points / muscle waypoints, and the motion subspace of its child joints (attached to the
+// link's X_sc, i.e. to the child's X_sj).  Instead of differentiating the quaternion formulas of the forward
+// kinematics link by link (the reference's generated adjoint does, spatial.h / quat.h adj_* functions), every such
+// cotangent is expressed as a world-frame wrench W_i on the link it is attached to; a joint coordinate q_d moves the
+// whole subtree of its link rigidly with twist S_d dq_d, hence   adj q_d = S_d . sum_{i in subtree(link(d))} W_i,
+// one subtree sum and one 6-dot per dof -- the same shape as tau = -S . f_tot in the forward pass.  Quaternion
+// coordinates (ball, free) get the tangent-space cotangent 2 (t, 0) (x) q; the component along q itself (which the
+// reference's literal differentiation also produces and the integrator's normalisation annihilates, DESIGN.md
+// "Quaternion radial component") is zero here.
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec& ex, bool update_mass) {
     ex.mark(10);
     ex.run([&](int lane) {
         for (int i = lane; i < c.d.L; i += DSIM_NL) {
             const inertia10 I = ld_i10(WF(i10) + 10 * i);
             const sv6 v = ldsv(WF(v) + 6 * i), a = ldsv(WF(a) + 6 * i), r = ldsv(WF(af) + 6 * i);
+            const v3 grav = ld3(CF(grav));
+            float g[10];
+            for (int k = 0; k < 10; ++k) g[k] = update_mass ? WF(ai10m)[10 * i + k] : 0.f;
             const sv6 hv = inertia_mul(I, v);
             sv6 a_v, a_hv;
             a_v.w = cross(hv.w, r.w) + cross(hv.v, r.v);
@@ -1060,21 +1179,23 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             a_hv.w = cross(r.w, v.w);
             a_hv.v = cross(r.w, v.v) + cross(r.v, v.w);
             a_v += inertia_mul(I, a_hv);
-            float g[10];
-            for (int k = 0; k < 10; ++k) g[k] = update_mass ? WF(ai10m)[10 * i + k] : 0.f;
             inertia_bilinear_adj(g, r, a, 1.0f);
             inertia_bilinear_adj(g, a_hv, v, 1.0f);
-            for (int k = 0; k < 10; ++k) WF(ai10)[10 * i + k] = g[k];
+            // pose wrench of the link: inertia + gravity (f_g = (c x m g, m g) enters f with a minus sign)
+            sv6 W = inertia_pose_wrench(I, g);
+            const v3 rg = cross(r.w, grav);
+            W.w += cross(I.h, rg);
+            W.v += rg * I.m;
             stsv(WF(aa) + 6 * i, inertia_mul(I, r));
-            st3(WF(ac) + 3 * i, cross(r.w, ld3(CF(grav)) * I.m));
             stsv(WF(av) + 6 * i, a_v);  // contact cotangents are added by the item-parallel gather below
+            stsv(WF(aw) + 6 * i, W);
         }
         dsim_bwd_external_items(c, ex, lane);
     });
     ex.run([&](int lane) {
         for (int m = lane; m < c.d.M; m += DSIM_NL) {
             float acc = 0.f;
-            for (int s = CI(ms_start)[m]; s < CI(ms_start)[m + 1]; ++s) acc += WF(mus)[15 * s + 14];
+            for (int s = CI(ms_start)[m]; s < CI(ms_start)[m + 1]; ++s) acc += WF(mus)[13 * s + 12];
             WF(amact)[m] += acc;
         }
         for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
@@ -1083,30 +1204,48 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             if constexpr (DsimSixRegs<Ctx>::value) n_known = ex.topo(lane).six_n;
             WF(aatot)[it] = dsim_subtree_sum(c, WF(aa), 6, k, i, n_known);
         }
-        // per-body gather of the contact (13 floats: X_sc 7, v_s 6) and muscle (7 floats: X_sc) cotangents
-        for (int it = lane; it < 13 * c.d.L; it += DSIM_NL) {
-            const int i = it / 13, r = it - 13 * i;
+        // per-body gather of the contact (12 floats: pose wrench 6, twist 6) and muscle (pose wrench 6) cotangents
+        for (int it = lane; it < 12 * c.d.L; it += DSIM_NL) {
+            const int i = it / 12, r = it - 12 * i;
             float acc;
             if (c.d.flags & DSIM_F_RANGES) {  // pre-order numbering: a body's own contacts are one contiguous range
                 if constexpr (DsimIsStatic<Ctx>::value)
-                    acc = dsim_range_sum_b<dsim_cap_body_contacts<decltype(c.d)>()>(WF(acx), 13, r, CI(cb_start)[i],
+                    acc = dsim_range_sum_b<dsim_cap_body_contacts<decltype(c.d)>()>(WF(acx), 12, r, CI(cb_start)[i],
                                                                                    CI(cb_start)[i + 1] - CI(cb_start)[i], 0.f);
                 else
-                    acc = dsim_range_sum(WF(acx), 13, r, CI(cb_start)[i], CI(cb_start)[i + 1] - CI(cb_start)[i], 0.f);
+                    acc = dsim_range_sum(WF(acx), 12, r, CI(cb_start)[i], CI(cb_start)[i + 1] - CI(cb_start)[i], 0.f);
             } else
-                acc = dsim_gather_sum(WF(acx), 13, r, CI(cb_list), CI(cb_start)[i], CI(cb_start)[i + 1], 0.f);
-            if (c.d.NS > 0 && r < 7)
+                acc = dsim_gather_sum(WF(acx), 12, r, CI(cb_list), CI(cb_start)[i], CI(cb_start)[i + 1], 0.f);
+            if (c.d.NS > 0 && r < 6)
                 for (int e = CI(ml_start)[i]; e < CI(ml_start)[i + 1]; ++e) {
                     const int code = CI(ml_list)[e];
-                    acc += WF(mus)[15 * (code >> 1) + 7 * (code & 1) + r];
+                    acc += WF(mus)[13 * (code >> 1) + 6 * (code & 1) + r];
                 }
             WF(agx)[it] = acc;
         }
     });
     ex.run([&](int lane) {
+        constexpr int MASK = dsim_tmask_static<Ctx>();
         for (int i = lane; i < c.d.L; i += DSIM_NL) {
-            const sv6 v = ldsv(WF(v) + 6 * i), vj = ldsv(WF(vj) + 6 * i), A = ldsv(WF(aatot) + 6 * i);
-            sv6 a_v = ldsv(WF(av) + 6 * i) + ldsv(WF(agx) + 13 * i + 7), a_vj;
+            int type, ds;
+            if constexpr (DsimRoleRegs<Ctx>::value) {
+                const DsimTopoRegs& tp = ex.topo(lane);
+                type = tp.own_type; ds = tp.own_ds;
+            } else {
+                type = CI(jtype)[i]; ds = CI(qdstart)[i];
+            }
+            const sv6 v = ldsv(WF(v) + 6 * i), A = ldsv(WF(aatot) + 6 * i);
+            sv6 a_v = ldsv(WF(av) + 6 * i) + ldsv(WF(agx) + 12 * i + 6), a_vj;
+            // vj = S qd of the link's own joint (not stored by the forward pass)
+            sv6 vj = zerosv();
+            if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
+                if (type == DSIM_JOINT_FREE) vj = ldsv(WF(qd) + ds);
+            }
+            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) vj = ldsv(WF(S) + 6 * ds) * WF(qd)[ds];
+            if constexpr ((MASK & DSIM_TM(DSIM_JOINT_BALL)) != 0) {
+                if (type == DSIM_JOINT_BALL)
+                    for (int k = 0; k < 3; ++k) vj += ldsv(WF(S) + 6 * (ds + k)) * WF(qd)[ds + k];
+            }
             a_v.w += cross(vj.w, A.w) + cross(vj.v, A.v);
             a_v.v += cross(vj.w, A.v);
             a_vj.w = cross(A.w, v.w) + cross(A.v, v.v);
@@ -1124,118 +1263,97 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
         }
     });
     ex.run([&](int lane) {
+        constexpr int MASK = dsim_tmask_static<Ctx>();
         for (int i = lane; i < c.d.L; i += DSIM_NL) {
-            int type, ds, d_end, leaf;
-            DsimLinkInfo own;
+            int type, ds;
             if constexpr (DsimRoleRegs<Ctx>::value) {
                 const DsimTopoRegs& tp = ex.topo(lane);
-                type = tp.own_type; ds = tp.own_ds; d_end = ds + tp.own_nd; leaf = tp.own_ch0 == tp.own_ch1;
-                own = DsimLinkInfo{tp.own_parent, type, tp.own_cs, ds, tp.own_level, 0, 0, 0};
+                type = tp.own_type; ds = tp.own_ds;
             } else {
-                type = CI(jtype)[i]; ds = CI(qdstart)[i]; d_end = CI(qdstart)[i + 1];
-                leaf = CI(child_start)[i] == CI(child_start)[i + 1];
-                own = dsim_link_info(c, i);
+                type = CI(jtype)[i]; ds = CI(qdstart)[i];
             }
             const sv6 a_vj = ldsv(WF(avj) + 6 * i) + ldsv(WF(avtot) + 6 * i);
-            const float* qd = WF(qd);
-            // vj = S qd
-            if (type == DSIM_JOINT_FREE) {
-                add3(WF(aqd) + ds, a_vj.w);
-                add3(WF(aqd) + ds + 3, a_vj.v);
-            } else {
-                for (int d = ds; d < d_end; ++d) {
-                    WF(aqd)[d] += sdot(ldsv(WF(S) + 6 * d), a_vj);
-                    float* o = WF(aS) + 6 * d;
-                    add3(o, a_vj.w * qd[d]);
-                    add3(o + 3, a_vj.v * qd[d]);
+            sv6 Z = ldsv(WF(aw) + 6 * i) + ldsv(WF(agx) + 12 * i);
+            sv6 Wp = zerosv();
+            float* aqd = WF(aqd);
+            // vj = S qd: cotangents of qd and of S; S is attached to the joint frame X_sj: W_par = sum S x* adj_S
+            if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
+                if (type == DSIM_JOINT_FREE) {
+                    const sv6 g = ldsv(aqd + ds);
+                    stsv(aqd + ds, g + a_vj);
                 }
             }
-            // cotangents of the poses: COM / inertia / gravity -> X_sc ; S -> X_sj
-            const q4 rc = ldq(WF(xsc) + 7 * i + 3);
-            const v3 cm = ld3(WF(pm) + 3 * i);
-            const float* g = WF(ai10) + 10 * i;
-            const float m = CF(mass)[i];
-            const float gxx = g[4], gxy = g[5], gxz = g[6], gyy = g[7], gyz = g[8], gzz = g[9];
-            v3 a_c = ld3(WF(ac) + 3 * i) + ld3(g + 1) * m;
-            a_c.x += m * (2.0f * cm.x * (gyy + gzz) - gxy * cm.y - gxz * cm.z);
-            a_c.y += m * (2.0f * cm.y * (gxx + gzz) - gxy * cm.x - gyz * cm.z);
-            a_c.z += m * (2.0f * cm.z * (gxx + gyy) - gxz * cm.x - gyz * cm.y);
-            q4 a_rc = rotate_adj_q(rc, ld3(CF(com) + 3 * i), a_c);
-            {
-                const float* ic = CF(ic6) + 6 * i;
-                const v3 ex_ = mk3(1.f, 0.f, 0.f), ey_ = mk3(0.f, 1.f, 0.f), ez_ = mk3(0.f, 0.f, 1.f);
-                const v3 rx = rotate(rc, ex_), ry = rotate(rc, ey_), rz = rotate(rc, ez_);
-                const v3 b0 = rx * ic[0] + ry * ic[1] + rz * ic[2];
-                const v3 b1 = rx * ic[1] + ry * ic[3] + rz * ic[4];
-                const v3 b2 = rx * ic[2] + ry * ic[4] + rz * ic[5];
-                // adj_R[:,k] = 2 G b_k with 2G = [[2gxx,gxy,gxz],[gxy,2gyy,gyz],[gxz,gyz,2gzz]]
-                const v3 c0 = mk3(2.f * gxx * b0.x + gxy * b0.y + gxz * b0.z, gxy * b0.x + 2.f * gyy * b0.y + gyz * b0.z,
-                                  gxz * b0.x + gyz * b0.y + 2.f * gzz * b0.z);
-                const v3 c1 = mk3(2.f * gxx * b1.x + gxy * b1.y + gxz * b1.z, gxy * b1.x + 2.f * gyy * b1.y + gyz * b1.z,
-                                  gxz * b1.x + gyz * b1.y + 2.f * gzz * b1.z);
-                const v3 c2 = mk3(2.f * gxx * b2.x + gxy * b2.y + gxz * b2.z, gxy * b2.x + 2.f * gyy * b2.y + gyz * b2.z,
-                                  gxz * b2.x + gyz * b2.y + 2.f * gzz * b2.z);
-                a_rc += rotate_adj_q(rc, ex_, c0);
-                a_rc += rotate_adj_q(rc, ey_, c1);
-                a_rc += rotate_adj_q(rc, ez_, c2);
+            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
+                const sv6 S = ldsv(WF(S) + 6 * ds), aS = ldsv(WF(aS) + 6 * ds);
+                const float qd = WF(qd)[ds], g = aqd[ds];
+                Wp = scross_dual(S, aS + a_vj * qd);
+                aqd[ds] = g + sdot(S, a_vj);
             }
-            st3(WF(axsc) + 7 * i, ld3(WF(agx) + 13 * i) + a_c);
-            stq(WF(axsc) + 7 * i + 3, ldq(WF(agx) + 13 * i + 3) + a_rc);
-            const v3 pj = ld3(WF(xsj) + 7 * i);
-            const q4 rj = ldq(WF(xsj) + 7 * i + 3);
-            v3 a_pj = zero3();
-            q4 a_rj = mkq(0.f, 0.f, 0.f, 0.f);
-            if (type == DSIM_JOINT_PRISMATIC) {
-                a_rj = rotate_adj_q(rj, ld3(CF(axis) + 3 * i), ld3(WF(aS) + 6 * ds + 3));
-            } else if (type == DSIM_JOINT_REVOLUTE || type == DSIM_JOINT_BALL) {
-                for (int d = ds; d < d_end; ++d) {
-                    const int k = d - ds;
-                    const v3 ax = type == DSIM_JOINT_REVOLUTE
-                                      ? ld3(CF(axis) + 3 * i)
-                                      : mk3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f);
-                    const v3 w = rotate(rj, ax);
-                    const v3 sw = ld3(WF(aS) + 6 * d), sv_ = ld3(WF(aS) + 6 * d + 3);
-                    a_pj += cross(w, sv_);
-                    a_rj += rotate_adj_q(rj, ax, sw - cross(pj, sv_));
+            if constexpr ((MASK & DSIM_TM(DSIM_JOINT_BALL)) != 0) {
+                if (type == DSIM_JOINT_BALL) {
+                    for (int k = 0; k < 3; ++k) {
+                        const sv6 S = ldsv(WF(S) + 6 * (ds + k)), aS = ldsv(WF(aS) + 6 * (ds + k));
+                        const float qd = WF(qd)[ds + k], g = aqd[ds + k];
+                        Wp += scross_dual(S, aS + a_vj * qd);
+                        aqd[ds + k] = g + sdot(S, a_vj);
+                    }
                 }
             }
-            if (leaf) {
-                // leaf: nothing will be added to its X_sc cotangent, finish its FK^T here (saves a tree-level phase)
-                dsim_fk_adjoint_link(c, i, own, ld3(WF(agx) + 13 * i) + a_c, ldq(WF(agx) + 13 * i + 3) + a_rc,
-                                     a_pj, a_rj);
+            stsv(WF(aw) + 6 * i, Z + Wp);
+            stsv(WF(awp) + 6 * i, Wp);
+        }
+    });
+    ex.run([&](int lane) {
+        for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
+            const int i = it / 6, k = it - 6 * i;
+            int n_known = -1;
+            if constexpr (DsimSixRegs<Ctx>::value) n_known = ex.topo(lane).six_n;
+            WF(azs)[it] = dsim_subtree_sum(c, WF(aw), 6, k, i, n_known);
+        }
+    });
+    // adj q_d = S_d . (subtree wrench of the link, without the part attached to the link's own joint frame)
+    ex.run([&](int lane) {
+        constexpr int MASK = dsim_tmask_static<Ctx>();
+        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+            int type, cs, ds, par;
+            if constexpr (DsimRoleRegs<Ctx>::value) {
+                const DsimTopoRegs& tp = ex.topo(lane);
+                type = tp.own_type; cs = tp.own_cs; ds = tp.own_ds; par = tp.own_parent;
             } else {
-                st3(WF(axsj) + 7 * i, a_pj);
-                stq(WF(axsj) + 7 * i + 3, a_rj);
+                type = CI(jtype)[i]; cs = CI(qstart)[i]; ds = CI(qdstart)[i]; par = CI(parent)[i];
+            }
+            const sv6 Wt = ldsv(WF(azs) + 6 * i) - ldsv(WF(awp) + 6 * i);
+            float* aq = WF(aq);
+            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
+                const sv6 S = ldsv(WF(S) + 6 * ds);
+                const float g = aq[cs];
+                aq[cs] = g + sdot(S, Wt);
+            }
+            if constexpr ((MASK & DSIM_TM(DSIM_JOINT_BALL)) != 0) {
+                if (type == DSIM_JOINT_BALL) {
+                    const q4 r = ldq(WF(q) + cs), g = ldq(aq + cs);
+                    const v3 t = mk3(sdot(ldsv(WF(S) + 6 * ds), Wt), sdot(ldsv(WF(S) + 6 * ds + 6), Wt),
+                                     sdot(ldsv(WF(S) + 6 * ds + 12), Wt));
+                    stq(aq + cs, g + qmul(mkq(t.x, t.y, t.z, 0.f), r) * 2.0f);
+                }
+            }
+            if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
+                if (type == DSIM_JOINT_FREE) {
+                    // X_sc = X_sj o (q_p, q_r): translation by R_j dq_p, rotation about p_c
+                    const v3 pc = ld3(WF(xsc) + 7 * i);
+                    const q4 rc = ldq(WF(xsc) + 7 * i + 3);
+                    const q4 rpj = ldq(CF(xpj) + 7 * i + 3);
+                    q4 rj = rpj;
+                    if (par >= 0) rj = qmul(ldq(WF(xsc) + 7 * par + 3), rpj);
+                    const v3 gp = ld3(aq + cs);
+                    const q4 gr = ldq(aq + cs + 3);
+                    const v3 tc = Wt.w - cross(pc, Wt.v);
+                    st3(aq + cs, gp + rotate_inv(rj, Wt.v));
+                    stq(aq + cs + 3, gr + qmul(qmul(qconj(rj), mkq(tc.x, tc.y, tc.z, 0.f)), rc) * 2.0f);
+                }
             }
         }
     });
-    // FK^T, leaves to root.  Leaf links were already finished inside the pose phase above (their X_sc cotangent has
-    // no contribution from children), so only the levels that contain interior links need a phase: d.Dinner of them.
-    for (int lv = c.d.Dinner - 1; lv >= 0; --lv) {
-        ex.run([&](int lane) {
-            for (int i = lane; i < c.d.L; i += DSIM_NL) {
-                DsimLinkInfo li;
-                int ch0, ch1;
-                if constexpr (DsimRoleRegs<Ctx>::value) {
-                    const DsimTopoRegs& tp = ex.topo(lane);
-                    li = DsimLinkInfo{tp.own_parent, tp.own_type, tp.own_cs, tp.own_ds, tp.own_level, 0, 0, 0};
-                    ch0 = tp.own_ch0; ch1 = tp.own_ch1;
-                } else {
-                    li = dsim_link_info(c, i);
-                    ch0 = CI(child_start)[i]; ch1 = CI(child_start)[i + 1];
-                }
-                if (li.level != lv || ch0 == ch1) continue;
-                v3 a_pc = ld3(WF(axsc) + 7 * i);
-                q4 a_rc = ldq(WF(axsc) + 7 * i + 3);
-                for (int e = ch0; e < ch1; ++e) {
-                    const float* o = WF(topar) + 7 * CI(child_list)[e];
-                    a_pc += ld3(o);
-                    a_rc += ldq(o + 3);
-                }
-                dsim_fk_adjoint_link(c, i, li, a_pc, a_rc, ld3(WF(axsj) + 7 * i), ldq(WF(axsj) + 7 * i + 3));
-            }
-        });
-    }
 }
 
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_substep(const Ctx& c, Exec& ex, bool update_mass) {

@@ -34,7 +34,7 @@ namespace {
 // what lets checkpoint traffic overlap with compute.
 __device__ __forceinline__ void dsim_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-#define DSIM_PF 24  // prefetch registers per lane: rows up to 1536 floats (Humanoid: 1421)
+#define DSIM_PF 6  // prefetch registers per lane (16 bytes each): rows up to 1536 floats (Humanoid: 1016)
 
 struct DevExec {
     template <class F> __device__ __forceinline__ void run(F&& f) {
@@ -52,26 +52,28 @@ struct DevExec {
     __device__ __forceinline__ DsimTopoRegs& topo(int) { return topo_; }
     // software prefetch of one checkpoint row: global loads are issued here and stay in flight (registers) until
     // commit() stores them to LDS one adjoint substep later; rows longer than 64*DSIM_PF lanes*regs are read at commit
-    float pf[DSIM_PF];
+    dsim_f4 pf[DSIM_PF];
     const float* pf_src;
     __device__ __forceinline__ void prefetch(const float* row, int words) {
         pf_src = row;
-        if (words > DSIM_NL * DSIM_PF) return;
+        if (words > 4 * DSIM_NL * DSIM_PF) return;
+        const dsim_f4* r4 = reinterpret_cast<const dsim_f4*>(row);
 #pragma unroll
         for (int r = 0; r < DSIM_PF; ++r) {
             const int k = (int)threadIdx.x + DSIM_NL * r;
-            if (k < words) pf[r] = row[k];
+            if (4 * k < words) pf[r] = r4[k];
         }
     }
     __device__ __forceinline__ void commit(float* dst, int words, int lane) {
-        if (words > DSIM_NL * DSIM_PF) {
+        if (words > 4 * DSIM_NL * DSIM_PF) {
             for (int k = lane; k < words; k += DSIM_NL) dst[k] = pf_src[k];
             return;
         }
+        dsim_f4* d4 = reinterpret_cast<dsim_f4*>(dst);
 #pragma unroll
         for (int r = 0; r < DSIM_PF; ++r) {
             const int k = lane + DSIM_NL * r;
-            if (k < words) dst[k] = pf[r];
+            if (4 * k < words) d4[k] = pf[r];
         }
     }
 };

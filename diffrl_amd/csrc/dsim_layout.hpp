@@ -14,11 +14,14 @@
 
 #include "../../include/dsim.h"
 
+#define DSIM_PMASK_N 10
 struct DsimDims {
     int L, nq, nd, C, M, W, NS, D;  // links, coords, dofs, contacts, muscles, waypoints, active muscle segments, tree levels
     int flags;                      // DSIM_F_*
-    int Dinner;                     // number of tree levels that contain links with children
+    int tmask;                      // bit t set: some joint has type t
+    int pmask[DSIM_PMASK_N];        // bit t set: some link has a joint of type t at position p of its ancestor chain (root = 0)
 };
+#define DSIM_TM(t) (1 << (t))
 #define DSIM_F_RANGES 1  // subtree(i) == links [i, i+n_i) and its contacts == one contiguous contact range (pre-order numbering)
 
 struct DsimOff {
@@ -42,13 +45,13 @@ struct DsimOff {
     int cpoint, cdist, cmat, grav, mpoints;
     int const_words;
     // ---- forward work arrays (floats)
-    int q, qd, act, mact, ua, obs, xsj, xsc, pm, S, vj, v, a, i10, f, ftot, cw, tau, qdd, ic10, F, hinv, prow, pcol, mus;
+    int q, qd, act, mact, ua, obs, xsc, S, v, a, i10, f, ftot, cw, tau, qdd, ic10, F, hinv, prow, pcol, mus;
     int epf;                    // episode flags (fused env surface): [0] invalid state seen, [1] episode finished
     int save_words;             // length of the saved block that starts at q (see dsim_build_layout)
     int fwd_words;
     // ---- adjoint work arrays (floats)
-    int aq, aqd, aqn, aqdn, aact, amact, aqdd, atau, aS, af, acx, axsc, axsj, ac, av, aa, aatot, avtot, avj,
-        ai10, ai10m, aic10, aH, topar, gua, agx;
+    int aq, aqd, aqn, aqdn, aact, amact, aqdd, atau, aS, af, acx, av, aa, aatot, avtot, avj,
+        aw, awp, azs, ai10m, aic10, aH, gua, agx;
     int total_words;
 };
 
@@ -285,31 +288,39 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     // forward launch can stream it to HBM with one linear copy per substep and the adjoint launch can read it back
     // instead of recomputing it (the checkpoint row of a substep IS this block; it starts with q, qd)
     o.q = take(nq); o.qd = take(nd);
-    o.xsj = take(7 * L); o.xsc = take(7 * L); o.pm = take(3 * L); o.S = take(6 * nd);
-    o.vj = take(6 * L); o.v = take(6 * L); o.a = take(6 * L); o.i10 = take(10 * L);
+    o.xsc = take(7 * L); o.S = take(6 * nd);
+    o.v = take(6 * L); o.a = take(6 * L); o.i10 = take(10 * L);
     o.ftot = take(6 * L); o.qdd = take(nd);
     o.save_words = cur - o.q;
     o.act = take(nd); o.mact = take(M);
     o.ua = take(M > nd ? M : nd); o.obs = take(16 + nq + nd + (M > nd ? M : nd));
     o.f = take(6 * L); o.cw = take(6 * C); o.tau = take(nd);
     o.ic10 = take(10 * L); o.F = take(6 * nd); o.hinv = take(nd * nd); o.prow = take(nd); o.pcol = take(nd);
-    o.mus = take(15 * NS);  // forward: 12 floats/segment (signed wrenches); adjoint: 15 floats/segment (cotangents)
+    o.mus = take(13 * NS);  // forward: 12 floats/segment (signed wrenches); adjoint: 13 floats/segment (two wrench cotangents + activation)
     o.epf = take(4);
     o.fwd_words = cur;
     o.aq = take(nq); o.aqd = take(nd);
     o.aqn = o.aq; o.aqdn = o.aqd;  // integrate^T turns the output cotangents into the input cotangents in place (per-link lanes)
     o.aact = take(nd); o.amact = take(M);
     o.aqdd = take(nd); o.atau = take(nd); o.aS = take(6 * nd); o.af = take(6 * L);
-    o.acx = take(13 * C); o.axsc = take(7 * L); o.axsj = take(7 * L); o.ac = take(3 * L);
+    o.acx = take(12 * C);   // per contact: cotangent wrench of the body's pose (6) + cotangent of the body's twist (6)
     o.av = take(6 * L); o.aa = take(6 * L); o.aatot = take(6 * L); o.avtot = take(6 * L); o.avj = take(6 * L);
-    o.ai10 = take(10 * L); o.ai10m = take(10 * L); o.aic10 = take(10 * (nd > L ? nd : L)); o.aH = take(nd * nd);
-    o.topar = take(7 * L); o.gua = take(M > nd ? M : nd); o.agx = take(13 * L);
+    o.aw = take(6 * L);     // pose cotangent of a link as a world-frame wrench (torque about the origin, force)
+    o.awp = take(6 * L);    // the same for the link's joint frame X_sj (what its motion subspace is attached to)
+    o.azs = take(6 * L);    // subtree sums of aw + awp
+    o.ai10m = take(10 * L); o.aic10 = take(10 * (nd > L ? nd : L)); o.aH = take(nd * nd);
+    o.gua = take(M > nd ? M : nd); o.agx = take(12 * L);
     o.total_words = cur;
 
     out.o = o;
-    int Dinner = 0;
-    for (int i = 0; i < L; ++i)
-        if (!child[i].empty() && level[i] + 1 > Dinner) Dinner = level[i] + 1;
-    out.d = DsimDims{L, nq, nd, C, M, W, NS, D, ranges ? DSIM_F_RANGES : 0, Dinner};
+    DsimDims dd;
+    memset(&dd, 0, sizeof(dd));
+    dd.L = L; dd.nq = nq; dd.nd = nd; dd.C = C; dd.M = M; dd.W = W; dd.NS = NS; dd.D = D;
+    dd.flags = ranges ? DSIM_F_RANGES : 0;
+    for (int i = 0; i < L; ++i) {
+        dd.tmask |= DSIM_TM(m.joint_type[i]);
+        for (size_t p = 0; p < anc[i].size() && p < DSIM_PMASK_N; ++p) dd.pmask[p] |= DSIM_TM(m.joint_type[anc[i][p]]);
+    }
+    out.d = dd;
     return "";
 }

@@ -21,6 +21,18 @@ def emu():
     return _lib
 
 
+_lay = None
+
+
+def layout_lib():
+    """the layout builder alone (tests/emu/dsim_layout_tool.cpp): does not depend on the generated static layouts"""
+    global _lay
+    if _lay is None:
+        subprocess.check_call(["make", "-C", EMU_DIR, "-s", "libdsim_layout.so"])
+        _lay = C.CDLL(os.path.join(EMU_DIR, "libdsim_layout.so"))
+    return _lay
+
+
 def _off_names():
     src = open(os.path.join(ROOT, "diffrl_amd", "csrc", "dsim_layout.hpp")).read()
     body = src[src.index("struct DsimOff {"):]
@@ -48,10 +60,12 @@ def layout(t):
     desc, keep = make_desc(t)
     names = _off_names()
     off = np.zeros(len(names) + 8, np.int32)
-    dims = np.zeros(12, np.int32)
-    n = emu().dsim_emu_layout(C.byref(desc), _p(off), C.c_int(off.size), _p(dims))
+    dims = np.zeros(24, np.int32)
+    n = layout_lib().dsim_emu_layout(C.byref(desc), _p(off), C.c_int(off.size), _p(dims))
     assert n == len(names), (n, len(names))
-    return dict(zip(names, off[:n].tolist())), dict(zip("L nq nd C M W NS D flags Dinner".split(), dims.tolist()))
+    d = dict(zip("L nq nd C M W NS D flags tmask".split(), dims.tolist()))
+    d["pmask"] = dims[10:20].tolist()
+    return dict(zip(names, off[:n].tolist())), d
 
 
 def substep_image(t, q, qd, act, mact, h):
