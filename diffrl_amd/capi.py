@@ -49,6 +49,7 @@ class Episode(C.Structure):
         ("progress", C.c_void_p), ("done", C.c_void_p), ("obs_before_reset", C.c_void_p), ("reset_q", C.c_void_p),
         ("reset_qd", C.c_void_p), ("reset_count", C.c_void_p), ("reset_pool", C.c_int32),
         ("episode_length", C.c_int32), ("height_terminate", C.c_int32), ("check_invalid", C.c_int32),
+        ("noise_q", C.c_void_p), ("noise_qd", C.c_void_p), ("noise_angle", C.c_float), ("seed", C.c_uint64),
     ]
 
 

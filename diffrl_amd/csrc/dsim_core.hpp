@@ -27,7 +27,7 @@
 #include "dsim_layout.hpp"
 #include "dsim_math.hpp"
 
-#define DSIM_NL 64
+#define DSIM_NL 64  // lanes of one wavefront; the lanes of an environment's workgroup are Exec::NL = 64 * waves
 
 typedef int __attribute__((may_alias)) dsim_int_a;
 
@@ -145,7 +145,7 @@ DSIM_FN float dsim_dot_n(const float* a, const float* b, int n) {
 // constant parts of the work arrays (written once per launch): the motion subspace of a free joint is the identity
 template <class Ctx, class Exec> DSIM_FN void dsim_init_static(const Ctx& c, Exec& ex) {
     ex.run([&](int lane) {
-        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+        for (int i = lane; i < c.d.L; i += Exec::NL) {
             const DsimLinkInfo li = dsim_link_info(c, i);
             if (li.type == DSIM_JOINT_FREE)
                 for (int k = 0; k < 6; ++k)
@@ -180,31 +180,31 @@ template <class Ctx> struct DsimChainRegs {
     }();
 };
 // (link, component) items, one per lane, with pre-order (range) numbering
-template <class Ctx> struct DsimSixRegs {
+template <class Ctx, int NL> struct DsimSixRegs {
     static constexpr bool value = []() {
         if constexpr (std::is_empty<decltype(Ctx::d)>::value)
-            return 6 * decltype(Ctx::d)::L <= DSIM_NL && (decltype(Ctx::d)::flags & DSIM_F_RANGES) != 0;
+            return 6 * decltype(Ctx::d)::L <= NL && (decltype(Ctx::d)::flags & DSIM_F_RANGES) != 0;
         else return false;
     }();
 };
-template <class Ctx> struct DsimAdofRegs {  // ... and few enough dofs for the ancestor-dof list of an item to sit in registers
+template <class Ctx, int NL> struct DsimAdofRegs {  // ... and few enough dofs for the ancestor-dof list of an item to sit in registers
     static constexpr bool value = []() {
         if constexpr (std::is_empty<decltype(Ctx::d)>::value)
-            return 6 * decltype(Ctx::d)::L <= DSIM_NL && (decltype(Ctx::d)::flags & DSIM_F_RANGES) != 0 && decltype(Ctx::d)::nd <= 16;
+            return 6 * decltype(Ctx::d)::L <= NL && (decltype(Ctx::d)::flags & DSIM_F_RANGES) != 0 && decltype(Ctx::d)::nd <= 16;
         else return false;
     }();
 };
 // roles are "item index == lane": needs every loop of that role to be a single pass
-template <class Ctx> struct DsimRoleRegs {  // link `lane` and dof `lane`
+template <class Ctx, int NL> struct DsimRoleRegs {  // link `lane` and dof `lane`
     static constexpr bool value = []() {
         if constexpr (std::is_empty<decltype(Ctx::d)>::value)
-            return decltype(Ctx::d)::L <= DSIM_NL && decltype(Ctx::d)::nd <= DSIM_NL;
+            return decltype(Ctx::d)::L <= NL && decltype(Ctx::d)::nd <= NL;
         else return false;
     }();
 };
-template <class Ctx> struct DsimContactRegs {  // contact `lane` / `63 - lane`
+template <class Ctx, int NL> struct DsimContactRegs {  // contact `lane` / `63 - lane`
     static constexpr bool value = []() {
-        if constexpr (std::is_empty<decltype(Ctx::d)>::value) return decltype(Ctx::d)::C <= DSIM_NL;
+        if constexpr (std::is_empty<decltype(Ctx::d)>::value) return decltype(Ctx::d)::C <= NL;
         else return false;
     }();
 };
@@ -224,7 +224,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_topo_init(const Ctx& c, Exec&
         }
         ch[4 * DSIM_CHAIN_MAX] = n;
     }
-    if constexpr (DsimRoleRegs<Ctx>::value) {
+    if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
         DsimTopoRegs& tp = ex.topo(lane);
         const int i = lane < c.d.L ? lane : 0;
         tp.own_type = CI(jtype)[i];
@@ -243,20 +243,20 @@ template <class Ctx, class Exec> DSIM_FN void dsim_topo_init(const Ctx& c, Exec&
         tp.dof_cs = CI(qstart)[l];
         tp.dof_ds = CI(qdstart)[l];
     }
-    if constexpr (DsimContactRegs<Ctx>::value) {
+    if constexpr (DsimContactRegs<Ctx, Exec::NL>::value) {
         DsimTopoRegs& tp = ex.topo(lane);
-        const int kf = lane < c.d.C ? lane : 0, kb = (DSIM_NL - 1 - lane) < c.d.C ? (DSIM_NL - 1 - lane) : 0;
+        const int kf = lane < c.d.C ? lane : 0, kb = (Exec::NL - 1 - lane) < c.d.C ? (Exec::NL - 1 - lane) : 0;
         tp.cbody_f = c.d.C > 0 ? CI(cbody)[kf] : 0;
         tp.cbody_b = c.d.C > 0 ? CI(cbody)[kb] : 0;
     }
-    if constexpr (DsimSixRegs<Ctx>::value) {
+    if constexpr (DsimSixRegs<Ctx, Exec::NL>::value) {
         DsimTopoRegs& tp = ex.topo(lane);
         const DsimLinkInfo li = dsim_link_info(c, lane < 6 * c.d.L ? lane / 6 : 0);
         tp.six_n = li.nsub;
         tp.six_c0 = li.c0;
         tp.six_nc = li.nc;
-        if constexpr (DsimAdofRegs<Ctx>::value) {
-            const int it = DSIM_NL - 1 - lane;
+        if constexpr (DsimAdofRegs<Ctx, Exec::NL>::value) {
+            const int it = Exec::NL - 1 - lane;
             const int j = it < 6 * c.d.L ? it / 6 : 0;
             const int e0 = CI(adof_start)[j], cnt = CI(adof_start)[j + 1] - e0;
             tp.adof_n = cnt;
@@ -301,7 +301,9 @@ struct DsimFkWalk {
 // types that can occur here.  Everything the position needs is LOADED FIRST (one LDS round trip; the words past a
 // joint's own coordinates are fetched but never used), then it is pure register arithmetic: no stores -- the lane
 // writes its results once, after the walk, so that no load of a later position has to wait behind a store.
-template <int MASK, class Ctx> DSIM_FN void dsim_fk_position(const Ctx& c, DsimFkWalk& w, int j, int type, int cs, int ds) {
+// FIRST: the chain's root position (parent pose = identity, v = a = 0 before it): X_sj = X_pj, v = v_j, and the bias
+// acceleration v x v_j of a vector with itself is exactly zero.
+template <int MASK, bool FIRST, class Ctx> DSIM_FN void dsim_fk_position(const Ctx& c, DsimFkWalk& w, int j, int type, int cs, int ds) {
     constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
     const float *q = WF(q), *qd = WF(qd);
     const v3 ppj = ld3(CF(xpj) + 7 * j);
@@ -312,8 +314,12 @@ template <int MASK, class Ctx> DSIM_FN void dsim_fk_position(const Ctx& c, DsimF
     for (int k = 0; k < NQ; ++k) qv[k] = q[cs + k];
 #pragma unroll
     for (int k = 0; k < NDF; ++k) qdv[k] = qd[ds + k];
-    const v3 pj = rotate(w.rsp, ppj) + w.psp;
-    const q4 rj = qmul(w.rsp, rpj);
+    v3 pj = ppj;
+    q4 rj = rpj;
+    if constexpr (!FIRST) {
+        pj = rotate(w.rsp, ppj) + w.psp;
+        rj = qmul(w.rsp, rpj);
+    }
     v3 pc = pj;
     q4 rc = rj;
     sv6 vj = zerosv();
@@ -336,7 +342,8 @@ template <int MASK, class Ctx> DSIM_FN void dsim_fk_position(const Ctx& c, DsimF
     if constexpr ((MASK & DSIM_TM(DSIM_JOINT_BALL)) != 0) {
         if (type == DSIM_JOINT_BALL) {
             rc = qmul(rj, mkq(qv[0], qv[1], qv[2], qv[3]));
-            const v3 u0 = rotate(rj, mk3(1.f, 0.f, 0.f)), u1 = rotate(rj, mk3(0.f, 1.f, 0.f)), u2 = rotate(rj, mk3(0.f, 0.f, 1.f));
+            v3 u0, u1, u2;
+            rotate_basis(rj, u0, u1, u2);
             w.s0 = mksv(u0, cross(pj, u0));
             w.s1 = mksv(u1, cross(pj, u1));
             w.s2 = mksv(u2, cross(pj, u2));
@@ -352,8 +359,12 @@ template <int MASK, class Ctx> DSIM_FN void dsim_fk_position(const Ctx& c, DsimF
             vj = mksv(mk3(qdv[0], qdv[1], qdv[2]), mk3(qdv[3], qdv[4], qdv[5]));  // S = identity (dsim_init_static)
         }
     }
-    w.v = w.v + vj;
-    w.a = w.a + scross(w.v, vj);
+    if constexpr (FIRST) {
+        w.v = vj;
+    } else {
+        w.v = w.v + vj;
+        w.a = w.a + scross(w.v, vj);
+    }
     w.pj = pj;
     w.rj = rj;
     w.psp = pc;
@@ -369,7 +380,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
     // Nothing is stored before the end of the walk: LDS stores in between would serialise the next position's loads
     // behind them (the compiler cannot prove that they do not alias).
     ex.run([&](int lane) {
-        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+        for (int i = lane; i < c.d.L; i += Exec::NL) {
             DsimFkWalk w;
             w.psp = zero3();
             w.rsp = mkq(0.f, 0.f, 0.f, 1.f);
@@ -383,7 +394,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
                 const int n = ch[4 * DSIM_CHAIN_MAX];
                 dsim_static_for<0, D::D>([&](auto P) {
                     constexpr int p = decltype(P)::value;
-                    if (p < n) dsim_fk_position<dsim_pos_mask<D, p>()>(c, w, ch[4 * p], ch[4 * p + 1], ch[4 * p + 2], ch[4 * p + 3]);
+                    if (p < n) dsim_fk_position<dsim_pos_mask<D, p>(), p == 0>(c, w, ch[4 * p], ch[4 * p + 1], ch[4 * p + 2], ch[4 * p + 3]);
                 });
                 own_type = ex.topo(lane).own_type;
                 own_ds = ex.topo(lane).own_ds;
@@ -393,7 +404,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
                 for (int e = e0; e < e1; ++e) {
                     const int j = CI(anc_list)[e];
                     li = dsim_link_info(c, j);
-                    dsim_fk_position<0x1f>(c, w, j, li.type, li.cs, li.ds);
+                    dsim_fk_position<0x1f, false>(c, w, j, li.type, li.cs, li.ds);
                 }
                 own_type = li.type;
                 own_ds = li.ds;
@@ -408,8 +419,8 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
             const v3 grav = ld3(CF(grav));
             const v3 cm = rotate(rc, com) + pc;
             // world-frame inertia about the origin: Theta = R Ic R^T, A = Theta + m(c.c 1 - c c^T), h = m c
-            const v3 rx = rotate(rc, mk3(1.f, 0.f, 0.f)), ry = rotate(rc, mk3(0.f, 1.f, 0.f)),
-                     rz = rotate(rc, mk3(0.f, 0.f, 1.f));
+            v3 rx, ry, rz;
+            rotate_basis(rc, rx, ry, rz);
             // B = R * Ic (columns of R are rx, ry, rz)
             const v3 b0 = rx * ic0 + ry * ic1 + rz * ic2;
             const v3 b1 = rx * ic1 + ry * ic3 + rz * ic4;
@@ -451,9 +462,9 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Ex
     ex.mark(2);
     if (c.d.C == 0 && c.d.NS == 0) return;
     ex.run([&](int lane) {
-        for (int k = lane; k < c.d.C; k += DSIM_NL) {
+        for (int k = lane; k < c.d.C; k += Exec::NL) {
             int b;
-            if constexpr (DsimContactRegs<Ctx>::value) b = ex.topo(lane).cbody_f;
+            if constexpr (DsimContactRegs<Ctx, Exec::NL>::value) b = ex.topo(lane).cbody_f;
             else b = CI(cbody)[k];
             const v3 xp = ld3(WF(xsc) + 7 * b);
             const q4 xq = ldq(WF(xsc) + 7 * b + 3);
@@ -480,7 +491,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Ex
             }
             stsv(WF(cw) + 6 * k, wr);
         }
-        for (int s = lane; s < c.d.NS; s += DSIM_NL) {
+        for (int s = lane; s < c.d.NS; s += Exec::NL) {
             const int w = CI(seg_wp)[s];
             const int l0 = CI(mlinks)[w], l1 = CI(mlinks)[w + 1];
             const v3 pos0 = ld3(WF(xsc) + 7 * l0) + rotate(ldq(WF(xsc) + 7 * l0 + 3), ld3(CF(mpoints) + 3 * w));
@@ -499,7 +510,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Ex
     });
     if (c.d.NS > 0) {
         ex.run([&](int lane) {
-            for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
+            for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
                 const int i = it / 6, k = it - 6 * i;
                 WF(f)[it] = dsim_gather_sum(WF(mus), 6, k, CI(ml_list), CI(ml_start)[i], CI(ml_start)[i + 1], WF(f)[it]);
             }
@@ -507,40 +518,48 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Ex
     }
 }
 
+// sum over subtree(i) of a per-link 6-vector component + sum over the contacts of all bodies in subtree(i) of a
+// per-contact component (forward: body forces + contact wrenches; adjoint: twist / pose-wrench cotangents)
+template <class Ctx, class Exec>
+DSIM_FN float dsim_subtree_contact_sum(const Ctx& c, Exec& ex, int lane, int i, const float* ldata, int k,
+                                       const float* cdata, int cstride, int ck) {
+    float acc;
+    if (c.d.flags & DSIM_F_RANGES) {
+        DsimLinkInfo li;
+        if constexpr (DsimSixRegs<Ctx, Exec::NL>::value) {
+            const DsimTopoRegs& tp = ex.topo(lane);
+            li.nsub = tp.six_n; li.c0 = tp.six_c0; li.nc = tp.six_nc;
+        } else {
+            li = dsim_link_info(c, i);
+        }
+        if constexpr (DsimIsStatic<Ctx>::value) {
+            acc = dsim_range_sum_b<dsim_cap_links<decltype(c.d)>()>(ldata, 6, k, i, li.nsub, 0.f);
+            acc = dsim_range_sum_b<dsim_cap_subtree_contacts<decltype(c.d)>()>(cdata, cstride, ck, li.c0, li.nc, acc);
+        } else {
+            acc = dsim_range_sum(ldata, 6, k, i, li.nsub, 0.f);
+            acc = dsim_range_sum(cdata, cstride, ck, li.c0, li.nc, acc);
+        }
+    } else {
+        acc = dsim_gather_sum(ldata, 6, k, CI(sub_list), CI(sub_start)[i], CI(sub_start)[i + 1], 0.f);
+        acc = dsim_gather_sum(cdata, cstride, ck, CI(scb_list), CI(scb_start)[i], CI(scb_start)[i + 1], acc);
+    }
+    return acc;
+}
+
 // joint-space forces (sim.py:1421-1502, 1792-1842)
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_tau(const Ctx& c, Exec& ex) {
     ex.mark(3);
     // f_tot[i] = sum over subtree(i) of (inverse-dynamics force [+ muscle wrenches, gathered per body]) + contact wrenches
     ex.run([&](int lane) {
-        for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
+        for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
             const int i = it / 6, k = it - 6 * i;
-            float acc;
-            if (c.d.flags & DSIM_F_RANGES) {
-                DsimLinkInfo li;
-                if constexpr (DsimSixRegs<Ctx>::value) {
-                    const DsimTopoRegs& tp = ex.topo(lane);
-                    li.nsub = tp.six_n; li.c0 = tp.six_c0; li.nc = tp.six_nc;
-                } else {
-                    li = dsim_link_info(c, i);
-                }
-                if constexpr (DsimIsStatic<Ctx>::value) {
-                    acc = dsim_range_sum_b<dsim_cap_links<decltype(c.d)>()>(WF(f), 6, k, i, li.nsub, 0.f);
-                    acc = dsim_range_sum_b<dsim_cap_subtree_contacts<decltype(c.d)>()>(WF(cw), 6, k, li.c0, li.nc, acc);
-                } else {
-                    acc = dsim_range_sum(WF(f), 6, k, i, li.nsub, 0.f);
-                    acc = dsim_range_sum(WF(cw), 6, k, li.c0, li.nc, acc);
-                }
-            } else {
-                acc = dsim_gather_sum(WF(f), 6, k, CI(sub_list), CI(sub_start)[i], CI(sub_start)[i + 1], 0.f);
-                acc = dsim_gather_sum(WF(cw), 6, k, CI(scb_list), CI(scb_start)[i], CI(scb_start)[i + 1], acc);
-            }
-            WF(ftot)[it] = acc;
+            WF(ftot)[it] = dsim_subtree_contact_sum(c, ex, lane, i, WF(f), k, WF(cw), 6, k);
         }
     });
     ex.run([&](int lane) {
-        for (int d = lane; d < c.d.nd; d += DSIM_NL) {
+        for (int d = lane; d < c.d.nd; d += Exec::NL) {
             int i, type, cs, ds;
-            if constexpr (DsimRoleRegs<Ctx>::value) {
+            if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
                 const DsimTopoRegs& tp = ex.topo(lane);
                 i = tp.dof_link; type = tp.dof_type; cs = tp.dof_cs; ds = tp.dof_ds;
             } else {
@@ -568,25 +587,32 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_composite(const Ctx& c, E
     ex.mark(4);
     const int nd = c.d.nd;
     ex.run([&](int lane) {
-        for (int it = lane; it < 10 * c.d.L; it += DSIM_NL) {
+        for (int it = lane; it < 10 * c.d.L; it += Exec::NL) {
             const int i = it / 10, k = it - 10 * i;
             WF(ic10)[it] = dsim_subtree_sum(c, WF(i10), 10, k, i);
         }
     });
     ex.run([&](int lane) {
-        for (int b = lane; b < nd; b += DSIM_NL) {
+        for (int b = lane; b < nd; b += Exec::NL) {
             const inertia10 I = ld_i10(WF(ic10) + 10 * CI(dof_link)[b]);
             stsv(WF(F) + 6 * b, inertia_mul(I, ldsv(WF(S) + 6 * b)));
         }
     });
 }
 
+// the register / cross-lane form of the Gauss-Jordan inverse needs a compile-time matrix size that fits one wavefront's lanes
+template <class Ctx, class Exec> struct DsimWaveGj {
+    static constexpr bool value = []() {
+        if constexpr (std::is_empty<decltype(Ctx::d)>::value) return decltype(Ctx::d)::nd <= 32;
+        else return false;
+    }();
+};
 // H = J^T M J in composite-rigid-body form + armature, inverted in place (Gauss-Jordan, SPD, no pivoting)
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_mass(const Ctx& c, Exec& ex) {
     const int nd = c.d.nd;
     dsim_fwd_composite(c, ex);
     ex.run([&](int lane) {
-        for (int it = lane; it < nd * nd; it += DSIM_NL) {
+        for (int it = lane; it < nd * nd; it += Exec::NL) {
             const int a = it / nd, b = it - nd * a;
             const int r = CI(rel)[it];
             float hv = 0.f;
@@ -596,21 +622,29 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_mass(const Ctx& c, Exec& 
             WF(hinv)[it] = hv;
         }
     });
-    for (int k = 0; k < nd; ++k) {
-        ex.run([&](int lane) {
-            for (int j = lane; j < nd; j += DSIM_NL) {
-                const float piv = WF(hinv)[k * nd + k];
-                WF(prow)[j] = (j == k ? 1.0f : WF(hinv)[k * nd + j]) / piv;
-                WF(pcol)[j] = WF(hinv)[j * nd + k];
-            }
-        });
-        ex.run([&](int lane) {
-            for (int it = lane; it < nd * nd; it += DSIM_NL) {
-                const int i = it / nd, j = it - nd * i;
-                if (i == k) WF(hinv)[it] = WF(prow)[j];
-                else WF(hinv)[it] = (j == k ? 0.0f : WF(hinv)[it]) - WF(pcol)[i] * WF(prow)[j];
-            }
-        });
+    // In-place Gauss-Jordan inverse, no pivoting (H is SPD).  Per pivot k: p_j = (j == k ? 1 : H[k][j]) * (1 / H[k][k]);
+    // row k <- p; every other row i: H[i][j] <- (j == k ? 0 : H[i][j]) - H[i][k] p_j.
+    // Specialised kernels: ONE phase -- lane i keeps row i in registers and the pivot row is broadcast across the
+    // wavefront with v_readlane (Exec::wave_gj), instead of 2 nd phases of LDS round trips.  Same formulas, same order.
+    if constexpr (DsimWaveGj<Ctx, Exec>::value) {
+        ex.template wave_gj<decltype(c.d)::nd>(WF(hinv));
+    } else {
+        for (int k = 0; k < nd; ++k) {
+            ex.run([&](int lane) {
+                for (int j = lane; j < nd; j += Exec::NL) {
+                    const float rp = 1.0f / WF(hinv)[k * nd + k];
+                    WF(prow)[j] = (j == k ? 1.0f : WF(hinv)[k * nd + j]) * rp;
+                    WF(pcol)[j] = WF(hinv)[j * nd + k];
+                }
+            });
+            ex.run([&](int lane) {
+                for (int it = lane; it < nd * nd; it += Exec::NL) {
+                    const int i = it / nd, j = it - nd * i;
+                    if (i == k) WF(hinv)[it] = WF(prow)[j];
+                    else WF(hinv)[it] = (j == k ? 0.0f : WF(hinv)[it]) - WF(pcol)[i] * WF(prow)[j];
+                }
+            });
+        }
     }
 }
 
@@ -618,7 +652,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_solve(const Ctx& c, Exec&
     ex.mark(5);
     const int nd = c.d.nd;
     ex.run([&](int lane) {
-        for (int i = lane; i < nd; i += DSIM_NL) {
+        for (int i = lane; i < nd; i += Exec::NL) {
             WF(qdd)[i] = dsim_dot_n(WF(hinv) + i * nd, WF(tau), nd);
         }
     });
@@ -637,9 +671,9 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_integrate(const Ctx& c, E
         constexpr int MASK = dsim_tmask_static<Ctx>();
         constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
         const float h = c.h;
-        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+        for (int i = lane; i < c.d.L; i += Exec::NL) {
             int type, cs, ds;
-            if constexpr (DsimRoleRegs<Ctx>::value) {
+            if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
                 const DsimTopoRegs& tp = ex.topo(lane);
                 type = tp.own_type; cs = tp.own_cs; ds = tp.own_ds;
             } else {
@@ -718,14 +752,15 @@ DSIM_FN void dsim_fwd_substep(const Ctx& c, Exec& ex, bool update_mass, float* g
     if (update_mass) dsim_fwd_mass(c, ex);
     dsim_fwd_solve(c, ex);
     if (g_row) {
-        // global stores to this environment's private rows: no barrier, no wait -- they drain while the step goes on
-        // (16 bytes per lane and instruction: the saved block and a checkpoint row are 16-byte aligned multiples of 4 words)
+        // Checkpoint row = the saved block.  Global stores to this environment's private row that nobody in this launch
+        // reads back: no wait -- they drain while the step goes on (16 bytes per lane and instruction: the saved block
+        // and a checkpoint row are 16-byte aligned multiples of 4 words).
         ex.fire([&](int lane) {
             const dsim_f4* src = reinterpret_cast<const dsim_f4*>(WF(q));
             dsim_f4* dst = reinterpret_cast<dsim_f4*>(g_row);
-            for (int k = lane; k < c.o.save_words / 4; k += DSIM_NL) dst[k] = src[k];
+            for (int k = lane; k < c.o.save_words / 4; k += Exec::NL) dst[k] = src[k];
             if (update_mass && g_hinv)
-                for (int k = lane; k < c.d.nd * c.d.nd; k += DSIM_NL) g_hinv[k] = WF(hinv)[k];
+                for (int k = lane; k < c.d.nd * c.d.nd; k += Exec::NL) g_hinv[k] = WF(hinv)[k];
         });
     }
     dsim_fwd_integrate(c, ex);
@@ -742,19 +777,19 @@ DSIM_FN void dsim_sim_step_forward(const Ctx& c, Exec& ex, int substeps, int mm_
     dsim_init_static(c, ex);
     ex.run([&](int lane) {
         dsim_topo_init(c, ex, lane);
-        for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = g_q[k];
-        for (int k = lane; k < nd; k += DSIM_NL) {
+        for (int k = lane; k < nq; k += Exec::NL) WF(q)[k] = g_q[k];
+        for (int k = lane; k < nd; k += Exec::NL) {
             WF(qd)[k] = g_qd[k];
             WF(act)[k] = g_act[k];
         }
-        for (int k = lane; k < M; k += DSIM_NL) WF(mact)[k] = g_mact[k];
+        for (int k = lane; k < M; k += Exec::NL) WF(mact)[k] = g_mact[k];
     });
     for (int s = 0; s < substeps; ++s)
         dsim_fwd_substep(c, ex, (s % mm_freq) == 0, g_ckpt ? g_ckpt + (size_t)s * c.o.save_words : nullptr,
                          g_ckpt ? dsim_ckpt_hinv(c, g_ckpt, substeps, s / mm_freq) : nullptr);
     ex.run([&](int lane) {
-        for (int k = lane; k < nq; k += DSIM_NL) g_q_out[k] = WF(q)[k];
-        for (int k = lane; k < nd; k += DSIM_NL) g_qd_out[k] = WF(qd)[k];
+        for (int k = lane; k < nq; k += Exec::NL) g_q_out[k] = WF(q)[k];
+        for (int k = lane; k < nd; k += Exec::NL) g_qd_out[k] = WF(qd)[k];
     });
 }
 
@@ -778,7 +813,7 @@ template <class Ctx> struct DsimHaccRegs {
 };
 template <class Ctx, class Exec> DSIM_FN void dsim_hacc_zero(const Ctx& c, Exec& ex, int lane) {
     if constexpr (DsimIsStatic<Ctx>::value) {
-        constexpr int NN = decltype(c.d)::nd * decltype(c.d)::nd, ACC = (NN + DSIM_NL - 1) / DSIM_NL;
+        constexpr int NN = decltype(c.d)::nd * decltype(c.d)::nd, ACC = (NN + Exec::NL - 1) / Exec::NL;
         if constexpr (ACC <= DSIM_HACC_MAX) {
             float* acc = ex.hacc(lane);
 #pragma unroll
@@ -795,9 +830,9 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
         constexpr int MASK = dsim_tmask_static<Ctx>();
         constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
         const float h = c.h;
-        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+        for (int i = lane; i < c.d.L; i += Exec::NL) {
             int type, cs, ds;
-            if constexpr (DsimRoleRegs<Ctx>::value) {
+            if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
                 const DsimTopoRegs& tp = ex.topo(lane);
                 type = tp.own_type; cs = tp.own_cs; ds = tp.own_ds;
             } else {
@@ -866,20 +901,20 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
         }
     });
     ex.run([&](int lane) {
-        for (int i = lane; i < nd; i += DSIM_NL) {
+        for (int i = lane; i < nd; i += Exec::NL) {
             WF(atau)[i] = dsim_dot_n(WF(hinv) + i * nd, WF(aqdd), nd);  // hinv is symmetric
         }
     });
     ex.run([&](int lane) {
         bool in_regs = false;
         if constexpr (DsimIsStatic<Ctx>::value) {
-            constexpr int NN = decltype(c.d)::nd * decltype(c.d)::nd, ACC = (NN + DSIM_NL - 1) / DSIM_NL;
+            constexpr int NN = decltype(c.d)::nd * decltype(c.d)::nd, ACC = (NN + Exec::NL - 1) / Exec::NL;
             if constexpr (ACC <= DSIM_HACC_MAX) {
                 in_regs = true;
                 float* acc = ex.hacc(lane);
 #pragma unroll
                 for (int m = 0; m < ACC; ++m) {
-                    const int it = lane + DSIM_NL * m;
+                    const int it = lane + Exec::NL * m;
                     if (it < NN) {
                         const int i = it / decltype(c.d)::nd, j = it - decltype(c.d)::nd * i;
                         acc[m] -= WF(atau)[i] * WF(qdd)[j];
@@ -889,14 +924,14 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
             }
         }
         if (!in_regs) {
-            for (int it = lane; it < nd * nd; it += DSIM_NL) {
+            for (int it = lane; it < nd * nd; it += Exec::NL) {
                 const int i = it / nd, j = it - nd * i;
                 WF(aH)[it] -= WF(atau)[i] * WF(qdd)[j];
             }
         }
-        for (int d = lane; d < nd; d += DSIM_NL) {
+        for (int d = lane; d < nd; d += Exec::NL) {
             int i, type, cs, ds;
-            if constexpr (DsimRoleRegs<Ctx>::value) {
+            if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
                 const DsimTopoRegs& tp = ex.topo(lane);
                 i = tp.dof_link; type = tp.dof_type; cs = tp.dof_cs; ds = tp.dof_ds;
             } else {
@@ -928,10 +963,10 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
         // cotangent of body_f_s[j]: f_tot of every ancestor-or-self i of j contains f[j] and tau_d = -S_d . f_tot[link(d)], so
         // af[j] = -sum over the dofs d of all ancestors-or-self of j of S_d atau_d (same phase: reads only S and atau;
         // items are dealt from the top lane down so that they do not pile onto the lanes of the per-dof loop above)
-        for (int it = DSIM_NL - 1 - lane; it < 6 * c.d.L; it += DSIM_NL) {
+        for (int it = Exec::NL - 1 - lane; it < 6 * c.d.L; it += Exec::NL) {
             const int j = it / 6, k = it - 6 * j;
             float acc = 0.f;
-            if constexpr (DsimAdofRegs<Ctx>::value) {
+            if constexpr (DsimAdofRegs<Ctx, Exec::NL>::value) {
                 // the dof list of this lane's item is in registers: operands in ONE round trip
                 constexpr int B = decltype(c.d)::nd;
                 const DsimTopoRegs& tp = ex.topo(lane);
@@ -987,10 +1022,10 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
 // the body's twist 6]; per muscle segment: [wrench on link 0, wrench on link 1, cotangent of the activation].
 // Runs inside the first body-level phase (both only need af); items are dealt from the top lane of the wavefront down.
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external_items(const Ctx& c, Exec& ex, int real_lane) {
-    const int lane = DSIM_NL - 1 - real_lane;
-    for (int k = lane; k < c.d.C; k += DSIM_NL) {
+    const int lane = Exec::NL - 1 - real_lane;
+    for (int k = lane; k < c.d.C; k += Exec::NL) {
         int b;
-        if constexpr (DsimContactRegs<Ctx>::value) b = ex.topo(real_lane).cbody_b;
+        if constexpr (DsimContactRegs<Ctx, Exec::NL>::value) b = ex.topo(real_lane).cbody_b;
         else b = CI(cbody)[k];
         const v3 xp = ld3(WF(xsc) + 7 * b);
         const q4 xq = ldq(WF(xsc) + 7 * b + 3);
@@ -1048,7 +1083,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external_items(const Ctx&
         stsv(o, wr);
         stsv(o + 6, tw);
     }
-    for (int s = lane; s < c.d.NS; s += DSIM_NL) {
+    for (int s = lane; s < c.d.NS; s += Exec::NL) {
         const int w = CI(seg_wp)[s];
         const int l0 = CI(mlinks)[w], l1 = CI(mlinks)[w + 1];
         const v3 pos0 = ld3(WF(xsc) + 7 * l0) + rotate(ldq(WF(xsc) + 7 * l0 + 3), ld3(CF(mpoints) + 3 * w));
@@ -1078,55 +1113,92 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external_items(const Ctx&
     }
 }
 
-// mass matrix^T (update substeps): aH -> aS (added), ai10m
+// mass matrix^T (update substeps): aH -> aS (added), ai10m.
+// H[a][b] = S_a^T Ic[deeper link] S_b for related dofs.  For dof a on link la the related dofs are (i) the dofs of the
+// strict subtree of la -- the deeper link is theirs, the term is S_a . F_b with F_b = Ic[link(b)] S_b -- and (ii) the
+// dofs of the ancestors-or-self of la (the list adof(la)) -- the deeper link is la, the term is S_a . Ic[la] S_b.
+// Both sets are short lists (a contiguous dof range with pre-order numbering), walked two entries per LDS round trip.
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_mass(const Ctx& c, Exec& ex) {
     ex.mark(9);
     const int nd = c.d.nd;
     ex.run([&](int lane) {
-        for (int a = lane; a < nd; a += DSIM_NL) {
+        for (int a = lane; a < nd; a += Exec::NL) {
             const int la = CI(dof_link)[a];
             sv6 acc = zerosv(), u = zerosv();
-            for (int b = 0; b < nd; ++b) {
-                const int r = CI(rel)[a * nd + b];
-                if (r == 0) continue;
-                // H[a][b] and H[b][a] are both S_a^T Ic S_b (for a == b the quadratic form gives the factor 2)
-                const float w = WF(aH)[a * nd + b] + WF(aH)[b * nd + a];
-                if (r == 1 && CI(dof_link)[b] != la) acc += ldsv(WF(F) + 6 * b) * w;
-                else u += ldsv(WF(S) + 6 * b) * w;
+            const float* aH = WF(aH);
+            // pair weight: H[a][b] and H[b][a] are the same bilinear form (for a == b this gives the factor 2 of the quadratic form)
+            if (c.d.flags & DSIM_F_RANGES) {
+                const int nsub = reinterpret_cast<const dsim_int_a*>(c.s)[c.o.linfo + 8 * la + 5];
+                int b = CI(qdstart)[la + 1];
+                const int b1 = CI(qdstart)[la + nsub];
+                for (; b + 2 <= b1; b += 2) {
+                    const float w0 = aH[a * nd + b] + aH[b * nd + a], w1 = aH[a * nd + b + 1] + aH[(b + 1) * nd + a];
+                    const sv6 f0 = ldsv(WF(F) + 6 * b), f1 = ldsv(WF(F) + 6 * b + 6);
+                    acc += f0 * w0;
+                    acc += f1 * w1;
+                }
+                if (b < b1) acc += ldsv(WF(F) + 6 * b) * (aH[a * nd + b] + aH[b * nd + a]);
+                const dsim_int_a* lst = CI(adof_list);
+                int e = CI(adof_start)[la];
+                const int e1 = CI(adof_start)[la + 1];
+                for (; e + 2 <= e1; e += 2) {
+                    const int d0 = lst[e], d1 = lst[e + 1];
+                    const float w0 = aH[a * nd + d0] + aH[d0 * nd + a], w1 = aH[a * nd + d1] + aH[d1 * nd + a];
+                    const sv6 s0 = ldsv(WF(S) + 6 * d0), s1 = ldsv(WF(S) + 6 * d1);
+                    u += s0 * w0;
+                    u += s1 * w1;
+                }
+                if (e < e1) {
+                    const int d0 = lst[e];
+                    u += ldsv(WF(S) + 6 * d0) * (aH[a * nd + d0] + aH[d0 * nd + a]);
+                }
+            } else {
+                for (int b = 0; b < nd; ++b) {
+                    const int r = CI(rel)[a * nd + b];
+                    if (r == 0) continue;
+                    const float w = aH[a * nd + b] + aH[b * nd + a];
+                    if (r == 1 && CI(dof_link)[b] != la) acc += ldsv(WF(F) + 6 * b) * w;
+                    else u += ldsv(WF(S) + 6 * b) * w;
+                }
             }
             acc += inertia_mul(ld_i10(WF(ic10) + 10 * la), u);
             float* o = WF(aS) + 6 * a;
-            add3(o, acc.w);
-            add3(o + 3, acc.v);
+            const sv6 g = ldsv(o);
+            stsv(o, g + acc);
         }
-        // cotangent of the composite inertia of link(b), one partial per dof b (upper lanes run concurrently with the
-        // aS loop above): pairs {a, b} whose deeper link is link(b); same-link pairs are counted once (a <= b)
-        for (int t = lane; t < nd + 32; t += DSIM_NL) {
+        // cotangent of the composite inertia of link(b), one partial per dof b (upper lanes: they do not pile onto the lanes
+        // of the aS loop above): pairs {a, b} whose deeper link is link(b), i.e. a in adof(link(b)) with a <= b (same-link
+        // pairs are counted once; ancestors have smaller dof indices)
+        for (int t = lane; t < nd + 32; t += Exec::NL) {
             const int b = t - 32;
             if (b < 0) continue;
             float g[10];
             for (int k = 0; k < 10; ++k) g[k] = 0.f;
             const int j = CI(dof_link)[b];
             const sv6 Sb = ldsv(WF(S) + 6 * b);
-            for (int a = 0; a < nd; ++a) {
-                const int la = CI(dof_link)[a];
-                float w;
-                if (la == j) {
-                    if (a > b) continue;
-                    w = (a == b) ? WF(aH)[a * nd + a] : WF(aH)[a * nd + b] + WF(aH)[b * nd + a];
-                } else if (CI(rel)[a * nd + b] == 1) {
-                    w = WF(aH)[a * nd + b] + WF(aH)[b * nd + a];
-                } else {
-                    continue;
-                }
-                inertia_bilinear_adj(g, ldsv(WF(S) + 6 * a), Sb, w);
+            const float* aH = WF(aH);
+            const dsim_int_a* lst = CI(adof_list);
+            int e = CI(adof_start)[j];
+            const int e1 = CI(adof_start)[j + 1];
+            for (; e + 2 <= e1; e += 2) {
+                const int a0 = lst[e], a1 = lst[e + 1];
+                const float w0 = (a0 == b) ? aH[a0 * nd + a0] : aH[a0 * nd + b] + aH[b * nd + a0];
+                const float w1 = (a1 == b) ? aH[a1 * nd + a1] : aH[a1 * nd + b] + aH[b * nd + a1];
+                const sv6 s0 = ldsv(WF(S) + 6 * a0), s1 = ldsv(WF(S) + 6 * a1);
+                if (a0 <= b) inertia_bilinear_adj(g, s0, Sb, w0);
+                if (a1 <= b) inertia_bilinear_adj(g, s1, Sb, w1);
+            }
+            if (e < e1) {
+                const int a0 = lst[e];
+                const float w0 = (a0 == b) ? aH[a0 * nd + a0] : aH[a0 * nd + b] + aH[b * nd + a0];
+                if (a0 <= b) inertia_bilinear_adj(g, ldsv(WF(S) + 6 * a0), Sb, w0);
             }
             for (int k = 0; k < 10; ++k) WF(aic10)[10 * b + k] = g[k];
         }
     });
     // ai10m[i] = sum over the dofs b of all ancestors-or-self of link i
     ex.run([&](int lane) {
-        for (int it = lane; it < 10 * c.d.L; it += DSIM_NL) {
+        for (int it = lane; it < 10 * c.d.L; it += Exec::NL) {
             const int i = it / 10, k = it - 10 * i;
             WF(ai10m)[it] = dsim_gather_sum(WF(aic10), 10, k, CI(adof_list), CI(adof_start)[i], CI(adof_start)[i + 1], 0.f);
         }
@@ -1166,7 +1238,7 @@ DSIM_FN sv6 inertia_pose_wrench(const inertia10& I, const float* g) {
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec& ex, bool update_mass) {
     ex.mark(10);
     ex.run([&](int lane) {
-        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+        for (int i = lane; i < c.d.L; i += Exec::NL) {
             const inertia10 I = ld_i10(WF(i10) + 10 * i);
             const sv6 v = ldsv(WF(v) + 6 * i), a = ldsv(WF(a) + 6 * i), r = ldsv(WF(af) + 6 * i);
             const v3 grav = ld3(CF(grav));
@@ -1193,49 +1265,53 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
         dsim_bwd_external_items(c, ex, lane);
     });
     ex.run([&](int lane) {
-        for (int m = lane; m < c.d.M; m += DSIM_NL) {
-            float acc = 0.f;
-            for (int s = CI(ms_start)[m]; s < CI(ms_start)[m + 1]; ++s) acc += WF(mus)[13 * s + 12];
-            WF(amact)[m] += acc;
+        for (int m = lane; m < c.d.M; m += Exec::NL) {
+            // a muscle's active segments are consecutive rows of `mus`: batched range sum, not a serial chain of loads
+            const int s0 = CI(ms_start)[m], s1 = CI(ms_start)[m + 1];
+            const float g = WF(amact)[m];
+            WF(amact)[m] = g + dsim_range_sum(WF(mus), 13, 12, s0, s1 - s0, 0.f);
         }
-        for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
+        for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
             const int i = it / 6, k = it - 6 * i;
             int n_known = -1;
-            if constexpr (DsimSixRegs<Ctx>::value) n_known = ex.topo(lane).six_n;
+            if constexpr (DsimSixRegs<Ctx, Exec::NL>::value) n_known = ex.topo(lane).six_n;
             WF(aatot)[it] = dsim_subtree_sum(c, WF(aa), 6, k, i, n_known);
         }
-        // per-body gather of the contact (12 floats: pose wrench 6, twist 6) and muscle (pose wrench 6) cotangents
-        for (int it = lane; it < 12 * c.d.L; it += DSIM_NL) {
-            const int i = it / 12, r = it - 12 * i;
-            float acc;
-            if (c.d.flags & DSIM_F_RANGES) {  // pre-order numbering: a body's own contacts are one contiguous range
-                if constexpr (DsimIsStatic<Ctx>::value)
-                    acc = dsim_range_sum_b<dsim_cap_body_contacts<decltype(c.d)>()>(WF(acx), 12, r, CI(cb_start)[i],
-                                                                                   CI(cb_start)[i + 1] - CI(cb_start)[i], 0.f);
-                else
-                    acc = dsim_range_sum(WF(acx), 12, r, CI(cb_start)[i], CI(cb_start)[i + 1] - CI(cb_start)[i], 0.f);
-            } else
-                acc = dsim_gather_sum(WF(acx), 12, r, CI(cb_list), CI(cb_start)[i], CI(cb_start)[i + 1], 0.f);
-            if (c.d.NS > 0 && r < 6)
-                for (int e = CI(ml_start)[i]; e < CI(ml_start)[i + 1]; ++e) {
-                    const int code = CI(ml_list)[e];
-                    acc += WF(mus)[13 * (code >> 1) + 6 * (code & 1) + r];
+        // per-body gather of the muscle pose wrenches (contact cotangents go straight into the subtree sums below)
+        if (c.d.NS > 0)
+            for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
+                const int i = it / 6, r = it - 6 * i;
+                // entry code 2 s + side -> row s, wrench `side` of the 13-float adjoint rows; four entries per round trip
+                float acc = 0.f;
+                const dsim_int_a* lst = CI(ml_list);
+                const float* mus = WF(mus) + r;
+                int e = CI(ml_start)[i];
+                const int e1 = CI(ml_start)[i + 1];
+                for (; e + 4 <= e1; e += 4) {
+                    const int c0 = lst[e], c1 = lst[e + 1], c2 = lst[e + 2], c3 = lst[e + 3];
+                    const float x0 = mus[6 * c0 + (c0 >> 1)], x1 = mus[6 * c1 + (c1 >> 1)], x2 = mus[6 * c2 + (c2 >> 1)],
+                                x3 = mus[6 * c3 + (c3 >> 1)];
+                    acc = (((acc + x0) + x1) + x2) + x3;
                 }
-            WF(agx)[it] = acc;
-        }
+                for (; e < e1; ++e) {
+                    const int code = lst[e];
+                    acc += mus[6 * code + (code >> 1)];
+                }
+                WF(agx)[it] = acc;
+            }
     });
     ex.run([&](int lane) {
         constexpr int MASK = dsim_tmask_static<Ctx>();
-        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+        for (int i = lane; i < c.d.L; i += Exec::NL) {
             int type, ds;
-            if constexpr (DsimRoleRegs<Ctx>::value) {
+            if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
                 const DsimTopoRegs& tp = ex.topo(lane);
                 type = tp.own_type; ds = tp.own_ds;
             } else {
                 type = CI(jtype)[i]; ds = CI(qdstart)[i];
             }
             const sv6 v = ldsv(WF(v) + 6 * i), A = ldsv(WF(aatot) + 6 * i);
-            sv6 a_v = ldsv(WF(av) + 6 * i) + ldsv(WF(agx) + 12 * i + 6), a_vj;
+            sv6 a_v = ldsv(WF(av) + 6 * i), a_vj;
             // vj = S qd of the link's own joint (not stored by the forward pass)
             sv6 vj = zerosv();
             if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
@@ -1255,25 +1331,27 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
         }
     });
     ex.run([&](int lane) {
-        for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
+        for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
             const int i = it / 6, k = it - 6 * i;
             int n_known = -1;
-            if constexpr (DsimSixRegs<Ctx>::value) n_known = ex.topo(lane).six_n;
-            WF(avtot)[it] = dsim_subtree_sum(c, WF(av), 6, k, i, n_known);
+            if constexpr (DsimSixRegs<Ctx, Exec::NL>::value) n_known = ex.topo(lane).six_n;
+            (void)n_known;
+            WF(avtot)[it] = dsim_subtree_contact_sum(c, ex, lane, i, WF(av), k, WF(acx), 12, 6 + k);  // + contact twist cotangents
         }
     });
     ex.run([&](int lane) {
         constexpr int MASK = dsim_tmask_static<Ctx>();
-        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+        for (int i = lane; i < c.d.L; i += Exec::NL) {
             int type, ds;
-            if constexpr (DsimRoleRegs<Ctx>::value) {
+            if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
                 const DsimTopoRegs& tp = ex.topo(lane);
                 type = tp.own_type; ds = tp.own_ds;
             } else {
                 type = CI(jtype)[i]; ds = CI(qdstart)[i];
             }
             const sv6 a_vj = ldsv(WF(avj) + 6 * i) + ldsv(WF(avtot) + 6 * i);
-            sv6 Z = ldsv(WF(aw) + 6 * i) + ldsv(WF(agx) + 12 * i);
+            sv6 Z = ldsv(WF(aw) + 6 * i);
+            if (c.d.NS > 0) Z += ldsv(WF(agx) + 6 * i);
             sv6 Wp = zerosv();
             float* aqd = WF(aqd);
             // vj = S qd: cotangents of qd and of S; S is attached to the joint frame X_sj: W_par = sum S x* adj_S
@@ -1304,19 +1382,20 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
         }
     });
     ex.run([&](int lane) {
-        for (int it = lane; it < 6 * c.d.L; it += DSIM_NL) {
+        for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
             const int i = it / 6, k = it - 6 * i;
             int n_known = -1;
-            if constexpr (DsimSixRegs<Ctx>::value) n_known = ex.topo(lane).six_n;
-            WF(azs)[it] = dsim_subtree_sum(c, WF(aw), 6, k, i, n_known);
+            if constexpr (DsimSixRegs<Ctx, Exec::NL>::value) n_known = ex.topo(lane).six_n;
+            (void)n_known;
+            WF(azs)[it] = dsim_subtree_contact_sum(c, ex, lane, i, WF(aw), k, WF(acx), 12, k);  // + contact pose wrenches
         }
     });
     // adj q_d = S_d . (subtree wrench of the link, without the part attached to the link's own joint frame)
     ex.run([&](int lane) {
         constexpr int MASK = dsim_tmask_static<Ctx>();
-        for (int i = lane; i < c.d.L; i += DSIM_NL) {
+        for (int i = lane; i < c.d.L; i += Exec::NL) {
             int type, cs, ds, par;
-            if constexpr (DsimRoleRegs<Ctx>::value) {
+            if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
                 const DsimTopoRegs& tp = ex.topo(lane);
                 type = tp.own_type; cs = tp.own_cs; ds = tp.own_ds; par = tp.own_parent;
             } else {
@@ -1372,13 +1451,13 @@ DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
     dsim_init_static(c, ex);
     ex.run([&](int lane) {
         dsim_topo_init(c, ex, lane);
-        for (int k = lane; k < nq; k += DSIM_NL) WF(aqn)[k] = g_gq_out[k];
-        for (int k = lane; k < nd; k += DSIM_NL) {
+        for (int k = lane; k < nq; k += Exec::NL) WF(aqn)[k] = g_gq_out[k];
+        for (int k = lane; k < nd; k += Exec::NL) {
             WF(aqdn)[k] = g_gqd_out[k];
             WF(act)[k] = g_act[k];
             WF(aact)[k] = 0.f;
         }
-        for (int k = lane; k < M; k += DSIM_NL) {
+        for (int k = lane; k < M; k += Exec::NL) {
             WF(mact)[k] = g_mact[k];
             WF(amact)[k] = 0.f;
         }
@@ -1395,7 +1474,7 @@ DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
             ex.run([&](int lane) {
                 ex.commit(WF(q), c.o.save_words, lane);
                 if (hv) {
-                    for (int k = lane; k < nd * nd; k += DSIM_NL) {
+                    for (int k = lane; k < nd * nd; k += Exec::NL) {
                         WF(hinv)[k] = hv[k];
                         WF(aH)[k] = 0.f;
                     }
@@ -1408,13 +1487,13 @@ DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
         }
     }
     ex.run([&](int lane) {
-        for (int k = lane; k < nq; k += DSIM_NL) g_gq_in[k] = WF(aqn)[k];
-        for (int k = lane; k < nd; k += DSIM_NL) {
+        for (int k = lane; k < nq; k += Exec::NL) g_gq_in[k] = WF(aqn)[k];
+        for (int k = lane; k < nd; k += Exec::NL) {
             g_gqd_in[k] = WF(aqdn)[k];
             if (g_gact) g_gact[k] = WF(aact)[k];
         }
         if (g_gmact)
-            for (int k = lane; k < M; k += DSIM_NL) g_gmact[k] = WF(amact)[k];
+            for (int k = lane; k < M; k += Exec::NL) g_gmact[k] = WF(amact)[k];
     });
 }
 
@@ -1460,7 +1539,29 @@ struct DsimEpisode {
     const float* reset_qd;  // [pool][N][nd]
     int* reset_count;       // [N] in/out
     int pool, episode_length, height_terminate, check_invalid;
+    const float* noise_q;   // [nq] or nullptr: in-kernel stochastic restart (include/dsim.h: dsim_episode)
+    const float* noise_qd;  // [nd] or nullptr
+    float noise_angle;
+    unsigned long long seed;
 };
+
+// Philox4x32-10 (Salmon et al., SC'11): counter-based generator, the one torch.rand uses on GPUs.  Restart noise of
+// environment e, restart number n, coordinate stream w: counter (e, n, w, 0), key = seed; 4 uniforms in [0, 1) with 24 bits.
+DSIM_FN void dsim_philox4(unsigned long long seed, unsigned e, unsigned n, unsigned w, float* u) {
+    unsigned c0 = e, c1 = n, c2 = w, c3 = 0u, k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned h0 = (unsigned)(p0 >> 32), l0 = (unsigned)p0, h1 = (unsigned)(p1 >> 32), l1 = (unsigned)p1;
+        const unsigned n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    u[0] = (float)(c0 >> 8) * (1.0f / 16777216.0f);
+    u[1] = (float)(c1 >> 8) * (1.0f / 16777216.0f);
+    u[2] = (float)(c2 >> 8) * (1.0f / 16777216.0f);
+    u[3] = (float)(c3 >> 8) * (1.0f / 16777216.0f);
+}
 #define DSIM_EP_DONE 1.0f
 #define DSIM_EP_INVALID 3.0f  // finished because the state blew up: reward forced to 0 (humanoid.py:340-356)
 
@@ -1468,10 +1569,10 @@ struct DsimEpisode {
 template <class Ctx, class Exec>
 DSIM_FN void dsim_env_load_actions(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, const float* g_actions) {
     ex.run([&](int lane) {
-        for (int k = lane; k < c.d.nd; k += DSIM_NL) WF(act)[k] = 0.f;
+        for (int k = lane; k < c.d.nd; k += Exec::NL) WF(act)[k] = 0.f;
     });
     ex.run([&](int lane) {
-        for (int k = lane; k < sp.n_act; k += DSIM_NL) {
+        for (int k = lane; k < sp.n_act; k += Exec::NL) {
             float a = g_actions[k];
             a = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
             if (sp.act_muscle) {
@@ -1508,10 +1609,10 @@ template <class Ctx, class Exec> DSIM_FN void dsim_env_obs_compute(const Ctx& c,
                 o[11 + nj + njd] = up.y;
                 o[12 + nj + njd] = hd.x * (tx / l) + hd.z * (tz / l);
             }
-            for (int k = lane; k < nj; k += DSIM_NL) o[11 + k] = q[7 + k];
-            for (int k = lane; k < njd; k += DSIM_NL) o[11 + nj + k] = sp.vel_scale * qd[6 + k];
+            for (int k = lane; k < nj; k += Exec::NL) o[11 + k] = q[7 + k];
+            for (int k = lane; k < njd; k += Exec::NL) o[11 + nj + k] = sp.vel_scale * qd[6 + k];
             if (sp.obs_actions)
-                for (int k = lane; k < sp.n_act; k += DSIM_NL) o[13 + nj + njd + k] = WF(ua)[k];
+                for (int k = lane; k < sp.n_act; k += Exec::NL) o[13 + nj + njd + k] = WF(ua)[k];
         } else if (sp.kind == DSIM_ENV_CARTPOLE) {
             if (lane == 0) {
                 o[0] = q[0];
@@ -1521,8 +1622,8 @@ template <class Ctx, class Exec> DSIM_FN void dsim_env_obs_compute(const Ctx& c,
                 o[4] = qd[1];
             }
         } else if (sp.kind == DSIM_ENV_PLANAR) {
-            for (int k = lane; k < nq - 1; k += DSIM_NL) o[k] = q[1 + k];
-            for (int k = lane; k < nd; k += DSIM_NL) o[nq - 1 + k] = qd[k];
+            for (int k = lane; k < nq - 1; k += Exec::NL) o[k] = q[1 + k];
+            for (int k = lane; k < nd; k += Exec::NL) o[nq - 1 + k] = qd[k];
         }
     });
 }
@@ -1577,7 +1678,7 @@ DSIM_FN void dsim_env_observe(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, flo
     dsim_env_obs_compute(c, ex, sp);
     ex.run([&](int lane) {
         const float* o = WF(obs);
-        for (int k = lane; k < sp.n_obs; k += DSIM_NL) g_obs[k] = o[k];
+        for (int k = lane; k < sp.n_obs; k += Exec::NL) g_obs[k] = o[k];
         if (lane == 0) g_rew[0] = dsim_env_reward(c, sp);
     });
 }
@@ -1593,7 +1694,7 @@ DSIM_FN void dsim_env_observe_adjoint(const Ctx& c, Exec& ex, const DsimEnvSpec&
     // (no dependence on this step) and the old one as obs_before_reset; an invalid state had its reward overwritten.
     const bool live = ep_flags == 0.f;
     ex.run([&](int lane) {
-        for (int k = lane; k < sp.n_obs; k += DSIM_NL) {  // obs buffer reused for its cotangent
+        for (int k = lane; k < sp.n_obs; k += Exec::NL) {  // obs buffer reused for its cotangent
             float g = (live && g_gobs) ? g_gobs[k] : 0.f;
             if (g_gobs_before) g += g_gobs_before[k];
             WF(obs)[k] = g;
@@ -1605,9 +1706,9 @@ DSIM_FN void dsim_env_observe_adjoint(const Ctx& c, Exec& ex, const DsimEnvSpec&
         float* go = WF(obs);
         if (sp.kind == DSIM_ENV_LOCOMOTION) {
             const int nj = nq - 7, njd = nd - 6, iu = 11 + nj + njd;
-            for (int k = lane; k < nj; k += DSIM_NL) WF(aqn)[7 + k] += go[11 + k];
-            for (int k = lane; k < njd; k += DSIM_NL) WF(aqdn)[6 + k] += sp.vel_scale * go[11 + nj + k];
-            for (int k = lane; k < sp.n_act; k += DSIM_NL) {
+            for (int k = lane; k < nj; k += Exec::NL) WF(aqn)[7 + k] += go[11 + k];
+            for (int k = lane; k < njd; k += Exec::NL) WF(aqdn)[6 + k] += sp.vel_scale * go[11 + nj + k];
+            for (int k = lane; k < sp.n_act; k += Exec::NL) {
                 const float a = WF(ua)[k];
                 float g = sp.obs_actions ? go[iu + 2 + k] : 0.f;
                 if (sp.rew_kind == DSIM_REW_SNU) g += gr * sp.act_pen * (a < 0.0f ? -1.0f : (a > 0.0f ? 1.0f : 0.0f));
@@ -1662,7 +1763,7 @@ DSIM_FN void dsim_env_observe_adjoint(const Ctx& c, Exec& ex, const DsimEnvSpec&
                 add3(WF(aqdn) + 3, g_lv);
             }
         } else if (sp.kind == DSIM_ENV_PLANAR) {
-            for (int k = lane; k < nq - 1; k += DSIM_NL) {
+            for (int k = lane; k < nq - 1; k += Exec::NL) {
                 float g = go[k];
                 if (sp.rew_kind == DSIM_REW_HOPPER) {
                     if (k == 0) {
@@ -1676,8 +1777,8 @@ DSIM_FN void dsim_env_observe_adjoint(const Ctx& c, Exec& ex, const DsimEnvSpec&
                 }
                 WF(aqn)[1 + k] += g;
             }
-            for (int k = lane; k < nd; k += DSIM_NL) WF(aqdn)[k] += go[nq - 1 + k] + (k == 0 ? gr : 0.f);
-            for (int k = lane; k < sp.n_act; k += DSIM_NL) WF(gua)[k] = gr * sp.act_pen * 2.0f * WF(ua)[k];
+            for (int k = lane; k < nd; k += Exec::NL) WF(aqdn)[k] += go[nq - 1 + k] + (k == 0 ? gr : 0.f);
+            for (int k = lane; k < sp.n_act; k += Exec::NL) WF(gua)[k] = gr * sp.act_pen * 2.0f * WF(ua)[k];
         } else if (sp.kind == DSIM_ENV_CARTPOLE) {
             if (lane == 0) {
                 const float th = atan2f(sinf(q[1]), cosf(q[1]));
@@ -1704,8 +1805,8 @@ DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& s
     dsim_init_static(c, ex);
     ex.run([&](int lane) {
         dsim_topo_init(c, ex, lane);
-        for (int k = lane; k < nq; k += DSIM_NL) WF(q)[k] = g_q[k];
-        for (int k = lane; k < nd; k += DSIM_NL) WF(qd)[k] = g_qd[k];
+        for (int k = lane; k < nq; k += Exec::NL) WF(q)[k] = g_q[k];
+        for (int k = lane; k < nd; k += Exec::NL) WF(qd)[k] = g_qd[k];
         if (lane == 0) WF(epf)[0] = 0.f;
     });
     dsim_env_load_actions(c, ex, sp, g_actions);
@@ -1715,11 +1816,11 @@ DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& s
     float* tail = g_ckpt ? dsim_ckpt_tail(c, g_ckpt, substeps, mm_freq) : nullptr;
     if (!ep.progress) {
         ex.fire([&](int lane) {
-            for (int k = lane; k < nq; k += DSIM_NL) g_q_out[k] = WF(q)[k];
-            for (int k = lane; k < nd; k += DSIM_NL) g_qd_out[k] = WF(qd)[k];
+            for (int k = lane; k < nq; k += Exec::NL) g_q_out[k] = WF(q)[k];
+            for (int k = lane; k < nd; k += Exec::NL) g_qd_out[k] = WF(qd)[k];
             if (tail) {
-                for (int k = lane; k < nq; k += DSIM_NL) tail[k] = WF(q)[k];
-                for (int k = lane; k < nd; k += DSIM_NL) tail[nq + k] = WF(qd)[k];
+                for (int k = lane; k < nq; k += Exec::NL) tail[k] = WF(q)[k];
+                for (int k = lane; k < nd; k += Exec::NL) tail[nq + k] = WF(qd)[k];
                 if (lane == 0) tail[nq + nd] = 0.f;
             }
         });
@@ -1731,9 +1832,9 @@ DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& s
         // humanoid.py:340-356: non-finite observation / state, or |q|, |qd| > 1e6
         ex.run([&](int lane) {
             bool bad = false;
-            for (int k = lane; k < nq; k += DSIM_NL) bad = bad || !(fabsf(WF(q)[k]) <= 1e6f);
-            for (int k = lane; k < nd; k += DSIM_NL) bad = bad || !(fabsf(WF(qd)[k]) <= 1e6f);
-            for (int k = lane; k < sp.n_obs; k += DSIM_NL) bad = bad || !(fabsf(WF(obs)[k]) <= 3.4028235e38f);
+            for (int k = lane; k < nq; k += Exec::NL) bad = bad || !(fabsf(WF(q)[k]) <= 1e6f);
+            for (int k = lane; k < nd; k += Exec::NL) bad = bad || !(fabsf(WF(qd)[k]) <= 1e6f);
+            for (int k = lane; k < sp.n_obs; k += Exec::NL) bad = bad || !(fabsf(WF(obs)[k]) <= 3.4028235e38f);
             if (bad) WF(epf)[0] = 1.f;  // every writer stores the same value
         });
     }
@@ -1743,10 +1844,10 @@ DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& s
         const bool bad = ep.check_invalid && WF(epf)[0] != 0.f;
         done = (ep.height_terminate && o[0] < sp.term_h) || p1 > (long long)(ep.episode_length - 1) || bad;
         if (ep.obs_before)
-            for (int k = lane; k < sp.n_obs; k += DSIM_NL) ep.obs_before[(size_t)e * sp.n_obs + k] = o[k];
+            for (int k = lane; k < sp.n_obs; k += Exec::NL) ep.obs_before[(size_t)e * sp.n_obs + k] = o[k];
         if (tail) {
-            for (int k = lane; k < nq; k += DSIM_NL) tail[k] = WF(q)[k];
-            for (int k = lane; k < nd; k += DSIM_NL) tail[nq + k] = WF(qd)[k];
+            for (int k = lane; k < nq; k += Exec::NL) tail[k] = WF(q)[k];
+            for (int k = lane; k < nd; k += Exec::NL) tail[nq + k] = WF(qd)[k];
         }
         if (lane == 0) {
             g_rew[0] = bad ? 0.f : dsim_env_reward(c, sp);
@@ -1756,24 +1857,59 @@ DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& s
             if (done) ep.reset_count[e] = cnt + 1;
         }
         if (!done) {
-            for (int k = lane; k < sp.n_obs; k += DSIM_NL) g_obs[k] = o[k];
-            for (int k = lane; k < nq; k += DSIM_NL) g_q_out[k] = WF(q)[k];
-            for (int k = lane; k < nd; k += DSIM_NL) g_qd_out[k] = WF(qd)[k];
+            for (int k = lane; k < sp.n_obs; k += Exec::NL) g_obs[k] = o[k];
+            for (int k = lane; k < nq; k += Exec::NL) g_q_out[k] = WF(q)[k];
+            for (int k = lane; k < nd; k += Exec::NL) g_qd_out[k] = WF(qd)[k];
         } else {
-            // restart: every lane replaces exactly the words it has just read
+            // restart: every lane replaces exactly the words it has just read.  Start state = pool entry [+ fresh uniform
+            // noise drawn here: coordinate k of q uses stream k, of qd stream 0x2000 + k, the root rotation stream 0x1000]
             const size_t slot = (size_t)(cnt % ep.pool) * n_envs + e;
-            for (int k = lane; k < nq; k += DSIM_NL) g_q_out[k] = WF(q)[k] = ep.reset_q[slot * nq + k];
-            for (int k = lane; k < nd; k += DSIM_NL) g_qd_out[k] = WF(qd)[k] = ep.reset_qd[slot * nd + k];
+            const bool root_rot = ep.noise_q && sp.kind == DSIM_ENV_LOCOMOTION && ep.noise_angle != 0.f;
+            for (int k = lane; k < nq; k += Exec::NL) {
+                float x = ep.reset_q[slot * nq + k];
+                if (ep.noise_q) {
+                    float u[4];
+                    if (root_rot && k >= 3 && k < 7) {
+                        // start rotation (x) rotation by (u0 - 0.5) * noise_angle about normalize((u1, u2, u3) - 0.5); all four
+                        // lanes of the block evaluate the same quaternion and keep their own component
+                        dsim_philox4(ep.seed, (unsigned)e, (unsigned)cnt, 0x1000u, u);
+                        const float half = 0.5f * (u[0] - 0.5f) * ep.noise_angle;
+                        v3 ax = mk3(u[1] - 0.5f, u[2] - 0.5f, u[3] - 0.5f);
+                        float l = sqrtf(dot(ax, ax));
+                        ax = ax * (1.0f / (l < 1e-9f ? 1e-9f : l));
+                        const float sh = sinf(half), ch = cosf(half);
+                        q4 dq = mkq(ax.x * sh, ax.y * sh, ax.z * sh, ch);
+                        l = sqrtf(qdot(dq, dq));
+                        dq = dq * (1.0f / (l < 1e-9f ? 1e-9f : l));
+                        const q4 r0 = ldq(ep.reset_q + slot * nq + 3);
+                        const q4 r = qmul(r0, dq);
+                        x = k == 3 ? r.x : (k == 4 ? r.y : (k == 5 ? r.z : r.w));
+                    } else {
+                        dsim_philox4(ep.seed, (unsigned)e, (unsigned)cnt, (unsigned)k, u);
+                        x += ep.noise_q[k] * (u[0] - 0.5f);
+                    }
+                }
+                g_q_out[k] = WF(q)[k] = x;
+            }
+            for (int k = lane; k < nd; k += Exec::NL) {
+                float x = ep.reset_qd[slot * nd + k];
+                if (ep.noise_qd) {
+                    float u[4];
+                    dsim_philox4(ep.seed, (unsigned)e, (unsigned)cnt, 0x2000u + (unsigned)k, u);
+                    x += ep.noise_qd[k] * (u[0] - 0.5f);
+                }
+                g_qd_out[k] = WF(qd)[k] = x;
+            }
         }
     });
     if (done) {
         // observation of the new state with cleared stored actions (ant.py:228-233)
         ex.run([&](int lane) {
-            for (int k = lane; k < sp.n_act; k += DSIM_NL) WF(ua)[k] = 0.f;
+            for (int k = lane; k < sp.n_act; k += Exec::NL) WF(ua)[k] = 0.f;
         });
         dsim_env_obs_compute(c, ex, sp);
         ex.fire([&](int lane) {
-            for (int k = lane; k < sp.n_obs; k += DSIM_NL) g_obs[k] = WF(obs)[k];
+            for (int k = lane; k < sp.n_obs; k += Exec::NL) g_obs[k] = WF(obs)[k];
         });
     }
 }
@@ -1783,9 +1919,9 @@ template <class Ctx, class Exec>
 DSIM_FN void dsim_env_observe_only(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, const float* g_q, const float* g_qd,
                                    const float* g_stored_actions, float* g_obs, float* g_rew) {
     ex.run([&](int lane) {
-        for (int k = lane; k < c.d.nq; k += DSIM_NL) WF(q)[k] = g_q[k];
-        for (int k = lane; k < c.d.nd; k += DSIM_NL) WF(qd)[k] = g_qd[k];
-        for (int k = lane; k < sp.n_act; k += DSIM_NL) WF(ua)[k] = g_stored_actions[k];
+        for (int k = lane; k < c.d.nq; k += Exec::NL) WF(q)[k] = g_q[k];
+        for (int k = lane; k < c.d.nd; k += Exec::NL) WF(qd)[k] = g_qd[k];
+        for (int k = lane; k < sp.n_act; k += Exec::NL) WF(ua)[k] = g_stored_actions[k];
     });
     dsim_env_observe(c, ex, sp, g_obs, g_rew);
 }
@@ -1806,25 +1942,25 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
         // only obs_before_reset could carry a cotangent -- through intermediates that are inf / NaN.  The reference
         // scrubs what comes out of that with nan_to_num hooks (humanoid.py:195-206); here the gradient is zero outright.
         ex.fire([&](int lane) {
-            for (int k = lane; k < nq; k += DSIM_NL) g_gq_in[k] = 0.f;
-            for (int k = lane; k < nd; k += DSIM_NL) g_gqd_in[k] = 0.f;
-            for (int k = lane; k < sp.n_act; k += DSIM_NL) g_gactions[k] = 0.f;
+            for (int k = lane; k < nq; k += Exec::NL) g_gq_in[k] = 0.f;
+            for (int k = lane; k < nd; k += Exec::NL) g_gqd_in[k] = 0.f;
+            for (int k = lane; k < sp.n_act; k += Exec::NL) g_gactions[k] = 0.f;
         });
         return;
     }
     dsim_init_static(c, ex);
     ex.run([&](int lane) {
         dsim_topo_init(c, ex, lane);
-        for (int k = lane; k < nq; k += DSIM_NL) {
+        for (int k = lane; k < nq; k += Exec::NL) {
             WF(q)[k] = tail[k];
             WF(aqn)[k] = (live && g_gq_out) ? g_gq_out[k] : 0.f;
         }
-        for (int k = lane; k < nd; k += DSIM_NL) {
+        for (int k = lane; k < nd; k += Exec::NL) {
             WF(qd)[k] = tail[nq + k];
             WF(aqdn)[k] = (live && g_gqd_out) ? g_gqd_out[k] : 0.f;
             WF(aact)[k] = 0.f;
         }
-        for (int k = lane; k < M; k += DSIM_NL) WF(amact)[k] = 0.f;
+        for (int k = lane; k < M; k += Exec::NL) WF(amact)[k] = 0.f;
     });
     dsim_env_load_actions(c, ex, sp, g_actions);
     dsim_env_observe_adjoint(c, ex, sp, g_gobs, g_grew, g_gobs_before, ep_flags);
@@ -1840,7 +1976,7 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
             ex.run([&](int lane) {
                 ex.commit(WF(q), c.o.save_words, lane);
                 if (hv) {
-                    for (int k = lane; k < nd * nd; k += DSIM_NL) {
+                    for (int k = lane; k < nd * nd; k += Exec::NL) {
                         WF(hinv)[k] = hv[k];
                         WF(aH)[k] = 0.f;
                     }
@@ -1853,9 +1989,9 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
         }
     }
     ex.run([&](int lane) {
-        for (int k = lane; k < nq; k += DSIM_NL) g_gq_in[k] = WF(aqn)[k];
-        for (int k = lane; k < nd; k += DSIM_NL) g_gqd_in[k] = WF(aqdn)[k];
-        for (int k = lane; k < sp.n_act; k += DSIM_NL) {
+        for (int k = lane; k < nq; k += Exec::NL) g_gq_in[k] = WF(aqn)[k];
+        for (int k = lane; k < nd; k += Exec::NL) g_gqd_in[k] = WF(aqdn)[k];
+        for (int k = lane; k < sp.n_act; k += Exec::NL) {
             const float a = g_actions[k];
             float g = WF(gua)[k];
             if (sp.act_muscle) g = 0.5f * (g + sp.act_scale[k] * WF(amact)[k]);

@@ -36,14 +36,55 @@ __device__ __forceinline__ void dsim_wave_sync() { asm volatile("s_waitcnt lgkmc
 
 #define DSIM_PF 6  // prefetch registers per lane (16 bytes each): rows up to 1536 floats (Humanoid: 1016)
 
-struct DevExec {
+template <int N, int NW> __device__ __forceinline__ void dsim_wave_gj(float* H) {
+    const int lane = (int)threadIdx.x;
+    if (NW > 1 && lane >= DSIM_NL) return;
+    const int r = lane < N ? lane : 0;  // idle lanes shadow row 0; they store nothing
+    float row[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) row[j] = H[r * N + j];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float piv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row[k]), k));
+        const float rp = 1.0f / piv;
+        const float cik = row[k];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float hkj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row[j]), k));
+            const float pj = (j == k ? 1.0f : hkj) * rp;
+            row[j] = (lane == k) ? pj : ((j == k ? 0.0f : row[j]) - cik * pj);
+        }
+    }
+    if (lane < N) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) H[lane * N + j] = row[j];
+    }
+}
+
+// NW wavefronts per environment (workgroup of 64 * NW lanes).  NW == 1: a phase boundary is the s_waitcnt above;
+// NW > 1: a workgroup barrier (phases whose item count exceeds 64 -- muscles, contacts, matrix entries of the bigger
+// models -- are spread over the waves, which sit on different SIMDs of the CU).
+template <int NW> struct DevExec {
+    static constexpr int NL = DSIM_NL * NW;
+    __device__ __forceinline__ void sync() {
+        if constexpr (NW == 1) dsim_wave_sync();
+        else __syncthreads();
+    }
     template <class F> __device__ __forceinline__ void run(F&& f) {
         f((int)threadIdx.x);
-        dsim_wave_sync();
+        sync();
     }
-    // phase that only writes global memory nobody in this launch reads back: no barrier, no vmcnt wait
-    template <class F> __device__ __forceinline__ void fire(F&& f) { f((int)threadIdx.x); }
+    // phase that only writes global memory nobody in this launch reads back: no vmcnt wait.  One wave: no barrier either
+    // (its LDS reads precede, in program order, whatever the next phase stores); several waves: the LDS words it reads
+    // must not be overwritten by a wave that runs ahead, hence a barrier.
+    template <class F> __device__ __forceinline__ void fire(F&& f) {
+        f((int)threadIdx.x);
+        if constexpr (NW > 1) __syncthreads();
+    }
     __device__ __forceinline__ void mark(int) {}
+    // Gauss-Jordan inverse of the N x N matrix at H (LDS, row-major), in place, by the first wavefront: lane i holds row i
+    // in registers, the pivot row travels through v_readlane (dsim_core.hpp: dsim_fwd_mass has the formulas).
+    template <int N> __device__ __forceinline__ void wave_gj(float* H) { dsim_wave_gj<N, NW>(H); sync(); }
     // lane-private accumulators of the mass-matrix cotangent (dsim_core.hpp: DSIM_HACC_MAX registers per lane)
     float hacc_[DSIM_HACC_MAX];
     __device__ __forceinline__ float* hacc(int) { return hacc_; }
@@ -56,23 +97,23 @@ struct DevExec {
     const float* pf_src;
     __device__ __forceinline__ void prefetch(const float* row, int words) {
         pf_src = row;
-        if (words > 4 * DSIM_NL * DSIM_PF) return;
+        if (words > 4 * NL * DSIM_PF) return;
         const dsim_f4* r4 = reinterpret_cast<const dsim_f4*>(row);
 #pragma unroll
         for (int r = 0; r < DSIM_PF; ++r) {
-            const int k = (int)threadIdx.x + DSIM_NL * r;
+            const int k = (int)threadIdx.x + NL * r;
             if (4 * k < words) pf[r] = r4[k];
         }
     }
     __device__ __forceinline__ void commit(float* dst, int words, int lane) {
-        if (words > 4 * DSIM_NL * DSIM_PF) {
-            for (int k = lane; k < words; k += DSIM_NL) dst[k] = pf_src[k];
+        if (words > 4 * NL * DSIM_PF) {
+            for (int k = lane; k < words; k += NL) dst[k] = pf_src[k];
             return;
         }
         dsim_f4* d4 = reinterpret_cast<dsim_f4*>(dst);
 #pragma unroll
         for (int r = 0; r < DSIM_PF; ++r) {
-            const int k = lane + DSIM_NL * r;
+            const int k = lane + NL * r;
             if (4 * k < words) d4[k] = pf[r];
         }
     }
@@ -87,10 +128,13 @@ template <class O, class D> struct KCommonT {
     long long ckpt_stride;  // floats per environment (dsim_ckpt_words)
 };
 
-template <class O, class D> __device__ __forceinline__ DsimCtxT<O, D> start_env(float* lds, const KCommonT<O, D>& k) {
-    uint32_t* l = reinterpret_cast<uint32_t*>(lds);
-    for (int i = threadIdx.x; i < k.o.const_words; i += DSIM_NL) l[i] = k.cblob[i];
-    dsim_wave_sync();
+template <int NW, class O, class D> __device__ __forceinline__ DsimCtxT<O, D> start_env(float* lds, const KCommonT<O, D>& k) {
+    // 16 bytes per lane and load (const_words is a multiple of 4, both sides are 16-byte aligned)
+    dsim_f4* l = reinterpret_cast<dsim_f4*>(lds);
+    const dsim_f4* g = reinterpret_cast<const dsim_f4*>(k.cblob);
+    for (int i = threadIdx.x; i < k.o.const_words / 4; i += DSIM_NL * NW) l[i] = g[i];
+    if constexpr (NW == 1) dsim_wave_sync();
+    else __syncthreads();
     DsimCtxT<O, D> c;
     c.s = lds;
     c.o = k.o;
@@ -99,8 +143,8 @@ template <class O, class D> __device__ __forceinline__ DsimCtxT<O, D> start_env(
     return c;
 }
 
-template <class O, class D>
-__global__ __launch_bounds__(DSIM_NL) void dsim_fwd_kernel(KCommonT<O, D> k, const float* __restrict__ q_in,
+template <class O, class D, int NW>
+__global__ __launch_bounds__(DSIM_NL * NW) void dsim_fwd_kernel(KCommonT<O, D> k, const float* __restrict__ q_in,
                                                            const float* __restrict__ qd_in,
                                                            const float* __restrict__ act,
                                                            const float* __restrict__ mact, float* q_out,
@@ -108,16 +152,16 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_fwd_kernel(KCommonT<O, D> k, con
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    auto c = start_env(lds, k);
-    DevExec ex;
+    auto c = start_env<NW>(lds, k);
+    DevExec<NW> ex;
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_sim_step_forward(c, ex, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, act + e * nd,
                           M ? mact + e * M : nullptr, q_out + e * nq, qd_out + e * nd,
                           ckpt ? ckpt + (size_t)e * k.ckpt_stride : nullptr);
 }
 
-template <class O, class D>
-__global__ __launch_bounds__(DSIM_NL) void dsim_bwd_kernel(KCommonT<O, D> k, const float* __restrict__ ckpt,
+template <class O, class D, int NW>
+__global__ __launch_bounds__(DSIM_NL * NW) void dsim_bwd_kernel(KCommonT<O, D> k, const float* __restrict__ ckpt,
                                                            const float* __restrict__ act,
                                                            const float* __restrict__ mact,
                                                            const float* __restrict__ gq_out,
@@ -126,16 +170,16 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_bwd_kernel(KCommonT<O, D> k, con
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    auto c = start_env(lds, k);
-    DevExec ex;
+    auto c = start_env<NW>(lds, k);
+    DevExec<NW> ex;
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_sim_step_backward(c, ex, k.substeps, k.mm_freq, ckpt + (size_t)e * k.ckpt_stride, act + e * nd,
                            M ? mact + e * M : nullptr, gq_out + e * nq, gqd_out + e * nd, gq_in + e * nq,
                            gqd_in + e * nd, gact ? gact + e * nd : nullptr, (gmact && M) ? gmact + e * M : nullptr);
 }
 
-template <class O, class D>
-__global__ __launch_bounds__(DSIM_NL) void dsim_env_fwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp, DsimEpisode ep,
+template <class O, class D, int NW>
+__global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_fwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp, DsimEpisode ep,
                                                                const float* __restrict__ q_in,
                                                                const float* __restrict__ qd_in,
                                                                const float* __restrict__ actions, float* q_out,
@@ -143,16 +187,16 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_env_fwd_kernel(KCommonT<O, D> k,
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    auto c = start_env(lds, k);
-    DevExec ex;
+    auto c = start_env<NW>(lds, k);
+    DevExec<NW> ex;
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_forward(c, ex, sp, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, actions + (size_t)e * sp.n_act,
                            q_out + e * nq, qd_out + e * nd, obs + (size_t)e * sp.n_obs, rew + e,
                            ckpt ? ckpt + (size_t)e * k.ckpt_stride : nullptr, ep, e, k.n_envs);
 }
 
-template <class O, class D>
-__global__ __launch_bounds__(DSIM_NL) void dsim_env_bwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp,
+template <class O, class D, int NW>
+__global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_bwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp,
                                                                const float* __restrict__ ckpt,
                                                                const float* __restrict__ actions,
                                                                const float* __restrict__ gq_out,
@@ -164,8 +208,8 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_env_bwd_kernel(KCommonT<O, D> k,
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    auto c = start_env(lds, k);
-    DevExec ex;
+    auto c = start_env<NW>(lds, k);
+    DevExec<NW> ex;
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_backward(c, ex, sp, k.substeps, k.mm_freq, ckpt + (size_t)e * k.ckpt_stride,
                             actions + (size_t)e * sp.n_act, gq_out ? gq_out + e * nq : nullptr,
@@ -174,8 +218,8 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_env_bwd_kernel(KCommonT<O, D> k,
                             gq_in + e * nq, gqd_in + e * nd, gactions + (size_t)e * sp.n_act);
 }
 
-template <class O, class D>
-__global__ __launch_bounds__(DSIM_NL) void dsim_env_obs_kernel(KCommonT<O, D> k, DsimEnvSpec sp,
+template <class O, class D, int NW>
+__global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_obs_kernel(KCommonT<O, D> k, DsimEnvSpec sp,
                                                                const float* __restrict__ q,
                                                                const float* __restrict__ qd,
                                                                const float* __restrict__ stored, float* obs,
@@ -188,14 +232,15 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_env_obs_kernel(KCommonT<O, D> k,
     c.o = k.o;
     c.d = k.d;
     c.h = k.h;
-    DevExec ex;
+    DevExec<NW> ex;
     dsim_env_observe_only(c, ex, sp, q + (size_t)e * k.d.nq, qd + (size_t)e * k.d.nd, stored + (size_t)e * sp.n_act,
                           obs + (size_t)e * sp.n_obs, rew + e);
 }
 
 #ifdef DSIM_ENABLE_PHASE_TIMER
 // developer tool (tools/phase_timer.py): per-phase cycle stamps of workgroup 0; NOT compiled into the product library
-struct TimingExec {
+template <int NW> struct TimingExec {
+    static constexpr int NL = DSIM_NL * NW;
     long long* buf;
     int idx, cap;
     int tag = 0;
@@ -210,7 +255,13 @@ struct TimingExec {
         ++tag;
         ++idx;
     }
-    template <class F> __device__ __forceinline__ void fire(F&& f) { f((int)threadIdx.x); }
+    template <class F> __device__ __forceinline__ void fire(F&& f) {
+        f((int)threadIdx.x);
+        if constexpr (NW > 1) __syncthreads();
+    }
+    template <int N> __device__ __forceinline__ void wave_gj(float* H) {
+        run([&](int) { dsim_wave_gj<N, NW>(H); });
+    }
     float hacc_[DSIM_HACC_MAX];
     __device__ __forceinline__ float* hacc(int) { return hacc_; }
     DsimTopoRegs topo_;
@@ -218,11 +269,11 @@ struct TimingExec {
     const float* pf_src;
     __device__ __forceinline__ void prefetch(const float* row, int) { pf_src = row; }
     __device__ __forceinline__ void commit(float* dst, int words, int lane) {
-        for (int k = lane; k < words; k += DSIM_NL) dst[k] = pf_src[k];
+        for (int k = lane; k < words; k += NL) dst[k] = pf_src[k];
     }
 };
-template <class O, class D>
-__global__ __launch_bounds__(DSIM_NL) void dsim_timer_kernel(KCommonT<O, D> k, DsimEnvSpec sp, int backward,
+template <class O, class D, int NW>
+__global__ __launch_bounds__(DSIM_NL * NW) void dsim_timer_kernel(KCommonT<O, D> k, DsimEnvSpec sp, int backward,
                                                              const float* q_in, const float* qd_in, const float* actions,
                                                              float* q_out, float* qd_out, float* obs, float* rew,
                                                              float* ckpt, const float* gq_out, const float* gqd_out,
@@ -231,8 +282,8 @@ __global__ __launch_bounds__(DSIM_NL) void dsim_timer_kernel(KCommonT<O, D> k, D
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    auto c = start_env(lds, k);
-    TimingExec ex{stamps, 1, cap};
+    auto c = start_env<NW>(lds, k);
+    TimingExec<NW> ex{stamps, 1, cap};
     if (blockIdx.x == 0 && threadIdx.x == 0) stamps[0] = clock64();
     const size_t nq = k.d.nq, nd = k.d.nd;
     float* ck = ckpt + (size_t)e * k.ckpt_stride;
@@ -284,21 +335,39 @@ struct dsim_model {
     DsimLayout lay;
     uint32_t* d_cblob = nullptr;
     int variant = V_GENERIC;
+    int waves = 1;   // wavefronts per environment: 1 or DSIM_WAVES_WIDE
 };
+#define DSIM_WAVES_WIDE 4
 
 namespace {
 
-// calls f(offsets, dims) with the (static or runtime) layout types of the model's kernel variant
+// calls f(offsets, dims, waves) with the (static or runtime) layout types of the model's kernel variant and the number of
+// wavefronts per environment as a compile-time constant
 template <class F> int dispatch(const dsim_model* m, F&& f) {
+    const bool wide = m->waves > 1;
     switch (m->variant) {
-#define DSIM_CASE(T) \
-    case V_##T:      \
-        return f(DsimOff##T{}, DsimDims##T{});
+#define DSIM_CASE(T)                                                                                   \
+    case V_##T:                                                                                        \
+        return wide ? f(DsimOff##T{}, DsimDims##T{}, std::integral_constant<int, DSIM_WAVES_WIDE>{})   \
+                    : f(DsimOff##T{}, DsimDims##T{}, std::integral_constant<int, 1>{});
         DSIM_STATIC_VARIANTS(DSIM_CASE)
 #undef DSIM_CASE
         default:
-            return f(m->lay.o, m->lay.d);
+            return wide ? f(m->lay.o, m->lay.d, std::integral_constant<int, DSIM_WAVES_WIDE>{})
+                        : f(m->lay.o, m->lay.d, std::integral_constant<int, 1>{});
     }
+}
+
+// Wavefronts per environment.  One wave is the lowest-latency mapping while the per-item phases are one or two passes
+// over a wavefront (Ant, Humanoid, the planar models, cartpole): a workgroup barrier costs more than a second pass, and
+// 4 waves per environment need 4 resident waves per SIMD at 1024 environments, which the kernels' ~200 registers per
+// lane do not allow (measured: Humanoid forward 0.45 -> 0.90 ms).  Models with item lists several wavefronts long
+// (SNUHumanoid: 198 muscle segments, 88 contacts) run 4 waves per environment: their long phases become single
+// passes on the CU's 4 SIMDs (SNUHumanoid 512 envs: 0.62 + 0.98 -> 0.48 + 0.67 ms).  DSIM_WAVES=1|4 overrides (A/B runs).
+int pick_waves(const DsimLayout& lay) {
+    if (const char* e = getenv("DSIM_WAVES")) return atoi(e) > 1 ? DSIM_WAVES_WIDE : 1;
+    const DsimDims& d = lay.d;
+    return (d.NS > DSIM_NL || d.C > DSIM_NL) ? DSIM_WAVES_WIDE : 1;
 }
 
 template <class O, class D>
@@ -385,6 +454,7 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
         return fail(DSIM_ERR_LIMIT, "model needs more than 160 KiB of LDS per environment");
     }
     m->variant = match_variant(m->lay);
+    m->waves = pick_waves(m->lay);
     hipError_t e = hipMalloc(&m->d_cblob, sizeof(uint32_t) * m->lay.cblob.size());
     if (e == hipSuccess)
         e = hipMemcpy(m->d_cblob, m->lay.cblob.data(), sizeof(uint32_t) * m->lay.cblob.size(), hipMemcpyHostToDevice);
@@ -392,14 +462,15 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
         // Opt in to > 64 KiB of dynamic LDS.  The attribute belongs to the kernel FUNCTION, not to this model: two models
         // that share a kernel variant (e.g. two user models on the generic kernels) must not lower each other's limit,
         // so it is set once to the hardware maximum (160 KiB); what a launch actually gets is its own byte count.
-        dispatch(m, [&](auto o, auto d) {
+        dispatch(m, [&](auto o, auto d, auto nw) {
             using O = decltype(o);
             using D = decltype(d);
-            const void* fns[] = {reinterpret_cast<const void*>(dsim_bwd_kernel<O, D>),
-                                 reinterpret_cast<const void*>(dsim_env_bwd_kernel<O, D>),
-                                 reinterpret_cast<const void*>(dsim_fwd_kernel<O, D>),
-                                 reinterpret_cast<const void*>(dsim_env_fwd_kernel<O, D>),
-                                 reinterpret_cast<const void*>(dsim_env_obs_kernel<O, D>)};
+            constexpr int NW = decltype(nw)::value;
+            const void* fns[] = {reinterpret_cast<const void*>(dsim_bwd_kernel<O, D, NW>),
+                                 reinterpret_cast<const void*>(dsim_env_bwd_kernel<O, D, NW>),
+                                 reinterpret_cast<const void*>(dsim_fwd_kernel<O, D, NW>),
+                                 reinterpret_cast<const void*>(dsim_env_fwd_kernel<O, D, NW>),
+                                 reinterpret_cast<const void*>(dsim_env_obs_kernel<O, D, NW>)};
             for (const void* fn : fns)
                 if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             return 0;
@@ -436,9 +507,10 @@ int dsim_step_forward(const dsim_model* m, int n_envs, const float* q_in, const 
     if (!q_in || !qd_in || !act || !q_out || !qd_out) return fail(DSIM_ERR_INVALID, "null state pointer");
     if (m->lay.d.M > 0 && !muscle_act) return fail(DSIM_ERR_INVALID, "model has muscles but muscle_act is null");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    return dispatch(m, [&](auto o, auto d) {
+    return dispatch(m, [&](auto o, auto d, auto nw) {
+        constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        hipLaunchKernelGGL((dsim_fwd_kernel<decltype(o), decltype(d)>), dim3(n_envs), dim3(DSIM_NL),
+        hipLaunchKernelGGL((dsim_fwd_kernel<decltype(o), decltype(d), NW>), dim3(n_envs), dim3(DSIM_NL * NW),
                            (size_t)m->lay.o.fwd_words * 4, st, k, q_in, qd_in, act, muscle_act, q_out, qd_out, ckpt);
         return launched("launch dsim_fwd_kernel");
     });
@@ -453,9 +525,10 @@ int dsim_step_backward(const dsim_model* m, int n_envs, const float* ckpt, const
         return fail(DSIM_ERR_INVALID, "null pointer (ckpt/act/grad)");
     if (m->lay.d.M > 0 && !muscle_act) return fail(DSIM_ERR_INVALID, "model has muscles but muscle_act is null");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    return dispatch(m, [&](auto o, auto d) {
+    return dispatch(m, [&](auto o, auto d, auto nw) {
+        constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        hipLaunchKernelGGL((dsim_bwd_kernel<decltype(o), decltype(d)>), dim3(n_envs), dim3(DSIM_NL),
+        hipLaunchKernelGGL((dsim_bwd_kernel<decltype(o), decltype(d), NW>), dim3(n_envs), dim3(DSIM_NL * NW),
                            (size_t)m->lay.o.total_words * 4, st, k, ckpt, act, muscle_act, gq_out, gqd_out, gq_in, gqd_in,
                            gact, gmuscle_act);
         return launched("launch dsim_bwd_kernel");
@@ -488,11 +561,16 @@ int dsim_env_step_forward(const dsim_model* m, const dsim_env_spec* env, int n_e
         ep.episode_length = episode->episode_length;
         ep.height_terminate = episode->height_terminate;
         ep.check_invalid = episode->check_invalid;
+        ep.noise_q = episode->noise_q;
+        ep.noise_qd = episode->noise_qd;
+        ep.noise_angle = episode->noise_angle;
+        ep.seed = episode->seed;
     }
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    return dispatch(m, [&](auto o, auto d) {
+    return dispatch(m, [&](auto o, auto d, auto nw) {
+        constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        hipLaunchKernelGGL((dsim_env_fwd_kernel<decltype(o), decltype(d)>), dim3(n_envs), dim3(DSIM_NL),
+        hipLaunchKernelGGL((dsim_env_fwd_kernel<decltype(o), decltype(d), NW>), dim3(n_envs), dim3(DSIM_NL * NW),
                            (size_t)m->lay.o.fwd_words * 4, st, k, sp, ep, q_in, qd_in, actions, q_out, qd_out, obs, rew,
                            ckpt);
         return launched("launch dsim_env_fwd_kernel");
@@ -510,9 +588,10 @@ int dsim_env_step_backward(const dsim_model* m, const dsim_env_spec* env, int n_
     if (rc) return rc;
     if (!ckpt || !actions || !gq_in || !gqd_in || !gactions) return fail(DSIM_ERR_INVALID, "null pointer");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    return dispatch(m, [&](auto o, auto d) {
+    return dispatch(m, [&](auto o, auto d, auto nw) {
+        constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        hipLaunchKernelGGL((dsim_env_bwd_kernel<decltype(o), decltype(d)>), dim3(n_envs), dim3(DSIM_NL),
+        hipLaunchKernelGGL((dsim_env_bwd_kernel<decltype(o), decltype(d), NW>), dim3(n_envs), dim3(DSIM_NL * NW),
                            (size_t)m->lay.o.total_words * 4, st, k, sp, ckpt, actions, gq_out, gqd_out, gobs, grew,
                            gobs_before_reset, gq_in, gqd_in, gactions);
         return launched("launch dsim_env_bwd_kernel");
@@ -528,9 +607,10 @@ int dsim_env_observe(const dsim_model* m, const dsim_env_spec* env, int n_envs, 
     if (rc) return rc;
     if (!q || !qd || !stored_actions || !obs || !rew) return fail(DSIM_ERR_INVALID, "null pointer");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    return dispatch(m, [&](auto o, auto d) {
+    return dispatch(m, [&](auto o, auto d, auto nw) {
+        constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, 1.0f, 1, 1);
-        hipLaunchKernelGGL((dsim_env_obs_kernel<decltype(o), decltype(d)>), dim3(n_envs), dim3(DSIM_NL),
+        hipLaunchKernelGGL((dsim_env_obs_kernel<decltype(o), decltype(d), NW>), dim3(n_envs), dim3(DSIM_NL * NW),
                            (size_t)m->lay.o.fwd_words * 4, st, k, sp, q, qd, stored_actions, obs, rew);
         return launched("launch dsim_env_obs_kernel");
     });
@@ -550,9 +630,10 @@ int dsim_debug_phase_timer(const dsim_model* m, const dsim_env_spec* env, int n_
     DsimEnvSpec sp;
     rc = make_spec(m, env, sp);
     if (rc) return rc;
-    return dispatch(m, [&](auto o, auto d) {
+    return dispatch(m, [&](auto o, auto d, auto nw) {
+        constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        hipLaunchKernelGGL((dsim_timer_kernel<decltype(o), decltype(d)>), dim3(n_envs), dim3(DSIM_NL),
+        hipLaunchKernelGGL((dsim_timer_kernel<decltype(o), decltype(d), NW>), dim3(n_envs), dim3(DSIM_NL * NW),
                            (size_t)m->lay.o.total_words * 4, static_cast<hipStream_t>(hip_stream), k, sp, backward, q_in,
                            qd_in, actions, q_out, qd_out, obs, rew, ckpt, gq_out, gqd_out, gobs, grew, gq_in, gqd_in, gactions,
                            stamps, cap);

@@ -61,6 +61,15 @@ DSIM_FN v3 rotate(q4 q, v3 x) {
     v3 qv = qvec(q);
     return x * (2.0f * q.w * q.w - 1.0f) + cross(qv, x) * (q.w * 2.0f) + qv * (dot(qv, x) * 2.0f);
 }
+// columns of the rotation matrix: rotate(q, e_x), rotate(q, e_y), rotate(q, e_z) with the exact-zero terms of the
+// formula above left out (0 * finite and + 0 are exact, so the values are those of three rotate() calls)
+DSIM_FN void rotate_basis(q4 q, v3& rx, v3& ry, v3& rz) {
+    const float a = 2.0f * q.w * q.w - 1.0f, b = q.w * 2.0f;
+    const float cx = q.x * 2.0f, cy = q.y * 2.0f, cz = q.z * 2.0f;
+    rx = v3{a + q.x * cx, q.z * b + q.y * cx, -q.y * b + q.z * cx};
+    ry = v3{-q.z * b + q.x * cy, a + q.y * cy, q.x * b + q.z * cy};
+    rz = v3{q.y * b + q.x * cz, -q.x * b + q.y * cz, a + q.z * cz};
+}
 // R(q)^T r : adjoint of rotate w.r.t. x
 DSIM_FN v3 rotate_inv(q4 q, v3 r) {
     v3 qv = qvec(q);

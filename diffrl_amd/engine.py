@@ -145,10 +145,12 @@ class EpisodeIO:
     start states finished environments restart from, and the termination rules."""
 
     def __init__(self, progress, reset_q, reset_qd, reset_count, episode_length, height_terminate, check_invalid,
-                 want_obs_before):
+                 want_obs_before, noise_q=None, noise_qd=None, noise_angle=0.0, seed=0):
         self.progress, self.reset_q, self.reset_qd, self.reset_count = progress, reset_q, reset_qd, reset_count
         self.episode_length, self.height_terminate, self.check_invalid = episode_length, height_terminate, check_invalid
         self.want_obs_before = want_obs_before
+        # in-kernel stochastic restart: per-coordinate noise amplitudes [n_q] / [n_qd] (device, float32) or None
+        self.noise_q, self.noise_qd, self.noise_angle, self.seed = noise_q, noise_qd, float(noise_angle), int(seed)
 
     def bind(self, engine, n, n_obs):
         dev = engine.device
@@ -167,6 +169,12 @@ class EpisodeIO:
         ep.reset_q, ep.reset_qd, ep.reset_count = self.reset_q.data_ptr(), self.reset_qd.data_ptr(), self.reset_count.data_ptr()
         ep.reset_pool, ep.episode_length = int(k), int(self.episode_length)
         ep.height_terminate, ep.check_invalid = int(bool(self.height_terminate)), int(bool(self.check_invalid))
+        for t, cols, name in ((self.noise_q, engine.n_q, "noise_q"), (self.noise_qd, engine.n_qd, "noise_qd")):
+            if t is not None and (t.device != dev or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != cols):
+                raise capi.DsimError("episode.%s must be a contiguous float32 [%d] tensor on %s" % (name, cols, dev))
+        ep.noise_q = self.noise_q.data_ptr() if self.noise_q is not None else None
+        ep.noise_qd = self.noise_qd.data_ptr() if self.noise_qd is not None else None
+        ep.noise_angle, ep.seed = self.noise_angle, self.seed & 0xFFFFFFFFFFFFFFFF
         return ep, (obs_before, done)
 
 

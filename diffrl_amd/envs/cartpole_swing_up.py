@@ -67,12 +67,14 @@ class CartPoleSwingUpEnv(DFlexEnv):
             q[env_ids, :] = q[env_ids, :] + np.pi * (torch.rand(size=(k, self.num_joint_q), device=self.device) - 0.5)
             qd[env_ids, :] = qd[env_ids, :] + 0.5 * (torch.rand(size=(k, self.num_joint_qd), device=self.device) - 0.5)
 
+    def reset_noise(self):
+        return np.full(self.num_joint_q, np.pi, np.float32), np.full(self.num_joint_qd, 0.5, np.float32), 0.0
+
     def clear_grad(self, checkpoint=None):
         with torch.no_grad():
             q, qd, act = self.state.joint_q.clone(), self.state.joint_qd.clone(), self.state.joint_act.clone()
             self.state = self.model.state()
             self.state.joint_q, self.state.joint_qd, self.state.joint_act = q, qd, act
-            self._pool_stale = True
 
     def calculateObservations(self):
         q, qd = self._q(), self._qd()

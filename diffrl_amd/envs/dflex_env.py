@@ -130,49 +130,54 @@ class DFlexEnv:
     # termination rules the fused step applies in-kernel (the tail of the reference's calculateReward)
     height_terminate = False     # obs[:, 0] < termination_height
     check_invalid = False        # non-finite / exploded state -> reset with reward 0 (humanoid.py:340-356)
-    reset_pool_size = 2          # start states kept per environment when resets are stochastic
+    def reset_noise(self):
+        """(noise_q [n_q], noise_qd [n_qd], noise_angle): amplitudes of the uniform noise a stochastic restart adds to the
+        start state, coordinate k gets + noise[k] * (u - 0.5), u ~ U[0, 1) -- the environment's reset_state() written
+        as data, so that the fused step can draw a FRESH start state in the kernel for every restart (envs/ant.py:199-234
+        does it with torch.rand per reset).  None: the environment has no stochastic reset."""
+        return None
 
-    def _draw_start_states(self, k):
-        """[k][num_envs][nq], [k][num_envs][nd]: k independent draws of reset_state() for every environment"""
+    def _deterministic_start_state(self):
+        """[1][num_envs][nq], [1][num_envs][nd]: reset_state() of every environment without the stochastic part"""
         saved_state, saved_actions = self.state, self.actions
+        saved_flag = getattr(self, "stochastic_init", False)
         ids = torch.arange(self.num_envs, dtype=torch.long, device=self.device)
-        qs, qds = [], []
         with torch.no_grad():
-            for _ in range(k):
-                st = self.model.state()
-                st.joint_q, st.joint_qd = self.model.joint_q.clone(), self.model.joint_qd.clone()
-                self.state = st
+            st = self.model.state()
+            st.joint_q, st.joint_qd = self.model.joint_q.clone(), self.model.joint_qd.clone()
+            self.state = st
+            self.stochastic_init = False
+            try:
                 self.reset_state(ids)
-                qs.append(self.state.joint_q.view(self.num_envs, -1))
-                qds.append(self.state.joint_qd.view(self.num_envs, -1))
+            finally:
+                self.stochastic_init = saved_flag
+            q, qd = self.state.joint_q.view(1, self.num_envs, -1).clone(), self.state.joint_qd.view(1, self.num_envs, -1).clone()
         self.state, self.actions = saved_state, saved_actions
-        return torch.stack(qs).contiguous(), torch.stack(qds).contiguous()
+        return q.contiguous(), qd.contiguous()
 
     def _episode_io(self):
-        """EpisodeIO of the fused step: progress_buf + the pool of start states that finished environments restart from.
-        The pool is drawn with this environment's own reset_state(); with stochastic resets it is redrawn after every
-        clear_grad() (once per rollout), so an environment repeats a start state only if it finishes more than
-        reset_pool_size times within one rollout."""
+        """EpisodeIO of the fused step: progress_buf, the deterministic start state of every environment and -- with
+        stochastic resets -- the noise amplitudes the kernel perturbs it with (a fresh counter-based draw per restart:
+        no pool to exhaust, no host work per step, nothing to redraw under a captured graph)."""
         from ..engine import EpisodeIO
-        stochastic = bool(getattr(self, "stochastic_init", False))
-        if getattr(self, "_pool", None) is None or (stochastic and self._pool_stale and not getattr(self, "_pool_frozen", False)):
-            self._pool = self._draw_start_states(self.reset_pool_size if stochastic else 1)
-            self._pool_stale = False
-            if getattr(self, "_reset_count", None) is None:
-                self._reset_count = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        if getattr(self, "_pool", None) is None:
+            self._pool = self._deterministic_start_state()
+            self._reset_count = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+            self._noise = None
+            if bool(getattr(self, "stochastic_init", False)):
+                n = self.reset_noise()
+                if n is None:
+                    raise NotImplementedError("%s: stochastic_init needs reset_noise() for the fused step" % type(self).__name__)
+                nq, nqd, ang = n
+                self._noise = (torch.as_tensor(nq, dtype=torch.float32).to(self.device).contiguous(),
+                               torch.as_tensor(nqd, dtype=torch.float32).to(self.device).contiguous(), float(ang))
         if not self.progress_buf.is_contiguous():
             self.progress_buf = self.progress_buf.contiguous()
+        nq, nqd, ang = self._noise if self._noise is not None else (None, None, 0.0)
         return EpisodeIO(self.progress_buf, self._pool[0], self._pool[1], self._reset_count, self.episode_length,
-                         self.height_terminate, self.check_invalid, want_obs_before=not self.no_grad)
-
-    def redraw_start_states(self):
-        """new random start states into the EXISTING pool tensors (graph replays keep their addresses, diffrl_amd/graph.py)"""
-        if getattr(self, "_pool", None) is None:
-            self._episode_io()
-        elif getattr(self, "stochastic_init", False):
-            q, qd = self._draw_start_states(self._pool[0].shape[0])
-            self._pool[0].copy_(q)
-            self._pool[1].copy_(qd)
+                         self.height_terminate, self.check_invalid, want_obs_before=not self.no_grad,
+                         noise_q=nq, noise_qd=nqd, noise_angle=ang,
+                         seed=(int(self.seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF)
 
     def _step_fused(self, actions, spec):
         actions = actions.view((self.num_envs, self.num_actions))
@@ -335,7 +340,6 @@ class DFlexEnv:
             self.state = st
             if act is not None:
                 self.state.joint_act = act
-            self._pool_stale = True
 
     def detach_buffers(self):
         """drops every reference this object holds into an autograd graph (observation / reward buffers, extras, state):

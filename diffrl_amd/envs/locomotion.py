@@ -58,6 +58,13 @@ class FloatingBaseEnv(DFlexEnv):
         self.actions = self.actions.clone()
         self.actions[env_ids, :] = 0.0
 
+    def reset_noise(self):
+        nq = np.zeros(self.num_joint_q, np.float32)
+        nq[0:3] = 0.1 * 2.0
+        if self.randomize_joints:
+            nq[7:] = 0.2 * 2.0
+        return nq, np.full(self.num_joint_qd, 0.5, np.float32), np.pi / 12.0
+
     def calculateObservations(self):
         q, qd = self._q(), self._qd()
         torso_pos, torso_rot = q[:, 0:3], q[:, 3:7]

@@ -59,6 +59,13 @@ class PlanarEnv(DFlexEnv):
         self.actions = self.actions.clone()
         self.actions[env_ids, :] = 0.0
 
+    def reset_noise(self):
+        nq = np.empty(self.num_joint_q, np.float32)
+        nq[0:2] = self.pos_noise * 2.0
+        nq[2] = self.rot_noise
+        nq[3:] = self.joint_noise * 2.0
+        return nq, np.full(self.num_joint_qd, self.vel_noise[0] * self.vel_noise[1], np.float32), 0.0
+
     def calculateObservations(self):
         self.obs_buf = torch.cat([self._q()[:, 1:], self._qd()], dim=-1)
 

@@ -42,12 +42,10 @@ class GraphedRollout:
             self._act = env.actions.detach().clone()
             self._progress = env.progress_buf.clone()
         self._frames_per_replay = None
-        # The environments' reset_state() (reference-style indexed writes) is not capturable, so the pool of start states
-        # that finished environments restart from is drawn eagerly, in place, before every replay instead of inside the
-        # body's clear_grad(); the captured kernels read it from fixed addresses.
-        env.redraw_start_states()
-        env._pool_frozen = True
-        self._stochastic = bool(getattr(env, "stochastic_init", False))
+        # Finished environments restart inside the captured step kernels: the start state is perturbed with counter-based
+        # random numbers keyed by the per-environment restart counter, which lives in device memory and advances with every
+        # replay -- nothing has to be drawn on the host (the reference's reset_state() indexed writes are not capturable).
+        env._episode_io()
         # warm-up on a side stream (lazy initialisation, allocator pools), as torch.cuda.graph requires
         side = torch.cuda.Stream(device=env.device)
         side.wait_stream(torch.cuda.current_stream(env.device))
@@ -88,8 +86,6 @@ class GraphedRollout:
 
     def replay(self):
         """re-executes the captured rollout (forward + backward); returns the static loss tensor"""
-        if self._stochastic:
-            self.env.redraw_start_states()
         self.graph.replay()
         if self._frames_per_replay:
             self.env.num_frames += self._frames_per_replay

@@ -158,9 +158,16 @@ typedef struct dsim_env_spec {
 /* Episode bookkeeping fused into the step kernel.  Replaces, per env.step(), the torch ops and the device->host sync of
  * the reference: progress_buf += 1 and reset_buf at the end of calculateReward (envs/ant.py:176-184, 297-307;
  * humanoid.py:340-356; hopper.py:288-293), env_ids = reset_buf.nonzero() and reset(env_ids) (ant.py:186-234).
- * A finished environment e restarts from entry (reset_count[e] % reset_pool) of a pool of start states which the host
- * draws from the environment's own reset distribution; q_out / qd_out / obs then describe the NEW state (stored actions
- * cleared), obs_before_reset the old one, rew the old one (0 for an invalid state), progress[e] = 0, done[e] = 1. */
+ * A finished environment e restarts from entry (reset_count[e] % reset_pool) of a pool of start states [normally one:
+ * the deterministic start state], perturbed IN THE KERNEL when noise_q / noise_qd are given -- a fresh draw for every
+ * restart, as the reference's reset() does with torch.rand (envs/ant.py:199-234, hopper.py:180-212,
+ * cartpole_swing_up.py:140-160): coordinate k gets  + noise[k] * (u - 0.5)  with u uniform in [0, 1) from the counter-based
+ * generator Philox4x32-10 keyed by `seed` at counter (environment index, reset_count[e], coordinate), so a restart never
+ * repeats a state, needs no host work and is replay-safe under a captured HIP graph; for a free-floating root
+ * (DSIM_ENV_LOCOMOTION) the start rotation is composed with a rotation by (u - 0.5) * noise_angle about a uniformly drawn
+ * axis (normalize(u3 - 0.5), ant.py:208-213) and noise_q[3..6] is ignored.
+ * q_out / qd_out / obs then describe the NEW state (stored actions cleared), obs_before_reset the old one, rew the old
+ * one (0 for an invalid state), progress[e] = 0, done[e] = 1. */
 typedef struct dsim_episode {
     int64_t* progress;          /* [N] in/out: progress_buf */
     int64_t* done;              /* [N] out: reset_buf */
@@ -172,6 +179,10 @@ typedef struct dsim_episode {
     int32_t episode_length;     /* done when progress > episode_length - 1 */
     int32_t height_terminate;   /* done when obs[0] < spec.termination_height */
     int32_t check_invalid;      /* done, reward 0, when obs / q / qd is non-finite or |q|, |qd| > 1e6 */
+    const float* noise_q;       /* [n_q] DEVICE pointer or NULL: amplitude of the uniform restart noise per coordinate */
+    const float* noise_qd;      /* [n_qd] DEVICE pointer or NULL */
+    float noise_angle;          /* free-floating root: amplitude of the random start rotation (radians) */
+    uint64_t seed;              /* Philox key */
 } dsim_episode;
 
 /* actions[N][n_act] -> q_out, qd_out, obs[N][n_obs], rew[N]  (+ ckpt as in dsim_step_forward; use dsim_ckpt_floats_mm).

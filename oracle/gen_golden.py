@@ -17,6 +17,8 @@ path, so parity is pinned by these files instead:
   ant_1024x32.npz    BASELINE.json configs[1] literally: 1024 envs, H = 32 (slimmed, see main; `... ant_1024x32`)
   cartpole_rollout_64x16.npz   BASELINE.json configs[0] literally: 64 envs, H = 16 (`... cartpole_64x16`)
   humanoid_rollout_h32.npz, snu_rollout_h32.npz   H = 32, 2 envs (`python oracle/gen_golden.py h32_extra`)
+  <env>_rollout_mm1.npz  (`... mm1`) Ant 8 x H=8, SNU 2 x H=4, Humanoid 2 x H=4 with MM_caching_frequency = 1
+  humanoid_exploded.npz  (`... exploded`) a rollout in which two environments blow up (finite > 1e6, and inf / NaN)
   <env>_episode.npz  (`... ant_extra`, `... episodes_extra`)  H steps WITH the reference's episode handling active:
                      early termination on, episode_length = 10, so every env is
                      reset (envs/ant.py:176-234) at least twice inside the
@@ -262,6 +264,43 @@ def episode_golden(envs, name, n, H, L, act_gain=3.0, min_done=None):
                 **{k: np.stack(v) for k, v in rec.items()})
 
 
+def exploded_golden(envs, name="humanoid", n=4, H=6):
+    """rollout in which environments blow up: env 1 starts with a finite but absurd root velocity (|qd| > 1e6: the
+    'invalid value' rule of humanoid.py:340-356 fires at the first step), env 3 with one that overflows to inf / NaN inside
+    the step.  Loss = -sum(rew) + 0.01 sum(w * obs_before_reset) with the observation of an invalid environment masked out, as
+    algorithms/shac.py:205-213 does before it feeds obs_before_reset to the critic.  Records what the reference returns
+    (rewards forced to 0, done flags) and the action gradients after its nan_to_num hooks (humanoid.py:195-206)."""
+    cls, mmf, _, _, has_et = CONFIGS[name]
+    torch.manual_seed(0)
+    np.random.seed(0)
+    env = getattr(envs, cls)(num_envs=n, device="cpu", render=False, seed=0, episode_length=1000, no_grad=False,
+                             stochastic_init=False, MM_caching_frequency=mmf)
+    env.clear_grad()
+    env.reset()
+    q0, qd0 = env.get_state()
+    qd0 = qd0.view(n, -1).clone()
+    qd0[1, 3] = 3.0e6
+    qd0[3, 4] = 1.0e30
+    env.reset_with_state(q0, qd0.view(-1))
+    g = torch.Generator().manual_seed(5)
+    obs0 = env.initialize_trajectory()
+    acts = torch.tanh(2.0 * torch.rand((H, n, env.num_actions), generator=g) - 1.0).clone().requires_grad_(True)
+    w = torch.randn((n, env.num_obs), generator=g)
+    rec = dict(rew=[], done=[], progress=[], obs=[])
+    loss = 0.0
+    for t in range(H):
+        obs, rew, done, info = env.step(acts[t])
+        ob = info["obs_before_reset"]
+        bad = (torch.isnan(ob).sum(-1) > 0) | (torch.isinf(ob).sum(-1) > 0) | ((ob.abs() > 1e6).sum(-1) > 0)
+        loss = loss - rew.sum() + 0.01 * (w * torch.where(bad.unsqueeze(-1), torch.zeros_like(ob), ob)).sum()
+        rec["rew"].append(t2n(rew)); rec["done"].append(t2n(done)); rec["progress"].append(t2n(env.progress_buf))
+        rec["obs"].append(t2n(obs))
+    loss.backward()
+    return dict(q0=t2n(q0).reshape(n, -1), qd0=t2n(qd0), obs0=t2n(obs0), actions=t2n(acts), w=t2n(w),
+                grad_actions=t2n(acts.grad), loss=np.float64(loss.item()), mm_freq=mmf,
+                q_final=t2n(env.state.joint_q).reshape(n, -1), **{k: np.stack(v) for k, v in rec.items()})
+
+
 def ant_extra_goldens(df, envs):
     """H = 32 rollout, and a rollout through the reference's own reset logic (see module docstring)"""
     out = {}
@@ -325,6 +364,20 @@ def main():
                         seed=np.int64(11))
             np.savez_compressed(os.path.join(OUT, tag + ".npz"), **slim)
             print("golden written:", tag, "restarts recorded:", int(g["done"].sum()))
+    if "mm1" in names:
+        # MM_caching_frequency = 1, the constructor default of every environment class (envs/ant.py:32): the mass matrix is
+        # rebuilt and its adjoint runs in EVERY substep (sim.py:2113, 2475)
+        names.remove("mm1")
+        for name, n, H in (("ant", 8, 8), ("snu", 2, 4), ("humanoid", 2, 4)):
+            saved = CONFIGS[name]
+            CONFIGS[name] = (saved[0], 1, n, H, saved[4])
+            np.savez_compressed(os.path.join(OUT, name + "_rollout_mm1.npz"), **rollout_golden(df, envs, name))
+            CONFIGS[name] = saved
+            print("golden written:", name + "_rollout_mm1")
+    if "exploded" in names:
+        names.remove("exploded")
+        np.savez_compressed(os.path.join(OUT, "humanoid_exploded.npz"), **exploded_golden(envs))
+        print("golden written: humanoid_exploded")
     if "episodes_extra" in names:
         # the other environments' termination rules through the reference (humanoid: height + invalid-state checks,
         # humanoid.py:340-356; hopper: height, hopper.py:288-293; cartpole / cheetah: episode length only)

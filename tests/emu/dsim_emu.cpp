@@ -11,22 +11,41 @@
 #include "../../diffrl_amd/csrc/dsim_core.hpp"
 #include "../../diffrl_amd/csrc/dsim_static_layouts.hpp"
 
-struct HostExec {
+// NW wavefronts per environment: NL = 64 * NW lanes, run one after another (the library's kernels use 1 or 4)
+template <int NW> struct HostExecT {
+    static constexpr int NL = DSIM_NL * NW;
     template <class F> void run(F&& f) {
-        for (int lane = 0; lane < DSIM_NL; ++lane) f(lane);
+        for (int lane = 0; lane < NL; ++lane) f(lane);
     }
     template <class F> void fire(F&& f) { run(f); }
+    // host form of the register / v_readlane Gauss-Jordan of the kernels (dsim_hip.hip: dsim_wave_gj): same formulas
+    template <int N> void wave_gj(float* H) {
+        for (int k = 0; k < N; ++k) {
+            float p[N], col[N];
+            const float rp = 1.0f / H[k * N + k];
+            for (int j = 0; j < N; ++j) {
+                p[j] = (j == k ? 1.0f : H[k * N + j]) * rp;
+                col[j] = H[j * N + k];
+            }
+            for (int i = 0; i < N; ++i)
+                for (int j = 0; j < N; ++j)
+                    H[i * N + j] = (i == k) ? p[j] : ((j == k ? 0.0f : H[i * N + j]) - col[i] * p[j]);
+        }
+    }
     void mark(int) {}
-    float hacc_[DSIM_NL][DSIM_HACC_MAX];  // what a lane keeps in registers across phases on the GPU
+    float hacc_[NL][DSIM_HACC_MAX];  // what a lane keeps in registers across phases on the GPU
     float* hacc(int lane) { return hacc_[lane]; }
-    DsimTopoRegs topo_[DSIM_NL];
+    DsimTopoRegs topo_[NL];
     DsimTopoRegs& topo(int lane) { return topo_[lane]; }
     const float* pf_src = nullptr;
     void prefetch(const float* row, int) { pf_src = row; }
     void commit(float* dst, int words, int lane) {
-        for (int k = lane; k < words; k += DSIM_NL) dst[k] = pf_src[k];
+        for (int k = lane; k < words; k += NL) dst[k] = pf_src[k];
     }
 };
+typedef HostExecT<1> HostExec;
+static int g_waves = 1;
+extern "C" void dsim_emu_set_waves(int w) { g_waves = w > 1 ? 4 : 1; }
 
 static void make_ctx(const DsimLayout& lay, std::vector<float>& lds, DsimCtx& c, float h) {
     lds.assign(lay.o.total_words, 0.f);
@@ -128,13 +147,21 @@ static DsimEnvSpec to_spec(const dsim_env_spec* e) {
 static int g_use_static = 0;
 extern "C" void dsim_emu_use_static(int on) { g_use_static = on; }
 
+template <class F, class O, class D> static int emu_waves(F&& f, O o, D d) {
+    if (g_waves > 1) {
+        static HostExecT<4> ex4;
+        return f(o, d, ex4);
+    }
+    static HostExecT<1> ex1;
+    return f(o, d, ex1);
+}
 template <class F> static int emu_dispatch(const DsimLayout& lay, F&& f) {
-    if (!g_use_static) return f(lay.o, lay.d);
+    if (!g_use_static) return emu_waves(f, lay.o, lay.d);
     const size_t no = sizeof(DsimOff) / sizeof(int), nd = sizeof(DsimDims) / sizeof(int);
 #define DSIM_EMU_CASE(T)                                                                                            \
     if (sizeof(kDsimStatic##T) == (no + nd) * sizeof(int) && memcmp(kDsimStatic##T, &lay.o, no * sizeof(int)) == 0 && \
         memcmp(kDsimStatic##T + no, &lay.d, nd * sizeof(int)) == 0)                                                  \
-        return f(DsimOff##T{}, DsimDims##T{});
+        return emu_waves(f, DsimOff##T{}, DsimDims##T{});
     DSIM_STATIC_VARIANTS(DSIM_EMU_CASE)
 #undef DSIM_EMU_CASE
     return -2;  // no specialised variant for this model
@@ -149,6 +176,8 @@ static DsimEpisode to_episode(const dsim_episode* episode) {
         ep.reset_q = episode->reset_q; ep.reset_qd = episode->reset_qd; ep.reset_count = episode->reset_count;
         ep.pool = episode->reset_pool; ep.episode_length = episode->episode_length;
         ep.height_terminate = episode->height_terminate; ep.check_invalid = episode->check_invalid;
+        ep.noise_q = episode->noise_q; ep.noise_qd = episode->noise_qd; ep.noise_angle = episode->noise_angle;
+        ep.seed = episode->seed;
     }
     return ep;
 }
@@ -163,8 +192,7 @@ extern "C" int dsim_emu_env_forward(const dsim_model_desc* m, const dsim_env_spe
     DsimEnvSpec sp = to_spec(env);
     DsimEpisode ep = to_episode(episode);
     const size_t stride = dsim_ckpt_words(lay.o.save_words, nq, nd, substeps, mm_freq);
-    return emu_dispatch(lay, [&](auto o, auto d) {
-        HostExec ex;
+    return emu_dispatch(lay, [&](auto o, auto d, auto& ex) {
         for (int e = 0; e < n_envs; ++e) {
             std::vector<float> lds(lay.o.total_words, 0.f);
             memcpy(lds.data(), lay.cblob.data(), sizeof(uint32_t) * lay.o.const_words);
@@ -188,8 +216,7 @@ extern "C" int dsim_emu_env_backward(const dsim_model_desc* m, const dsim_env_sp
     const int nq = lay.d.nq, nd = lay.d.nd;
     DsimEnvSpec sp = to_spec(env);
     const size_t stride = dsim_ckpt_words(lay.o.save_words, nq, nd, substeps, mm_freq);
-    return emu_dispatch(lay, [&](auto o, auto d) {
-        HostExec ex;
+    return emu_dispatch(lay, [&](auto o, auto d, auto& ex) {
         for (int e = 0; e < n_envs; ++e) {
             std::vector<float> lds(lay.o.total_words, 0.f);
             memcpy(lds.data(), lay.cblob.data(), sizeof(uint32_t) * lay.o.const_words);

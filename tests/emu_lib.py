@@ -156,7 +156,7 @@ def env_spec_for(env_name, t):
 
 
 def make_episode(progress, done, obs_before, reset_q, reset_qd, reset_count, episode_length, height_terminate,
-                 check_invalid):
+                 check_invalid, noise_q=None, noise_qd=None, noise_angle=0.0, seed=0):
     """capi.Episode over numpy arrays (int64 progress/done, float32 pool [K][N][.], int32 reset_count)"""
     from diffrl_amd import capi
     ep = capi.Episode()
@@ -165,6 +165,9 @@ def make_episode(progress, done, obs_before, reset_q, reset_qd, reset_count, epi
     ep.reset_q, ep.reset_qd, ep.reset_count = reset_q.ctypes.data, reset_qd.ctypes.data, reset_count.ctypes.data
     ep.reset_pool, ep.episode_length = int(reset_q.shape[0]), int(episode_length)
     ep.height_terminate, ep.check_invalid = int(bool(height_terminate)), int(bool(check_invalid))
+    ep.noise_q = noise_q.ctypes.data if noise_q is not None else None
+    ep.noise_qd = noise_qd.ctypes.data if noise_qd is not None else None
+    ep.noise_angle, ep.seed = float(noise_angle), int(seed)
     return ep
 
 

@@ -54,8 +54,18 @@ def _struct_fields(name):
 def test_envspec_and_episode_match_header_field_order():
     assert _struct_fields("dsim_env_spec") == [f[0] for f in capi.EnvSpec._fields_]
     assert _struct_fields("dsim_episode") == [f[0] for f in capi.Episode._fields_]
-    # layout as the C compiler sees it: 6 pointers + 4 int32
-    assert ctypes.sizeof(capi.Episode) == 6 * 8 + 4 * 4
+    # layout as the C compiler sees it
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(
+            '#include <stdio.h>\n#include <stddef.h>\n#include "dsim.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n",'
+            'sizeof(dsim_episode), offsetof(dsim_episode, noise_q), offsetof(dsim_episode, noise_angle),'
+            'offsetof(dsim_episode, seed), sizeof(dsim_env_spec));return 0;}\n')
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        c = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).split()]
+    E = capi.Episode
+    assert c == [ctypes.sizeof(E), E.noise_q.offset, E.noise_angle.offset, E.seed.offset, ctypes.sizeof(capi.EnvSpec)]
 
 
 def test_engine_refuses_cpu():

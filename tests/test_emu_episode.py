@@ -144,3 +144,45 @@ def test_multi_step_episode_rollover():
         if done[0]:
             np.testing.assert_array_equal(q[0], pq[(c[0] - 1) % 3, 0])
     assert seen == [(1, 0, 0), (2, 0, 0), (0, 1, 1), (1, 0, 1), (2, 0, 1), (0, 1, 2), (1, 0, 2), (2, 0, 2)]
+
+
+def test_in_kernel_restart_noise_cpu_harness():
+    """stochastic restarts drawn inside the step (Philox counter = (env, restart number, coordinate)): within the stated
+    amplitudes around the start state, unit root rotation tilted by at most noise_angle / 2, a different draw for every
+    environment and every restart, reproducible from the seed.  (The GPU test checks the distribution against reset_state().)"""
+    t = template_from_golden("ant")
+    g = golden("ant_rollout")
+    spec, keep = env_spec_for("ant", t)
+    n = 8
+    q0 = np.tile(g["q0"][:1], (n, 1)).astype(np.float32)
+    qd0 = np.zeros((n, t.n_qd), np.float32)
+    nq = np.zeros(t.n_q, np.float32); nq[0:3] = 0.2; nq[7:] = 0.4
+    nqd = np.full(t.n_qd, 0.5, np.float32)
+    a = np.zeros((n, 8), np.float32)
+
+    def run(seed, restarts):
+        prog, done, cnt = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.int32)
+        pq, pqd = q0[None].copy(), qd0[None].copy()
+        out = []
+        for _ in range(restarts):
+            ep = make_episode(prog, done, None, pq, pqd, cnt, 1, False, False, nq, nqd, np.pi / 12.0, seed)
+            qo, qdo, obs, rew, ck = emu_env_forward(t, spec, q0, qd0, a, 1.0 / 60.0, 16, 16, ep)
+            assert done.sum() == n
+            out.append((qo.copy(), qdo.copy()))
+        assert (cnt == restarts).all()
+        return out
+
+    r = run(7, 3)
+    for qo, qdo in r:
+        d = qo - q0
+        assert (np.abs(d[:, 0:3]) <= 0.1 + 1e-6).all() and (np.abs(d[:, 7:]) <= 0.2 + 1e-6).all()
+        assert (np.abs(qdo) <= 0.25 + 1e-6).all()
+        rot = qo[:, 3:7]
+        assert np.allclose(np.linalg.norm(rot, axis=1), 1.0, atol=1e-6)
+        cosang = np.abs((rot * q0[:, 3:7]).sum(1)).clip(max=1.0)
+        assert (2.0 * np.arccos(cosang) <= np.pi / 24.0 + 1e-3).all()
+        assert len(np.unique(np.round(qo, 7), axis=0)) == n          # environments differ
+    assert not np.allclose(r[0][0], r[1][0]) and not np.allclose(r[1][0], r[2][0])   # restarts differ
+    r2 = run(7, 3)
+    assert all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(r, r2))
+    assert not np.array_equal(run(8, 1)[0][0], r[0][0])

@@ -54,3 +54,32 @@ def test_unknown_model_has_no_specialised_variant(static_mode):
         emu_env_forward(t, spec, g["q0"][:1], g["qd0"][:1], g["actions"][0][:1], 1 / 60, 16, 16)
     emu().dsim_emu_use_static(0)
     emu_env_forward(t, spec, g["q0"][:1], g["qd0"][:1], g["actions"][0][:1], 1 / 60, 16, 16)
+
+
+@pytest.mark.parametrize("env", ["ant", "humanoid", "snu", "cheetah"])
+@pytest.mark.parametrize("static", [0, 1])
+def test_four_waves_per_environment_match_one(env, static):
+    """The library runs the bigger models with 4 wavefronts per environment (256 lanes: the long item lists become single
+    passes).  The phase code must not depend on the lane count: same items, same arithmetic, same order per item."""
+    t = template_from_golden(env)
+    g = golden(env + "_rollout")
+    spec, keep = env_spec_for(env, t)
+    S, mm, dt = SUBSTEPS[env], int(g["mm_freq"]), 1.0 / 60.0
+    n = min(2, g["q0"].shape[0])
+    q, qd, a = g["q0"][:n], g["qd0"][:n], g["actions"][0][:n]
+    rng = np.random.default_rng(1)
+    cot = [rng.normal(size=x.shape).astype(np.float32) for x in (q, qd)]
+    gobs, grew = rng.normal(size=(n, spec.n_obs)).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    out = {}
+    try:
+        emu().dsim_emu_use_static(static)
+        for waves in (4, 1):
+            emu().dsim_emu_set_waves(waves)
+            f = emu_env_forward(t, spec, q, qd, a, dt, S, mm)
+            b = emu_env_backward(t, spec, f[4], a, dt, S, mm, cot[0], cot[1], gobs, grew)
+            out[waves] = (f[:4], b)
+    finally:
+        emu().dsim_emu_set_waves(1)
+        emu().dsim_emu_use_static(0)
+    for x, y in zip(out[4][0] + out[4][1], out[1][0] + out[1][1]):
+        np.testing.assert_allclose(x, y, rtol=0, atol=0)

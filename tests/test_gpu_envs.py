@@ -148,28 +148,67 @@ def test_fused_episode_gradients_match_the_torch_path():
     assert torch.allclose(res[0][2], res[1][2], rtol=1e-4, atol=1e-5)
 
 
-def test_stochastic_restarts_come_from_a_fresh_pool():
+def _restart_states(cls, n, steps, **kw):
+    """states of the environments right after in-kernel restarts: episode_length = 1 makes every step end an episode"""
     dev = torch.device("cuda:0")
-    from diffrl_amd import envs
-    n = 64
-    e = envs.AntEnv(num_envs=n, device="cuda:0", no_grad=True, stochastic_init=True, MM_caching_frequency=16,
-                    early_termination=True, episode_length=2)
+    e = cls(num_envs=n, device="cuda:0", no_grad=True, stochastic_init=True, episode_length=1, seed=3, **kw)
     e.reset()
-    a = torch.zeros((n, 8), device=dev)
-    e.step(a)
-    obs, rew, done, _ = e.step(a)
-    assert int(done.sum()) == n and int(e.progress_buf.sum()) == 0
-    pool_q = e._pool[0]
-    q = e.state.joint_q.view(n, -1)
-    assert torch.equal(q, pool_q[0])                       # first restart of every environment: pool entry 0
-    assert (q[:, 7:].std(0) > 0.01).all()                 # and it is a random draw (+-0.2 rad on the joints)
-    assert not torch.equal(pool_q[0], pool_q[1])
-    e.step(a)
-    obs, rew, done, _ = e.step(a)
-    assert torch.equal(e.state.joint_q.view(n, -1), pool_q[1])
-    e.clear_grad()                                        # a new rollout redraws the pool
-    e.step(a)
-    assert not torch.equal(e._pool[0][0], pool_q[0])
+    a = torch.zeros((n, e.num_actions), device=dev)
+    qs, qds = [], []
+    for _ in range(steps):
+        obs, rew, done, _ = e.step(a)
+        assert int(done.sum()) == n and int(e.progress_buf.sum()) == 0
+        qs.append(e.state.joint_q.view(n, -1).clone())
+        qds.append(e.state.joint_qd.view(n, -1).clone())
+    return e, torch.cat(qs), torch.cat(qds)
+
+
+@pytest.mark.parametrize("name", ["ant", "humanoid", "snu", "hopper", "cheetah", "cartpole"])
+def test_in_kernel_restarts_follow_the_reset_distribution(name):
+    """Every restart inside the fused step draws a FRESH start state (counter-based generator keyed by environment and
+    restart number).  Its distribution must be the environment's own reset_state() -- the reference's reset(),
+    envs/ant.py:199-234 etc.: first two moments of every coordinate over ~10k restarts against ~10k torch draws, the unit
+    norm and the tilt-angle range of the root rotation, and no state ever repeated."""
+    from diffrl_amd import envs
+    cls = {"ant": envs.AntEnv, "humanoid": envs.HumanoidEnv, "snu": envs.SNUHumanoidEnv, "hopper": envs.HopperEnv,
+           "cheetah": envs.CheetahEnv, "cartpole": envs.CartPoleSwingUpEnv}[name]
+    kw = {"MM_caching_frequency": {"ant": 16, "humanoid": 48, "snu": 8, "hopper": 16, "cheetah": 16, "cartpole": 4}[name]}
+    n, steps = 512, 20
+    e, q, qd = _restart_states(cls, n, steps, **kw)
+    # the same number of draws from the environment's torch reset_state()
+    ref_q, ref_qd = [], []
+    ids = torch.arange(n, device=q.device)
+    for _ in range(steps):
+        e.state.joint_q, e.state.joint_qd = e.state.joint_q.clone(), e.state.joint_qd.clone()
+        e.reset_state(ids)
+        ref_q.append(e.state.joint_q.view(n, -1).clone())
+        ref_qd.append(e.state.joint_qd.view(n, -1).clone())
+    ref_q, ref_qd = torch.cat(ref_q), torch.cat(ref_qd)
+    N = q.shape[0]
+    for x, r, what in ((q, ref_q, "q"), (qd, ref_qd, "qd")):
+        sd = r.std(0)
+        tol_mean = 5.0 * sd / N ** 0.5 + 1e-6            # 5 sigma of the sample mean
+        assert ((x.mean(0) - r.mean(0)).abs() <= 2 ** 0.5 * tol_mean).all(), what
+        # sample standard deviations of uniform noise: relative error ~ 0.5 / sqrt(N) -> 6 % is > 5 sigma
+        live = sd > 1e-6
+        assert ((x.std(0)[live] / sd[live] - 1.0).abs() < 0.06).all(), what
+        assert (x.std(0)[~live] < 1e-6).all(), what         # coordinates without noise stay put
+        # same support: the sample extremes of two sets of ~10k uniform draws agree to a few 1e-4 of the range
+        span = (r.max(0).values - r.min(0).values)
+        assert (x.min(0).values >= r.min(0).values - 0.03 * span - 1e-4).all() and \
+               (x.max(0).values <= r.max(0).values + 0.03 * span + 1e-4).all(), what
+    if name in ("ant", "humanoid", "snu"):
+        rot, ref_rot = q[:, 3:7], ref_q[:, 3:7]
+        assert ((rot.norm(dim=1) - 1.0).abs() < 1e-5).all()
+        start = e.start_rotation.view(1, 4)
+        ang = lambda r_: 2.0 * torch.acos(((r_ * start).sum(1)).abs().clamp(max=1.0))   # angle between r and the start rotation
+        assert float(ang(rot).max()) <= float(np.pi / 24.0) + 1e-3                        # |angle| <= noise_angle / 2
+        assert abs(float(ang(rot).mean()) - float(ang(ref_rot).mean())) < 0.01
+    # fresh draw every time: no two restart states coincide (a 2-entry pool repeated after two restarts)
+    assert torch.unique(torch.cat((q, qd), 1), dim=0).shape[0] == N
+    # and the sequence depends on the seed only: same seed -> same restarts
+    e2, q2, qd2 = _restart_states(cls, n, 2, **kw)
+    assert torch.equal(q2, q[:2 * n]) and torch.equal(qd2, qd[:2 * n])
 
 
 def test_shac_style_usage():

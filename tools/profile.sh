@@ -1,13 +1,17 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel trace + PMC passes of the default bench command.
 # Writes small summaries to gpurun_out/prof_<tag>/ (raw CSVs stay in /tmp on the box).
-TAG=${1:-r01}
+TAG=${1:-r02}
+ENVN=${2:-ant}
+ENVS=${3:-1024}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/prof_$TAG
-RAW=/tmp/prof_raw
+OUT=$REPO/gpurun_out/prof_${TAG}_$ENVN
+RAW=/tmp/prof_raw_$ENVN
 mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --env $ENVN --envs-per-gpu $ENVS"
+echo "$CMD" > $OUT/command.txt
+python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(bench.csrc_hash())" > $OUT/csrc_hash.txt 2>/dev/null
 run() { timeout 240 rocprofv3 --output-format csv "$@" < /dev/null; }
 run --kernel-trace --stats -d $RAW/trace -o t -- $CMD > $OUT/trace.log 2>&1
 run --pmc FETCH_SIZE --kernel-trace -d $RAW/fetch -o f -- $CMD > $OUT/fetch.log 2>&1
