@@ -54,6 +54,7 @@ class Episode(C.Structure):
 
 
 ENV_LOCOMOTION, ENV_CARTPOLE, ENV_PLANAR = 1, 2, 3
+CKPT_FULL, CKPT_LEAN = 0, 1
 REW_ANT, REW_HUMANOID, REW_SNU, REW_CARTPOLE, REW_HOPPER, REW_CHEETAH = 0, 1, 2, 3, 4, 5
 
 
@@ -136,6 +137,8 @@ def lib():
     L.dsim_ckpt_floats.restype = C.c_int64
     L.dsim_ckpt_floats_mm.argtypes = [vp, C.c_int, C.c_int]
     L.dsim_ckpt_floats_mm.restype = C.c_int64
+    L.dsim_model_set_ckpt_mode.argtypes = [vp, C.c_int]
+    L.dsim_model_set_ckpt_mode.restype = C.c_int
     L.dsim_step_forward.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp]
     L.dsim_step_backward.argtypes = [vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp,
                                      vp]
@@ -158,6 +161,6 @@ def check(rc):
 
 
 EXPORTS = ("dsim_last_error", "dsim_version", "dsim_model_create", "dsim_model_destroy", "dsim_model_variant",
-           "dsim_ckpt_floats", "dsim_ckpt_floats_mm",
+           "dsim_ckpt_floats", "dsim_ckpt_floats_mm", "dsim_model_set_ckpt_mode",
            "dsim_step_forward", "dsim_step_backward", "dsim_env_step_forward", "dsim_env_step_backward",
            "dsim_env_observe")

@@ -27,6 +27,14 @@
 #include "dsim_layout.hpp"
 #include "dsim_math.hpp"
 
+// DSIM_OPAQUE(x): the kernels define it as an empty asm that "modifies" x.  Used on the per-lane joint type / chain length
+// read from the register-resident topology records at the top of a phase: otherwise every lane predicate derived from
+// them (~50 exec masks) is hoisted out of the substep loop as a loop invariant and kept in an SGPR pair -- far more than
+// the 102 SGPRs there are, so they were spilled to VGPR lanes and read back with v_readlane at every use (measured:
+// 105-178 SGPR spills per kernel).  Recomputing a mask where it is used is one v_cmp.
+#ifndef DSIM_OPAQUE
+#define DSIM_OPAQUE(x) (void)0
+#endif
 #define DSIM_NL 64  // lanes of one wavefront; the lanes of an environment's workgroup are Exec::NL = 64 * waves
 
 typedef int __attribute__((may_alias)) dsim_int_a;
@@ -34,13 +42,18 @@ typedef int __attribute__((may_alias)) dsim_int_a;
 // O / D are either the runtime structs of dsim_layout.hpp (generic kernels: offsets and sizes live in SGPRs)
 // or generated all-constexpr structs (dsim_static_layouts.hpp: per-model specialised kernels in which every
 // LDS offset is an instruction immediate and every size a compile-time loop bound).
-template <class O, class D> struct DsimCtxT {
+// LEAN: checkpoint mode (include/dsim.h: DSIM_CKPT_LEAN) -- a compile-time property of the kernels, so that the full-mode
+// adjoint does not carry the forward phases the lean mode recomputes (they cost it registers: measured 2 -> 1 waves/SIMD).
+template <class O, class D, bool LEAN_ = false> struct DsimCtxT {
+    static constexpr bool LEAN = LEAN_;
     float* s;  // LDS image base
     O o;
     D d;
     float h;   // substep length
 };
 typedef DsimCtxT<DsimOff, DsimDims> DsimCtx;
+// words of one substep's checkpoint row: the saved block (everything the adjoint reads) or, in the lean mode, only (q, qd)
+template <class Ctx> DSIM_FN int dsim_row(const Ctx& c) { return Ctx::LEAN ? c.o.xsc - c.o.q : c.o.save_words; }
 
 #define CI(name) (reinterpret_cast<const dsim_int_a*>(c.s) + c.o.name)
 #define CF(name) (static_cast<const float*>(c.s) + c.o.name)
@@ -391,13 +404,17 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
             if constexpr (DsimChainRegs<Ctx>::value) {
                 using D = decltype(c.d);
                 const int* ch = ex.topo(lane).chain;
-                const int n = ch[4 * DSIM_CHAIN_MAX];
+                int n = ch[4 * DSIM_CHAIN_MAX];
+                DSIM_OPAQUE(n);
                 dsim_static_for<0, D::D>([&](auto P) {
                     constexpr int p = decltype(P)::value;
-                    if (p < n) dsim_fk_position<dsim_pos_mask<D, p>(), p == 0>(c, w, ch[4 * p], ch[4 * p + 1], ch[4 * p + 2], ch[4 * p + 3]);
+                    int ty = ch[4 * p + 1];
+                    DSIM_OPAQUE(ty);
+                    if (p < n) dsim_fk_position<dsim_pos_mask<D, p>(), p == 0>(c, w, ch[4 * p], ty, ch[4 * p + 2], ch[4 * p + 3]);
                 });
                 own_type = ex.topo(lane).own_type;
                 own_ds = ex.topo(lane).own_ds;
+                DSIM_OPAQUE(own_type);
             } else {
                 const int e0 = CI(anc_start)[i], e1 = CI(anc_start)[i + 1];
                 DsimLinkInfo li{};
@@ -562,6 +579,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_tau(const Ctx& c, Exec& e
             if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
                 const DsimTopoRegs& tp = ex.topo(lane);
                 i = tp.dof_link; type = tp.dof_type; cs = tp.dof_cs; ds = tp.dof_ds;
+                DSIM_OPAQUE(type);
             } else {
                 i = CI(dof_link)[d]; type = CI(jtype)[i]; cs = CI(qstart)[i]; ds = CI(qdstart)[i];
             }
@@ -676,6 +694,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_integrate(const Ctx& c, E
             if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
                 const DsimTopoRegs& tp = ex.topo(lane);
                 type = tp.own_type; cs = tp.own_cs; ds = tp.own_ds;
+                DSIM_OPAQUE(type);
             } else {
                 type = CI(jtype)[i]; cs = CI(qstart)[i]; ds = CI(qdstart)[i];
             }
@@ -735,12 +754,12 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_integrate(const Ctx& c, E
 // idle on this path (Ant: 37 KB per env-step), and reading the block back costs ~1.5k cycles against ~10k to recompute it.
 DSIM_FN int dsim_hinv_words_d(int nd) { return (nd * nd + 3) & ~3; }
 template <class Ctx> DSIM_FN float* dsim_ckpt_hinv(const Ctx& c, float* g_ckpt, int substeps, int group) {
-    return g_ckpt + (size_t)substeps * c.o.save_words + (size_t)group * dsim_hinv_words_d(c.d.nd);
+    return g_ckpt + (size_t)substeps * dsim_row(c) + (size_t)group * dsim_hinv_words_d(c.d.nd);
 }
 // tail of an environment's checkpoint: [q, qd at the end of the step (before any episode reset), episode flags]
 template <class Ctx> DSIM_FN float* dsim_ckpt_tail(const Ctx& c, float* g_ckpt, int substeps, int mm_freq) {
     const int groups = (substeps + mm_freq - 1) / mm_freq;
-    return g_ckpt + (size_t)substeps * c.o.save_words + (size_t)groups * dsim_hinv_words_d(c.d.nd);
+    return g_ckpt + (size_t)substeps * dsim_row(c) + (size_t)groups * dsim_hinv_words_d(c.d.nd);
 }
 
 // one substep on the LDS-resident state; g_row / g_hinv: where to stream the saved block / the fresh inverse (or null)
@@ -758,7 +777,7 @@ DSIM_FN void dsim_fwd_substep(const Ctx& c, Exec& ex, bool update_mass, float* g
         ex.fire([&](int lane) {
             const dsim_f4* src = reinterpret_cast<const dsim_f4*>(WF(q));
             dsim_f4* dst = reinterpret_cast<dsim_f4*>(g_row);
-            for (int k = lane; k < c.o.save_words / 4; k += Exec::NL) dst[k] = src[k];
+            for (int k = lane; k < dsim_row(c) / 4; k += Exec::NL) dst[k] = src[k];
             if (update_mass && g_hinv)
                 for (int k = lane; k < c.d.nd * c.d.nd; k += Exec::NL) g_hinv[k] = WF(hinv)[k];
         });
@@ -785,7 +804,7 @@ DSIM_FN void dsim_sim_step_forward(const Ctx& c, Exec& ex, int substeps, int mm_
         for (int k = lane; k < M; k += Exec::NL) WF(mact)[k] = g_mact[k];
     });
     for (int s = 0; s < substeps; ++s)
-        dsim_fwd_substep(c, ex, (s % mm_freq) == 0, g_ckpt ? g_ckpt + (size_t)s * c.o.save_words : nullptr,
+        dsim_fwd_substep(c, ex, (s % mm_freq) == 0, g_ckpt ? g_ckpt + (size_t)s * dsim_row(c) : nullptr,
                          g_ckpt ? dsim_ckpt_hinv(c, g_ckpt, substeps, s / mm_freq) : nullptr);
     ex.run([&](int lane) {
         for (int k = lane; k < nq; k += Exec::NL) g_q_out[k] = WF(q)[k];
@@ -835,6 +854,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
             if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
                 const DsimTopoRegs& tp = ex.topo(lane);
                 type = tp.own_type; cs = tp.own_cs; ds = tp.own_ds;
+                DSIM_OPAQUE(type);
             } else {
                 type = CI(jtype)[i]; cs = CI(qstart)[i]; ds = CI(qdstart)[i];
             }
@@ -934,6 +954,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
             if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
                 const DsimTopoRegs& tp = ex.topo(lane);
                 i = tp.dof_link; type = tp.dof_type; cs = tp.dof_cs; ds = tp.dof_ds;
+                DSIM_OPAQUE(type);
             } else {
                 i = CI(dof_link)[d]; type = CI(jtype)[i]; cs = CI(qstart)[i]; ds = CI(qdstart)[i];
             }
@@ -1307,6 +1328,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
                 const DsimTopoRegs& tp = ex.topo(lane);
                 type = tp.own_type; ds = tp.own_ds;
+                DSIM_OPAQUE(type);
             } else {
                 type = CI(jtype)[i]; ds = CI(qdstart)[i];
             }
@@ -1346,6 +1368,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
                 const DsimTopoRegs& tp = ex.topo(lane);
                 type = tp.own_type; ds = tp.own_ds;
+                DSIM_OPAQUE(type);
             } else {
                 type = CI(jtype)[i]; ds = CI(qdstart)[i];
             }
@@ -1398,6 +1421,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
                 const DsimTopoRegs& tp = ex.topo(lane);
                 type = tp.own_type; cs = tp.own_cs; ds = tp.own_ds; par = tp.own_parent;
+                DSIM_OPAQUE(type);
             } else {
                 type = CI(jtype)[i]; cs = CI(qstart)[i]; ds = CI(qdstart)[i]; par = CI(parent)[i];
             }
@@ -1435,6 +1459,15 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
     });
 }
 
+// Lean checkpoint mode: the row holds only (q, qd); the forward intermediates of the substep are recomputed here with the
+// forward pass's own phases (same code, same inputs: bit-identical to what the full mode reads back from HBM).
+template <class Ctx, class Exec> DSIM_FN void dsim_bwd_recompute_forward(const Ctx& c, Exec& ex) {
+    dsim_fwd_kinematics(c, ex);
+    dsim_fwd_external(c, ex);
+    dsim_fwd_tau(c, ex);
+    dsim_fwd_solve(c, ex);
+}
+
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_substep(const Ctx& c, Exec& ex, bool update_mass) {
     dsim_bwd_joint_space(c, ex, update_mass);
     if (update_mass) dsim_bwd_mass(c, ex);
@@ -1470,9 +1503,9 @@ DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
             // The row was requested one substep earlier (ex.prefetch keeps it in flight in registers while the
             // previous adjoint substep computes), so this phase only moves registers to LDS.
             const float* hv = (s == s1 - 1) ? dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, g) : nullptr;
-            if (s == substeps - 1) ex.prefetch(g_ckpt + (size_t)s * c.o.save_words, c.o.save_words);
+            if (s == substeps - 1) ex.prefetch(g_ckpt + (size_t)s * dsim_row(c), dsim_row(c));
             ex.run([&](int lane) {
-                ex.commit(WF(q), c.o.save_words, lane);
+                ex.commit(WF(q), dsim_row(c), lane);
                 if (hv) {
                     for (int k = lane; k < nd * nd; k += Exec::NL) {
                         WF(hinv)[k] = hv[k];
@@ -1481,7 +1514,8 @@ DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
                     dsim_hacc_zero(c, ex, lane);
                 }
             });
-            if (s > 0) ex.prefetch(g_ckpt + (size_t)(s - 1) * c.o.save_words, c.o.save_words);
+            if (s > 0) ex.prefetch(g_ckpt + (size_t)(s - 1) * dsim_row(c), dsim_row(c));
+            if constexpr (Ctx::LEAN) dsim_bwd_recompute_forward(c, ex);
             if (s == s0) dsim_fwd_composite(c, ex);
             dsim_bwd_substep(c, ex, s == s0);  // aq / aqd (== aqn / aqdn, same LDS words) now belong to substep s - 1
         }
@@ -1811,7 +1845,7 @@ DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& s
     });
     dsim_env_load_actions(c, ex, sp, g_actions);
     for (int s = 0; s < substeps; ++s)
-        dsim_fwd_substep(c, ex, (s % mm_freq) == 0, g_ckpt ? g_ckpt + (size_t)s * c.o.save_words : nullptr,
+        dsim_fwd_substep(c, ex, (s % mm_freq) == 0, g_ckpt ? g_ckpt + (size_t)s * dsim_row(c) : nullptr,
                          g_ckpt ? dsim_ckpt_hinv(c, g_ckpt, substeps, s / mm_freq) : nullptr);
     float* tail = g_ckpt ? dsim_ckpt_tail(c, g_ckpt, substeps, mm_freq) : nullptr;
     if (!ep.progress) {
@@ -1972,9 +2006,9 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
             // The row was requested one substep earlier (ex.prefetch keeps it in flight in registers while the
             // previous adjoint substep computes), so this phase only moves registers to LDS.
             const float* hv = (s == s1 - 1) ? dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, g) : nullptr;
-            if (s == substeps - 1) ex.prefetch(g_ckpt + (size_t)s * c.o.save_words, c.o.save_words);
+            if (s == substeps - 1) ex.prefetch(g_ckpt + (size_t)s * dsim_row(c), dsim_row(c));
             ex.run([&](int lane) {
-                ex.commit(WF(q), c.o.save_words, lane);
+                ex.commit(WF(q), dsim_row(c), lane);
                 if (hv) {
                     for (int k = lane; k < nd * nd; k += Exec::NL) {
                         WF(hinv)[k] = hv[k];
@@ -1983,7 +2017,8 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
                     dsim_hacc_zero(c, ex, lane);
                 }
             });
-            if (s > 0) ex.prefetch(g_ckpt + (size_t)(s - 1) * c.o.save_words, c.o.save_words);
+            if (s > 0) ex.prefetch(g_ckpt + (size_t)(s - 1) * dsim_row(c), dsim_row(c));
+            if constexpr (Ctx::LEAN) dsim_bwd_recompute_forward(c, ex);
             if (s == s0) dsim_fwd_composite(c, ex);
             dsim_bwd_substep(c, ex, s == s0);  // aq / aqd (== aqn / aqdn, same LDS words) now belong to substep s - 1
         }

@@ -22,6 +22,9 @@
 #include <string>
 
 #define DSIM_FN __device__ __forceinline__
+#ifndef DSIM_OPAQUE   // (-DDSIM_OPAQUE\(x\)= builds the A/B variant without it)
+#define DSIM_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
 #include "dsim_core.hpp"
 #include "dsim_static_layouts.hpp"
 
@@ -128,14 +131,14 @@ template <class O, class D> struct KCommonT {
     long long ckpt_stride;  // floats per environment (dsim_ckpt_words)
 };
 
-template <int NW, class O, class D> __device__ __forceinline__ DsimCtxT<O, D> start_env(float* lds, const KCommonT<O, D>& k) {
+template <int NW, bool LEAN, class O, class D> __device__ __forceinline__ DsimCtxT<O, D, LEAN> start_env(float* lds, const KCommonT<O, D>& k) {
     // 16 bytes per lane and load (const_words is a multiple of 4, both sides are 16-byte aligned)
     dsim_f4* l = reinterpret_cast<dsim_f4*>(lds);
     const dsim_f4* g = reinterpret_cast<const dsim_f4*>(k.cblob);
     for (int i = threadIdx.x; i < k.o.const_words / 4; i += DSIM_NL * NW) l[i] = g[i];
     if constexpr (NW == 1) dsim_wave_sync();
     else __syncthreads();
-    DsimCtxT<O, D> c;
+    DsimCtxT<O, D, LEAN> c;
     c.s = lds;
     c.o = k.o;
     c.d = k.d;
@@ -143,7 +146,7 @@ template <int NW, class O, class D> __device__ __forceinline__ DsimCtxT<O, D> st
     return c;
 }
 
-template <class O, class D, int NW>
+template <class O, class D, int NW, bool LEAN>
 __global__ __launch_bounds__(DSIM_NL * NW) void dsim_fwd_kernel(KCommonT<O, D> k, const float* __restrict__ q_in,
                                                            const float* __restrict__ qd_in,
                                                            const float* __restrict__ act,
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_fwd_kernel(KCommonT<O, D> k
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    auto c = start_env<NW>(lds, k);
+    auto c = start_env<NW, LEAN>(lds, k);
     DevExec<NW> ex;
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_sim_step_forward(c, ex, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, act + e * nd,
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_fwd_kernel(KCommonT<O, D> k
                           ckpt ? ckpt + (size_t)e * k.ckpt_stride : nullptr);
 }
 
-template <class O, class D, int NW>
+template <class O, class D, int NW, bool LEAN>
 __global__ __launch_bounds__(DSIM_NL * NW) void dsim_bwd_kernel(KCommonT<O, D> k, const float* __restrict__ ckpt,
                                                            const float* __restrict__ act,
                                                            const float* __restrict__ mact,
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_bwd_kernel(KCommonT<O, D> k
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    auto c = start_env<NW>(lds, k);
+    auto c = start_env<NW, LEAN>(lds, k);
     DevExec<NW> ex;
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_sim_step_backward(c, ex, k.substeps, k.mm_freq, ckpt + (size_t)e * k.ckpt_stride, act + e * nd,
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_bwd_kernel(KCommonT<O, D> k
                            gqd_in + e * nd, gact ? gact + e * nd : nullptr, (gmact && M) ? gmact + e * M : nullptr);
 }
 
-template <class O, class D, int NW>
+template <class O, class D, int NW, bool LEAN>
 __global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_fwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp, DsimEpisode ep,
                                                                const float* __restrict__ q_in,
                                                                const float* __restrict__ qd_in,
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_fwd_kernel(KCommonT<O, 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    auto c = start_env<NW>(lds, k);
+    auto c = start_env<NW, LEAN>(lds, k);
     DevExec<NW> ex;
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_forward(c, ex, sp, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, actions + (size_t)e * sp.n_act,
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_fwd_kernel(KCommonT<O, 
                            ckpt ? ckpt + (size_t)e * k.ckpt_stride : nullptr, ep, e, k.n_envs);
 }
 
-template <class O, class D, int NW>
+template <class O, class D, int NW, bool LEAN>
 __global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_bwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp,
                                                                const float* __restrict__ ckpt,
                                                                const float* __restrict__ actions,
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_bwd_kernel(KCommonT<O, 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    auto c = start_env<NW>(lds, k);
+    auto c = start_env<NW, LEAN>(lds, k);
     DevExec<NW> ex;
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_backward(c, ex, sp, k.substeps, k.mm_freq, ckpt + (size_t)e * k.ckpt_stride,
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_timer_kernel(KCommonT<O, D>
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    auto c = start_env<NW>(lds, k);
+    auto c = start_env<NW, false>(lds, k);
     TimingExec<NW> ex{stamps, 1, cap};
     if (blockIdx.x == 0 && threadIdx.x == 0) stamps[0] = clock64();
     const size_t nq = k.d.nq, nd = k.d.nd;
@@ -336,6 +339,8 @@ struct dsim_model {
     uint32_t* d_cblob = nullptr;
     int variant = V_GENERIC;
     int waves = 1;   // wavefronts per environment: 1 or DSIM_WAVES_WIDE
+    int lean = 0;    // checkpoint mode (dsim_model_set_ckpt_mode)
+    int row_words() const { return lean ? lay.o.xsc - lay.o.q : lay.o.save_words; }
 };
 #define DSIM_WAVES_WIDE 4
 
@@ -343,13 +348,17 @@ namespace {
 
 // calls f(offsets, dims, waves) with the (static or runtime) layout types of the model's kernel variant and the number of
 // wavefronts per environment as a compile-time constant
+template <class D> constexpr bool dsim_static_wide() { return D::NS > DSIM_NL || D::C > DSIM_NL; }
 template <class F> int dispatch(const dsim_model* m, F&& f) {
     const bool wide = m->waves > 1;
     switch (m->variant) {
-#define DSIM_CASE(T)                                                                                   \
-    case V_##T:                                                                                        \
-        return wide ? f(DsimOff##T{}, DsimDims##T{}, std::integral_constant<int, DSIM_WAVES_WIDE>{})   \
-                    : f(DsimOff##T{}, DsimDims##T{}, std::integral_constant<int, 1>{});
+    // a specialised variant exists with the wave count its model wants (pick_waves), not with both
+#define DSIM_CASE(T)                                                                                        \
+    case V_##T:                                                                                             \
+        if constexpr (dsim_static_wide<DsimDims##T>())                                                      \
+            return f(DsimOff##T{}, DsimDims##T{}, std::integral_constant<int, DSIM_WAVES_WIDE>{});          \
+        else                                                                                                \
+            return f(DsimOff##T{}, DsimDims##T{}, std::integral_constant<int, 1>{});
         DSIM_STATIC_VARIANTS(DSIM_CASE)
 #undef DSIM_CASE
         default:
@@ -363,11 +372,14 @@ template <class F> int dispatch(const dsim_model* m, F&& f) {
 // 4 waves per environment need 4 resident waves per SIMD at 1024 environments, which the kernels' ~200 registers per
 // lane do not allow (measured: Humanoid forward 0.45 -> 0.90 ms).  Models with item lists several wavefronts long
 // (SNUHumanoid: 198 muscle segments, 88 contacts) run 4 waves per environment: their long phases become single
-// passes on the CU's 4 SIMDs (SNUHumanoid 512 envs: 0.62 + 0.98 -> 0.48 + 0.67 ms).  DSIM_WAVES=1|4 overrides (A/B runs).
-int pick_waves(const DsimLayout& lay) {
-    if (const char* e = getenv("DSIM_WAVES")) return atoi(e) > 1 ? DSIM_WAVES_WIDE : 1;
+// passes on the CU's 4 SIMDs (SNUHumanoid 512 envs: 0.62 + 0.98 -> 0.45 + 0.62 ms).  DSIM_WAVES=1|4 overrides the
+// choice for the generic kernels (A/B runs: DSIM_FORCE_GENERIC=1 DSIM_WAVES=...).
+int pick_waves(const DsimLayout& lay, int variant) {
     const DsimDims& d = lay.d;
-    return (d.NS > DSIM_NL || d.C > DSIM_NL) ? DSIM_WAVES_WIDE : 1;
+    const int want = (d.NS > DSIM_NL || d.C > DSIM_NL) ? DSIM_WAVES_WIDE : 1;
+    if (variant != V_GENERIC) return want;   // specialised kernels are compiled for their model's wave count only
+    if (const char* e = getenv("DSIM_WAVES")) return atoi(e) > 1 ? DSIM_WAVES_WIDE : 1;
+    return want;
 }
 
 template <class O, class D>
@@ -380,7 +392,7 @@ KCommonT<O, D> make_k(const dsim_model* m, O o, D d, int n_envs, float dt, int s
     k.substeps = substeps;
     k.mm_freq = mm_freq;
     k.n_envs = n_envs;
-    k.ckpt_stride = dsim_ckpt_words(m->lay.o.save_words, m->lay.d.nq, m->lay.d.nd, substeps, mm_freq);
+    k.ckpt_stride = dsim_ckpt_words(m->row_words(), m->lay.d.nq, m->lay.d.nd, substeps, mm_freq);
     return k;
 }
 
@@ -454,7 +466,7 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
         return fail(DSIM_ERR_LIMIT, "model needs more than 160 KiB of LDS per environment");
     }
     m->variant = match_variant(m->lay);
-    m->waves = pick_waves(m->lay);
+    m->waves = pick_waves(m->lay, m->variant);
     hipError_t e = hipMalloc(&m->d_cblob, sizeof(uint32_t) * m->lay.cblob.size());
     if (e == hipSuccess)
         e = hipMemcpy(m->d_cblob, m->lay.cblob.data(), sizeof(uint32_t) * m->lay.cblob.size(), hipMemcpyHostToDevice);
@@ -466,10 +478,14 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
             using O = decltype(o);
             using D = decltype(d);
             constexpr int NW = decltype(nw)::value;
-            const void* fns[] = {reinterpret_cast<const void*>(dsim_bwd_kernel<O, D, NW>),
-                                 reinterpret_cast<const void*>(dsim_env_bwd_kernel<O, D, NW>),
-                                 reinterpret_cast<const void*>(dsim_fwd_kernel<O, D, NW>),
-                                 reinterpret_cast<const void*>(dsim_env_fwd_kernel<O, D, NW>),
+            const void* fns[] = {reinterpret_cast<const void*>(dsim_bwd_kernel<O, D, NW, false>),
+                                 reinterpret_cast<const void*>(dsim_env_bwd_kernel<O, D, NW, false>),
+                                 reinterpret_cast<const void*>(dsim_fwd_kernel<O, D, NW, false>),
+                                 reinterpret_cast<const void*>(dsim_env_fwd_kernel<O, D, NW, false>),
+                                 reinterpret_cast<const void*>(dsim_bwd_kernel<O, D, NW, true>),
+                                 reinterpret_cast<const void*>(dsim_env_bwd_kernel<O, D, NW, true>),
+                                 reinterpret_cast<const void*>(dsim_fwd_kernel<O, D, NW, true>),
+                                 reinterpret_cast<const void*>(dsim_env_fwd_kernel<O, D, NW, true>),
                                  reinterpret_cast<const void*>(dsim_env_obs_kernel<O, D, NW>)};
             for (const void* fn : fns)
                 if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -494,10 +510,17 @@ int dsim_model_destroy(dsim_model* m) {
 
 int64_t dsim_ckpt_floats_mm(const dsim_model* m, int substeps, int mm_freq) {
     if (!m || substeps <= 0 || mm_freq <= 0) return 0;
-    return (int64_t)dsim_ckpt_words(m->lay.o.save_words, m->lay.d.nq, m->lay.d.nd, substeps, mm_freq);
+    return (int64_t)dsim_ckpt_words(m->row_words(), m->lay.d.nq, m->lay.d.nd, substeps, mm_freq);
 }
 
 int64_t dsim_ckpt_floats(const dsim_model* m, int substeps) { return dsim_ckpt_floats_mm(m, substeps, 1); }
+
+int dsim_model_set_ckpt_mode(dsim_model* m, int mode) {
+    if (!m) return fail(DSIM_ERR_INVALID, "null model");
+    if (mode != DSIM_CKPT_FULL && mode != DSIM_CKPT_LEAN) return fail(DSIM_ERR_INVALID, "unknown checkpoint mode");
+    m->lean = mode == DSIM_CKPT_LEAN;
+    return DSIM_OK;
+}
 
 int dsim_step_forward(const dsim_model* m, int n_envs, const float* q_in, const float* qd_in, const float* act,
                       const float* muscle_act, float dt, int substeps, int mm_freq, float* q_out, float* qd_out,
@@ -510,7 +533,11 @@ int dsim_step_forward(const dsim_model* m, int n_envs, const float* q_in, const 
     return dispatch(m, [&](auto o, auto d, auto nw) {
         constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        hipLaunchKernelGGL((dsim_fwd_kernel<decltype(o), decltype(d), NW>), dim3(n_envs), dim3(DSIM_NL * NW),
+        if (m->lean)
+            hipLaunchKernelGGL((dsim_fwd_kernel<decltype(o), decltype(d), NW, true>), dim3(n_envs), dim3(DSIM_NL * NW),
+                           (size_t)m->lay.o.fwd_words * 4, st, k, q_in, qd_in, act, muscle_act, q_out, qd_out, ckpt);
+        else
+            hipLaunchKernelGGL((dsim_fwd_kernel<decltype(o), decltype(d), NW, false>), dim3(n_envs), dim3(DSIM_NL * NW),
                            (size_t)m->lay.o.fwd_words * 4, st, k, q_in, qd_in, act, muscle_act, q_out, qd_out, ckpt);
         return launched("launch dsim_fwd_kernel");
     });
@@ -528,7 +555,12 @@ int dsim_step_backward(const dsim_model* m, int n_envs, const float* ckpt, const
     return dispatch(m, [&](auto o, auto d, auto nw) {
         constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        hipLaunchKernelGGL((dsim_bwd_kernel<decltype(o), decltype(d), NW>), dim3(n_envs), dim3(DSIM_NL * NW),
+        if (m->lean)
+            hipLaunchKernelGGL((dsim_bwd_kernel<decltype(o), decltype(d), NW, true>), dim3(n_envs), dim3(DSIM_NL * NW),
+                           (size_t)m->lay.o.total_words * 4, st, k, ckpt, act, muscle_act, gq_out, gqd_out, gq_in, gqd_in,
+                           gact, gmuscle_act);
+        else
+            hipLaunchKernelGGL((dsim_bwd_kernel<decltype(o), decltype(d), NW, false>), dim3(n_envs), dim3(DSIM_NL * NW),
                            (size_t)m->lay.o.total_words * 4, st, k, ckpt, act, muscle_act, gq_out, gqd_out, gq_in, gqd_in,
                            gact, gmuscle_act);
         return launched("launch dsim_bwd_kernel");
@@ -570,7 +602,12 @@ int dsim_env_step_forward(const dsim_model* m, const dsim_env_spec* env, int n_e
     return dispatch(m, [&](auto o, auto d, auto nw) {
         constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        hipLaunchKernelGGL((dsim_env_fwd_kernel<decltype(o), decltype(d), NW>), dim3(n_envs), dim3(DSIM_NL * NW),
+        if (m->lean)
+            hipLaunchKernelGGL((dsim_env_fwd_kernel<decltype(o), decltype(d), NW, true>), dim3(n_envs), dim3(DSIM_NL * NW),
+                           (size_t)m->lay.o.fwd_words * 4, st, k, sp, ep, q_in, qd_in, actions, q_out, qd_out, obs, rew,
+                           ckpt);
+        else
+            hipLaunchKernelGGL((dsim_env_fwd_kernel<decltype(o), decltype(d), NW, false>), dim3(n_envs), dim3(DSIM_NL * NW),
                            (size_t)m->lay.o.fwd_words * 4, st, k, sp, ep, q_in, qd_in, actions, q_out, qd_out, obs, rew,
                            ckpt);
         return launched("launch dsim_env_fwd_kernel");
@@ -591,7 +628,12 @@ int dsim_env_step_backward(const dsim_model* m, const dsim_env_spec* env, int n_
     return dispatch(m, [&](auto o, auto d, auto nw) {
         constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        hipLaunchKernelGGL((dsim_env_bwd_kernel<decltype(o), decltype(d), NW>), dim3(n_envs), dim3(DSIM_NL * NW),
+        if (m->lean)
+            hipLaunchKernelGGL((dsim_env_bwd_kernel<decltype(o), decltype(d), NW, true>), dim3(n_envs), dim3(DSIM_NL * NW),
+                           (size_t)m->lay.o.total_words * 4, st, k, sp, ckpt, actions, gq_out, gqd_out, gobs, grew,
+                           gobs_before_reset, gq_in, gqd_in, gactions);
+        else
+            hipLaunchKernelGGL((dsim_env_bwd_kernel<decltype(o), decltype(d), NW, false>), dim3(n_envs), dim3(DSIM_NL * NW),
                            (size_t)m->lay.o.total_words * 4, st, k, sp, ckpt, actions, gq_out, gqd_out, gobs, grew,
                            gobs_before_reset, gq_in, gqd_in, gactions);
         return launched("launch dsim_env_bwd_kernel");

@@ -18,7 +18,9 @@ def _ptr(t):
 class Engine:
     """Owns the device copy of one articulation template on one GPU."""
 
-    def __init__(self, template: ArticulationTemplate, device):
+    def __init__(self, template: ArticulationTemplate, device, ckpt_mode=None):
+        """ckpt_mode: "full" (default; $DIFFRL_AMD_CKPT overrides) -- the forward launch streams every intermediate the
+        adjoint reads to HBM -- or "lean" -- (q, qd) per substep only, the adjoint recomputes (include/dsim.h)."""
         self.template = template
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -29,6 +31,11 @@ class Engine:
         with torch.cuda.device(self.device):
             capi.check(self._lib.dsim_model_create(C.byref(self._desc), C.byref(h)))
         self._h = h
+        import os
+        self.ckpt_mode = (ckpt_mode or os.environ.get("DIFFRL_AMD_CKPT", "full")).lower()
+        if self.ckpt_mode not in ("full", "lean"):
+            raise capi.DsimError("ckpt_mode must be 'full' or 'lean'")
+        capi.check(self._lib.dsim_model_set_ckpt_mode(h, capi.CKPT_LEAN if self.ckpt_mode == "lean" else capi.CKPT_FULL))
         self.variant = int(self._lib.dsim_model_variant(h))  # 0 = generic kernels, > 0 = specialised for this model
         self.n_q, self.n_qd, self.n_muscles = template.n_q, template.n_qd, template.n_muscles
 

@@ -101,6 +101,20 @@ int dsim_model_variant(const dsim_model* m);
  * (The reference keeps all 14 State tensors of every substep alive on its Tape, sim.py:2111 /
  * model.py:338-392.)  dsim_ckpt_floats() is the upper bound over mm_freq (mm_freq = 1). */
 int64_t dsim_ckpt_floats_mm(const dsim_model* m, int substeps, int mm_freq);
+
+/* Checkpoint mode of a model (default DSIM_CKPT_FULL).  Affects dsim_ckpt_floats(_mm) and every later forward / backward
+ * call with a checkpoint; a checkpoint must be consumed in the mode it was written in.
+ *   DSIM_CKPT_FULL  one row per substep with everything the adjoint reads (q, qd, X_sc, S, v, a, world inertias, f_tot,
+ *                   qdd): the adjoint launch reads it back instead of recomputing it (fastest; HBM is idle on this path).
+ *                   Floats per environment and env-step: Ant 7,524 (30 KB), Humanoid 49,748 (199 KB), SNUHumanoid
+ *                   33,272 (133 KB), i.e. 0.99 / 6.5 / 2.2 GB for a 1024- (SNU: 512-) environment, H = 32 rollout.
+ *   DSIM_CKPT_LEAN  one row per substep with (q, qd) only + the inverse mass matrices: the adjoint launch recomputes the
+ *                   forward phases of every substep (same code, bit-identical intermediates, identical gradients).
+ *                   Ant 740 floats (3 KB), Humanoid 3,476 (14 KB), SNUHumanoid 6,200 (25 KB) per environment and env-step:
+ *                   for rollouts whose full checkpoint would not fit (tens of thousands of environments per GPU). */
+#define DSIM_CKPT_FULL 0
+#define DSIM_CKPT_LEAN 1
+int dsim_model_set_ckpt_mode(dsim_model* m, int mode);
 int64_t dsim_ckpt_floats(const dsim_model* m, int substeps);
 
 /* One env.step() worth of simulation for N environments: `substeps` semi-implicit substeps of

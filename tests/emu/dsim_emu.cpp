@@ -44,6 +44,9 @@ template <int NW> struct HostExecT {
     }
 };
 typedef HostExecT<1> HostExec;
+static int g_lean = 0;   // checkpoint mode of the emu entry points (dsim_model_set_ckpt_mode of the library)
+extern "C" void dsim_emu_set_ckpt_lean(int on) { g_lean = on; }
+static int emu_row(const DsimLayout& lay) { return g_lean ? lay.o.xsc - lay.o.q : lay.o.save_words; }
 static int g_waves = 1;
 extern "C" void dsim_emu_set_waves(int w) { g_waves = w > 1 ? 4 : 1; }
 
@@ -150,10 +153,10 @@ extern "C" void dsim_emu_use_static(int on) { g_use_static = on; }
 template <class F, class O, class D> static int emu_waves(F&& f, O o, D d) {
     if (g_waves > 1) {
         static HostExecT<4> ex4;
-        return f(o, d, ex4);
+        return g_lean ? f(o, d, ex4, std::true_type{}) : f(o, d, ex4, std::false_type{});
     }
     static HostExecT<1> ex1;
-    return f(o, d, ex1);
+    return g_lean ? f(o, d, ex1, std::true_type{}) : f(o, d, ex1, std::false_type{});
 }
 template <class F> static int emu_dispatch(const DsimLayout& lay, F&& f) {
     if (!g_use_static) return emu_waves(f, lay.o, lay.d);
@@ -191,12 +194,12 @@ extern "C" int dsim_emu_env_forward(const dsim_model_desc* m, const dsim_env_spe
     const int nq = lay.d.nq, nd = lay.d.nd;
     DsimEnvSpec sp = to_spec(env);
     DsimEpisode ep = to_episode(episode);
-    const size_t stride = dsim_ckpt_words(lay.o.save_words, nq, nd, substeps, mm_freq);
-    return emu_dispatch(lay, [&](auto o, auto d, auto& ex) {
+    const size_t stride = dsim_ckpt_words(emu_row(lay), nq, nd, substeps, mm_freq);
+    return emu_dispatch(lay, [&](auto o, auto d, auto& ex, auto lean) {
         for (int e = 0; e < n_envs; ++e) {
             std::vector<float> lds(lay.o.total_words, 0.f);
             memcpy(lds.data(), lay.cblob.data(), sizeof(uint32_t) * lay.o.const_words);
-            DsimCtxT<decltype(o), decltype(d)> c;
+            DsimCtxT<decltype(o), decltype(d), decltype(lean)::value> c;
             c.s = lds.data(); c.o = o; c.d = d; c.h = dt / float(substeps);
             dsim_env_fused_forward(c, ex, sp, substeps, mm_freq, q_in + (size_t)e * nq, qd_in + (size_t)e * nd,
                                    actions + (size_t)e * sp.n_act, q_out + (size_t)e * nq, qd_out + (size_t)e * nd,
@@ -215,12 +218,12 @@ extern "C" int dsim_emu_env_backward(const dsim_model_desc* m, const dsim_env_sp
     if (!dsim_build_layout(*m, lay).empty()) return -1;
     const int nq = lay.d.nq, nd = lay.d.nd;
     DsimEnvSpec sp = to_spec(env);
-    const size_t stride = dsim_ckpt_words(lay.o.save_words, nq, nd, substeps, mm_freq);
-    return emu_dispatch(lay, [&](auto o, auto d, auto& ex) {
+    const size_t stride = dsim_ckpt_words(emu_row(lay), nq, nd, substeps, mm_freq);
+    return emu_dispatch(lay, [&](auto o, auto d, auto& ex, auto lean) {
         for (int e = 0; e < n_envs; ++e) {
             std::vector<float> lds(lay.o.total_words, 0.f);
             memcpy(lds.data(), lay.cblob.data(), sizeof(uint32_t) * lay.o.const_words);
-            DsimCtxT<decltype(o), decltype(d)> c;
+            DsimCtxT<decltype(o), decltype(d), decltype(lean)::value> c;
             c.s = lds.data(); c.o = o; c.d = d; c.h = dt / float(substeps);
             dsim_env_fused_backward(c, ex, sp, substeps, mm_freq, ckpt + (size_t)e * stride,
                                     actions + (size_t)e * sp.n_act, gq_out ? gq_out + (size_t)e * nq : nullptr,
@@ -236,5 +239,5 @@ extern "C" int dsim_emu_env_backward(const dsim_model_desc* m, const dsim_env_sp
 extern "C" long long dsim_emu_ckpt_floats(const dsim_model_desc* m, int substeps, int mm_freq) {
     DsimLayout lay;
     if (!dsim_build_layout(*m, lay).empty()) return -1;
-    return dsim_ckpt_words(lay.o.save_words, lay.d.nq, lay.d.nd, substeps, mm_freq);
+    return dsim_ckpt_words(emu_row(lay), lay.d.nq, lay.d.nd, substeps, mm_freq);
 }

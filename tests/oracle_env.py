@@ -15,11 +15,11 @@ CLS = {"cartpole": envs.CartPoleSwingUpEnv, "ant": envs.AntEnv, "humanoid": envs
        "snu": envs.SNUHumanoidEnv, "hopper": envs.HopperEnv, "cheetah": envs.CheetahEnv}
 
 
-def make_cpu_env(name, n, template):
-    kw = dict(num_envs=n, device="cpu", render=False, seed=0, episode_length=1000, no_grad=False,
+def make_cpu_env(name, n, template, episode_length=1000, early_termination=False):
+    kw = dict(num_envs=n, device="cpu", render=False, seed=0, episode_length=episode_length, no_grad=False,
               stochastic_init=False, MM_caching_frequency=MM[name])
     if name in ("cartpole", "ant", "hopper", "cheetah"):
-        kw["early_termination"] = False
+        kw["early_termination"] = early_termination
     e = CLS[name](**kw)
     e.fused = False
     t, S, mm, dt = template, SUBSTEPS[name], MM[name], 1.0 / 60.0
@@ -70,3 +70,27 @@ def rollout_grad(name, template, q0, qd0, actions):
         loss = loss - rew.sum()
     loss.backward()
     return np.stack(obs_l), np.stack(rew_l), acts.grad.numpy().copy()
+
+
+def episode_rollout_grad(name, template, progress0, actions, w, episode_length, q0_scale=None):
+    """The loss of the <env>_<N>x32 recordings (oracle/gen_golden.py: episode_golden) for a sub-batch of environments, through
+    the torch env surface WITH its termination rules and restarts + the oracle: d loss / d actions, done flags.
+    q0_scale: relative perturbation of the start state (1-ulp conditioning probe in the reference's operation order)."""
+    H, n = actions.shape[0], actions.shape[1]
+    e = make_cpu_env(name, n, template, episode_length=episode_length, early_termination=True)
+    e.clear_grad()
+    e.reset()
+    if q0_scale is not None:
+        q0, qd0 = e.get_state()
+        e.reset_with_state((q0.view(n, -1) * torch.tensor(q0_scale, dtype=torch.float32)).reshape(-1), qd0)
+    e.progress_buf[:] = torch.tensor(progress0)
+    e.initialize_trajectory()
+    acts = torch.tensor(actions, requires_grad=True)
+    wt = torch.tensor(w)
+    loss, dones = 0.0, []
+    for s in range(H):
+        obs, rew, done, info = e.step(acts[s])
+        loss = loss - rew.sum() + 0.01 * (wt * info["obs_before_reset"]).sum() + 0.01 * (wt * obs).sum()
+        dones.append(done.numpy().copy())
+    loss.backward()
+    return acts.grad.numpy().copy(), np.stack(dones)

@@ -9,10 +9,13 @@ from oracle_lib import golden, relerr, template_from_golden
 SUBSTEPS = {"cartpole": 4, "ant": 16, "humanoid": 48, "snu": 48, "hopper": 16, "cheetah": 16}
 
 
-@pytest.mark.parametrize("env", ["cartpole", "ant", "humanoid", "snu", "hopper", "cheetah"])
-def test_fused_rollout_vs_reference(env):
+# <env>_rollout_mm1: MM_caching_frequency = 1, the constructor default of the reference's environment classes
+# (envs/ant.py:32): mass matrix rebuilt -- and its adjoint run -- in every substep (sim.py:2113, 2475)
+@pytest.mark.parametrize("env,name", [(e, e + "_rollout") for e in ["cartpole", "ant", "humanoid", "snu", "hopper", "cheetah"]]
+                         + [(e, e + "_rollout_mm1") for e in ["ant", "snu", "humanoid"]])
+def test_fused_rollout_vs_reference(env, name):
     t = template_from_golden(env)
-    g = golden(env + "_rollout")
+    g = golden(name)
     spec, keep = env_spec_for(env, t)
     H, n = g["actions"].shape[0], g["actions"].shape[1]
     S, mm, dt = SUBSTEPS[env], int(g["mm_freq"]), 1.0 / 60.0

@@ -83,3 +83,33 @@ def test_four_waves_per_environment_match_one(env, static):
         emu().dsim_emu_use_static(0)
     for x, y in zip(out[4][0] + out[4][1], out[1][0] + out[1][1]):
         np.testing.assert_allclose(x, y, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("env", ["ant", "humanoid", "snu"])
+def test_lean_checkpoint_mode_gives_identical_gradients(env):
+    """DSIM_CKPT_LEAN: the checkpoint row of a substep holds only (q, qd) and the adjoint recomputes the forward phases
+    with the forward pass's own code: same inputs, same operations -> bit-identical gradients, a fraction of the memory."""
+    from emu_lib import ckpt_floats
+    t = template_from_golden(env)
+    g = golden(env + "_rollout")
+    spec, keep = env_spec_for(env, t)
+    S, mm, dt = SUBSTEPS[env], int(g["mm_freq"]), 1.0 / 60.0
+    n = min(2, g["q0"].shape[0])
+    q, qd, a = g["q0"][:n], g["qd0"][:n], g["actions"][0][:n]
+    rng = np.random.default_rng(2)
+    cot = [rng.normal(size=x.shape).astype(np.float32) for x in (q, qd)]
+    gobs, grew = rng.normal(size=(n, spec.n_obs)).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    out, words = {}, {}
+    try:
+        for lean in (1, 0):
+            emu().dsim_emu_set_ckpt_lean(lean)
+            words[lean] = ckpt_floats(t, S, mm)
+            f = emu_env_forward(t, spec, q, qd, a, dt, S, mm)
+            assert f[4].shape[1] == words[lean]
+            b = emu_env_backward(t, spec, f[4], a, dt, S, mm, cot[0], cot[1], gobs, grew)
+            out[lean] = (f[:4], b)
+    finally:
+        emu().dsim_emu_set_ckpt_lean(0)
+    for x, y in zip(out[1][0] + out[1][1], out[0][0] + out[0][1]):
+        np.testing.assert_allclose(x, y, rtol=0, atol=0)
+    assert words[1] < 0.2 * words[0]

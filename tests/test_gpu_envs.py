@@ -12,11 +12,11 @@ pytestmark = pytest.mark.gpu
 CASES = ["cartpole", "ant", "humanoid", "snu", "hopper", "cheetah"]
 
 
-def _make(env, n, no_grad=False):
+def _make(env, n, no_grad=False, mm=None):
     from diffrl_amd import envs
     cls = {"cartpole": envs.CartPoleSwingUpEnv, "ant": envs.AntEnv, "humanoid": envs.HumanoidEnv,
            "snu": envs.SNUHumanoidEnv, "hopper": envs.HopperEnv, "cheetah": envs.CheetahEnv}[env]
-    mm = {"cartpole": 4, "ant": 16, "humanoid": 48, "snu": 8, "hopper": 16, "cheetah": 16}[env]
+    mm = mm or {"cartpole": 4, "ant": 16, "humanoid": 48, "snu": 8, "hopper": 16, "cheetah": 16}[env]
     kw = dict(num_envs=n, device="cuda:0", render=False, seed=0, episode_length=1000, no_grad=no_grad,
               stochastic_init=False, MM_caching_frequency=mm)
     if env in ("cartpole", "ant", "hopper", "cheetah"):
@@ -25,13 +25,15 @@ def _make(env, n, no_grad=False):
 
 
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("env", CASES)
-def test_rollout_matches_reference(env, fused):
+@pytest.mark.parametrize("env,name", [(e, e + "_rollout") for e in CASES] + [(e, e + "_rollout_mm1") for e in ["ant", "snu", "humanoid"]])
+def test_rollout_matches_reference(env, name, fused):
     """fused=True: one launch per env.step each way (obs/reward inside the kernels);
-    fused=False: SimStep kernels + torch observation / reward code"""
-    g = golden(env + "_rollout")
+    fused=False: SimStep kernels + torch observation / reward code.
+    <env>_rollout_mm1: recorded with MM_caching_frequency = 1 (the reference classes' constructor default): the mass matrix
+    and its adjoint run in every substep."""
+    g = golden(name)
     H, n = g["actions"].shape[0], g["actions"].shape[1]
-    e = _make(env, n)
+    e = _make(env, n, mm=int(g["mm_freq"]))
     e.fused = fused
     dev = torch.device("cuda:0")
     e.clear_grad()

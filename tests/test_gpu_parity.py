@@ -165,3 +165,23 @@ def test_specialised_kernels_match_generic(env, dev, monkeypatch):
     b = _run(gen_eng, dev, g["q_in"], g["qd_in"], g["act_in"], g.get("muscle_act_in"), dt, S, mm, g["gq_out"], g["gqd_out"])
     for k in ("q", "qd", "gq", "gqd", "gact"):
         assert relerr(a[k], b[k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("env", ["ant", "humanoid", "snu"])
+def test_lean_checkpoint_mode(env, dev):
+    """DSIM_CKPT_LEAN (include/dsim.h): rows of (q, qd) only, the adjoint launch recomputes the forward phases -- identical
+    gradients (bit for bit: same code on the same inputs), a fraction of the checkpoint memory"""
+    from diffrl_amd.engine import Engine
+    t = template_from_golden(env)
+    g = golden(env + "_step")
+    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
+    mact = g.get("muscle_act_in")
+    res, words = {}, {}
+    for mode in ("full", "lean"):
+        eng = Engine(t, dev, ckpt_mode=mode)
+        res[mode] = _run(eng, dev, g["q_in"], g["qd_in"], g["act_in"], mact, dt, S, mm, g["gq_out"], g["gqd_out"])
+        words[mode] = int(eng._lib.dsim_ckpt_floats_mm(eng._h, S, mm))
+    for k in res["full"]:
+        if k != "ckpt":
+            assert np.array_equal(res["full"][k], res["lean"][k]), k
+    assert res["lean"]["ckpt"].shape[1] == words["lean"] < 0.2 * words["full"]

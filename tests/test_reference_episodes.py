@@ -275,29 +275,144 @@ def test_gpu_fullsize_humanoids_vs_reference(tag):
     acts, w = _fullsize_inputs(g, e.num_actions, e.num_obs)
     acts = acts.to(dev).requires_grad_(True)
     w = w.to(dev)
-    rews, dones, progs = [], [], []
+    rews, dones, progs, heights = [], [], [], []
     loss = 0.0
     for t in range(H):
         obs, rew, done, info = e.step(acts[t])
         loss = loss - rew.sum() + 0.01 * (w * info["obs_before_reset"]).sum() + 0.01 * (w * obs).sum()
         rews.append(rew.detach()); dones.append(done.clone()); progs.append(e.progress_buf.clone())
+        heights.append(info["obs_before_reset"][:, 0].detach().clone())
     loss.backward()
     D = torch.stack(dones).cpu().numpy()
+    Hq = torch.stack(heights).cpu().numpy()
     mism = D != g["done"]
-    # a restart decision is a threshold on the torso height: an environment may cross it one step earlier / later than in
-    # the recording when it is within rounding of the threshold; everything downstream of such a flip is excluded
+    # A restart decision is a threshold on the torso height: an environment may cross it one step earlier / later than in
+    # the recording only if its height is within the trajectory tolerance of the threshold at that step.  Every flip is
+    # listed with that margin and asserted; everything downstream of a flip is excluded from the comparisons below.
     flipped = mism.any(0)
-    assert flipped.mean() <= 0.01, "done flags differ for %d environments" % flipped.sum()
+    term_h = float(e.termination_height)
+    margins = []
+    for k in np.where(flipped)[0]:
+        t0 = int(np.argmax(mism[:, k]))
+        margins.append((int(k), t0, float(abs(Hq[t0, k] - term_h))))
+    print("%s: %d of %d environments flip a done flag; (env, step, |height - threshold|): %s" % (tag, flipped.sum(), n, margins))
+    assert all(m[2] < 1e-3 * max(1.0, abs(term_h)) for m in margins), margins
+    assert flipped.mean() <= 0.005, "done flags differ for %d environments" % flipped.sum()
     ok = ~flipped
     R = torch.stack(rews).cpu().numpy()
-    assert np.abs(R[:, ok] - g["rew"][:, ok]).max() < 2e-3 * max(1.0, np.abs(g["rew"]).max())
+    assert np.abs(R[:, ok] - g["rew"][:, ok]).max() < 1e-3 * max(1.0, np.abs(g["rew"]).max())
     assert np.array_equal(torch.stack(progs).cpu().numpy()[:, ok], g["progress"][:, ok])
-    assert relerr(e.state.joint_q.detach().view(n, -1).cpu().numpy()[ok], g["q_final"][ok]) < 2e-3
+    assert relerr(e.state.joint_q.detach().view(n, -1).cpu().numpy()[ok], g["q_final"][ok]) < 1e-3
     st = int(g["stride"])
+    sel = np.arange(n)[::st][ok[::st]]                       # global indices of the environments with recorded gradients
     a = acts.grad[:, ::st].cpu().numpy().astype(np.float64)[:, ok[::st]]
     r = g["grad_actions_strided"].astype(np.float64)[:, ok[::st]]
-    assert (a * r).sum() / (np.linalg.norm(a) * np.linalg.norm(r)) > 0.999
-    # per-environment relative error: the bulk within 1e-3; a few environments sit at ill-conditioned contact states
-    # (tests/test_emu_fused_env.py measures that sensitivity on the reference itself)
     per_env = np.abs(a - r).max(axis=(0, 2)) / (np.abs(r).max(axis=(0, 2)) + 1e-30)
-    assert np.median(per_env) < 1e-3 and (per_env < 1e-2).mean() >= 0.9 and (per_env < 1e-3).mean() >= 0.8, np.sort(per_env)[-4:]
+    # Stated tolerance 1e-3 (BASELINE.md section 4, H = 32) per environment.  An environment above it must be one whose
+    # REFERENCE-order gradient is itself that sensitive: contacts switch on / off and friction switches regime at
+    # thresholds, so the gradient of a rollout is piecewise -- a state that differs in the 6th digit (what the fp32
+    # re-association of this implementation amounts to: 10-parameter inertias, composite-body mass matrix, explicit
+    # inverse) can sit on the other side of such a threshold for one substep, and the gradient then takes the OTHER
+    # branch's value.  Probe: perturb the start state by 1e-7 .. 3e-6 (relative), recompute the gradient with the scalar
+    # oracle (reference operation order, same termination rules, same loss); the reference-order gradient must move by at
+    # least a third of this implementation's error for every such environment (measured: it lands on the same values).
+    well = per_env < 1e-3
+    hard = np.where(~well)[0]
+    print("%s: %d of %d sampled environments above 1e-3 (max %.2e, median %.2e)" % (tag, len(hard), len(per_env), per_env.max(), np.median(per_env)))
+    assert len(hard) <= 0.15 * len(per_env)
+    if len(hard):
+        from oracle_env import episode_rollout_grad
+        A, Wn = acts.detach().cpu().numpy(), w.cpu().numpy()
+        rr_all = g["grad_actions_strided"].astype(np.float64)[:, ok[::st]]
+        sens = np.zeros(len(hard))
+        todo = np.arange(len(hard))
+        for mag, seed in ((1e-7, 0), (1e-6, 0), (3e-6, 0), (1e-6, 1), (3e-6, 1), (1e-6, 2), (3e-6, 2)):
+            if not len(todo):
+                break
+            hs = sel[hard[todo]]
+            rng = np.random.default_rng(seed)
+            scale = (1.0 + mag * rng.normal(size=(len(hs), e.num_joint_q))).astype(np.float32)
+            gp, dp = episode_rollout_grad(name, template_from_golden(name), g["progress0"][hs], A[:, hs], Wn[hs],
+                                          int(g["episode_length"]), q0_scale=scale)
+            rr = rr_all[:, hard[todo]]
+            sens[todo] = np.maximum(sens[todo], np.abs(gp - rr).max(axis=(0, 2)) / (np.abs(rr).max(axis=(0, 2)) + 1e-30))
+            todo = todo[per_env[hard[todo]] >= np.maximum(3.0 * sens[todo], 1e-3)]
+        print("%s: (error, reference-order sensitivity) of the environments above 1e-3: %s"
+              % (tag, [("%.1e" % x, "%.1e" % y) for x, y in zip(per_env[hard], sens)]))
+        assert not len(todo), "environments whose error exceeds 3x the reference-order sensitivity: %s" % sel[hard[todo]]
+    aw, rw = a[:, well], r[:, well]
+    assert (aw * rw).sum() / (np.linalg.norm(aw) * np.linalg.norm(rw)) > 0.9999
+
+
+# ---- environments that blow up (humanoid.py:340-356 invalid-state rule; nan_to_num hooks humanoid.py:195-206) -------
+def _exploded_masks(ob):
+    return ~np.isfinite(ob).all(-1) | (np.abs(np.nan_to_num(ob, nan=0.0, posinf=0.0, neginf=0.0)) > 1e6).any(-1)
+
+
+def _check_exploded(rew, done, prog, ga, q_final, g):
+    np.testing.assert_array_equal(done, g["done"])
+    np.testing.assert_array_equal(prog, g["progress"])
+    assert g["done"][0].tolist() == [0, 1, 0, 1]                  # env 1: |qd| > 1e6, env 3: inf / NaN, both at the first step
+    assert np.isfinite(rew).all() and (rew[0, [1, 3]] == 0.0).all()
+    assert np.abs(rew - g["rew"]).max() < 1e-3 * np.abs(g["rew"]).max()
+    a, r = ga.astype(np.float64), g["grad_actions"].astype(np.float64)
+    assert np.isfinite(a).all()
+    # the reference's hooks scrub what comes back through the inf / NaN intermediates: the action of the exploding step
+    # gets exactly zero there; here the adjoint launch writes that zero outright (stated deviation, bounded here)
+    assert (r[0, [1, 3]] == 0.0).all() and (a[0, [1, 3]] == 0.0).all()
+    assert (a * r).sum() / (np.linalg.norm(a) * np.linalg.norm(r)) > 0.9999
+    assert relerr(a, r) < 1e-3
+    assert relerr(q_final, g["q_final"]) < 1e-3
+
+
+def test_emu_exploded_environments_vs_reference():
+    from emu_lib import emu_env_backward, emu_env_forward, env_spec_for, make_episode
+    g = golden("humanoid_exploded")
+    t = template_from_golden("humanoid")
+    spec, keep = env_spec_for("humanoid", t)
+    H, n = g["actions"].shape[:2]
+    S, mm = 48, int(g["mm_freq"])
+    q, qd = g["q0"].copy(), g["qd0"].copy()
+    pool_q, pool_qd = g["q0"][None].copy(), np.zeros_like(g["qd0"])[None]      # deterministic restart: the rest pose
+    prog, cnt = np.zeros(n, np.int64), np.zeros(n, np.int32)
+    tape, rews, dones, progs, masks = [], [], [], [], []
+    for s in range(H):
+        done, ob = np.zeros(n, np.int64), np.zeros((n, spec.n_obs), np.float32)
+        ep = make_episode(prog, done, ob, pool_q, pool_qd, cnt, 1000, True, True)
+        with np.errstate(all="ignore"):
+            q, qd, obs, rew, ck = emu_env_forward(t, spec, q, qd, g["actions"][s], DT, S, mm, episode=ep)
+        tape.append(ck); rews.append(rew.copy()); dones.append(done.copy()); progs.append(prog.copy())
+        masks.append(_exploded_masks(ob))
+    gq, gqd, ga = np.zeros_like(q), np.zeros_like(qd), np.zeros_like(g["actions"])
+    for s in reversed(range(H)):
+        wb = (0.01 * g["w"] * (~masks[s])[:, None]).astype(np.float32)
+        with np.errstate(all="ignore"):
+            gq, gqd, ga[s] = emu_env_backward(t, spec, tape[s], g["actions"][s], DT, S, mm, gq, gqd, None,
+                                              -np.ones(n, np.float32), wb)
+    _check_exploded(np.stack(rews), np.stack(dones), np.stack(progs), ga, q, g)
+
+
+@pytest.mark.gpu
+def test_gpu_exploded_environments_vs_reference():
+    from diffrl_amd import envs
+    g = golden("humanoid_exploded")
+    H, n = g["actions"].shape[:2]
+    dev = torch.device("cuda:0")
+    e = envs.HumanoidEnv(num_envs=n, device="cuda:0", render=False, seed=0, episode_length=1000, no_grad=False,
+                         stochastic_init=False, MM_caching_frequency=int(g["mm_freq"]))
+    e.clear_grad()
+    e.reset()
+    e.reset_with_state(torch.tensor(g["q0"], device=dev).reshape(-1), torch.tensor(g["qd0"], device=dev).reshape(-1))
+    e.initialize_trajectory()
+    acts = torch.tensor(g["actions"], device=dev, requires_grad=True)
+    w = torch.tensor(g["w"], device=dev)
+    loss, rews, dones, progs = 0.0, [], [], []
+    for t in range(H):
+        obs, rew, done, info = e.step(acts[t])
+        ob = info["obs_before_reset"]
+        bad = (torch.isnan(ob).sum(-1) > 0) | (torch.isinf(ob).sum(-1) > 0) | ((ob.abs() > 1e6).sum(-1) > 0)   # shac.py:205-213
+        loss = loss - rew.sum() + 0.01 * (w * torch.where(bad.unsqueeze(-1), torch.zeros_like(ob), ob)).sum()
+        rews.append(rew.detach().cpu().numpy()); dones.append(done.cpu().numpy()); progs.append(e.progress_buf.cpu().numpy().copy())
+    loss.backward()
+    _check_exploded(np.stack(rews), np.stack(dones), np.stack(progs), acts.grad.cpu().numpy(),
+                    e.state.joint_q.detach().cpu().numpy().reshape(n, -1), g)
