@@ -221,12 +221,28 @@ template <class Ctx, int NL> struct DsimContactRegs {  // contact `lane` / `63 -
         else return false;
     }();
 };
+// Contacts evaluated INSIDE the kinematics phase: lane L + k walks the ancestor chain of contact k's body next to the link
+// lanes (same instruction stream, so the walk costs nothing extra) and evaluates its contact from the pose and twist it
+// holds in registers -- no phase boundary, no reload of X_sc / v.  Needs the chain records and L + C lanes.
+template <class Ctx, int NL> struct DsimContactsInKin {
+    static constexpr bool value = []() {
+        if constexpr (DsimChainRegs<Ctx>::value) return decltype(Ctx::d)::C > 0 && decltype(Ctx::d)::L + decltype(Ctx::d)::C <= NL;
+        else return false;
+    }();
+};
 template <class Ctx, class Exec> DSIM_FN void dsim_topo_init(const Ctx& c, Exec& ex, int lane) {
     if constexpr (DsimChainRegs<Ctx>::value) {
         constexpr int DEPTH = decltype(c.d)::D;
         int* ch = ex.topo(lane).chain;
-        const int i = lane < c.d.L ? lane : 0;
-        const int e0 = CI(anc_start)[i], n = lane < c.d.L ? CI(anc_start)[i + 1] - e0 : 0;
+        int i = lane < c.d.L ? lane : 0;
+        bool walker = lane < c.d.L;
+        if constexpr (DsimContactsInKin<Ctx, Exec::NL>::value) {
+            if (lane >= c.d.L && lane < c.d.L + c.d.C) {
+                i = CI(cbody)[lane - c.d.L];
+                walker = true;
+            }
+        }
+        const int e0 = CI(anc_start)[i], n = walker ? CI(anc_start)[i + 1] - e0 : 0;
 #pragma unroll
         for (int p = 0; p < DEPTH; ++p) {
             const DsimLinkInfo li = dsim_link_info(c, CI(anc_list)[e0 + (p < n ? p : 0)]);
@@ -393,7 +409,9 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
     // Nothing is stored before the end of the walk: LDS stores in between would serialise the next position's loads
     // behind them (the compiler cannot prove that they do not alias).
     ex.run([&](int lane) {
-        for (int i = lane; i < c.d.L; i += Exec::NL) {
+        constexpr bool with_contacts = DsimContactsInKin<Ctx, Exec::NL>::value;
+        const int n_walkers = with_contacts ? c.d.L + c.d.C : c.d.L;
+        for (int i = lane; i < n_walkers; i += Exec::NL) {
             DsimFkWalk w;
             w.psp = zero3();
             w.rsp = mkq(0.f, 0.f, 0.f, 1.f);
@@ -425,6 +443,14 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
                 }
                 own_type = li.type;
                 own_ds = li.ds;
+            }
+            if constexpr (with_contacts) {
+                if (i >= c.d.L) {
+                    // contact lane: the walk ended at the contact's body; its pose and twist are in registers
+                    const int k = i - c.d.L;
+                    stsv(WF(cw) + 6 * k, dsim_contact_wrench(c, k, w.psp, w.rsp, w.v));
+                    continue;
+                }
             }
             // COM, world inertia and body force of link i from the values still in registers
             const v3 pc = w.psp;
@@ -474,39 +500,47 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
     });
 }
 
+// wrench of ground contact k on its body with pose (xp, xq) and twist vb (sim.py:1137-1206)
+template <class Ctx> DSIM_FN sv6 dsim_contact_wrench(const Ctx& c, int k, v3 xp, q4 xq, sv6 vb) {
+    const float* mat = CF(cmat) + 4 * k;
+    const float ke = mat[0], kd = mat[1], kf = mat[2], mu = mat[3];
+    v3 p = xp + rotate(xq, ld3(CF(cpoint) + 3 * k));
+    p.y -= CF(cdist)[k];
+    const v3 dpdt = vb.v + cross(vb.w, p);
+    const float cc = p.y;
+    sv6 wr = zerosv();
+    if (cc < 0.0f) {
+        const float vn = dpdt.y;
+        const v3 vt = mk3(dpdt.x, 0.f, dpdt.z);
+        const float fn = cc * ke;
+        const float fd = (vn < 0.0f ? vn : 0.0f) * kd * (0.0f - cc);
+        const float lt = sqrtf(dot(vt, vt));
+        const float a1 = kf * lt, a2 = 0.0f - mu * cc * ke;
+        const float smin = a1 < a2 ? a1 : a2;
+        v3 ft = zero3();
+        if (lt > 0.0f) ft = vt * (smin / lt);
+        const v3 ftot = mk3(ft.x, fn + fd, ft.z);
+        wr = mksv(cross(p, ftot), ftot);
+    }
+    return wr;
+}
+
 // ground contacts (sim.py:1137-1206) and muscle segments (sim.py:1209-1242): per-item wrenches
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Exec& ex) {
     ex.mark(2);
-    if (c.d.C == 0 && c.d.NS == 0) return;
+    constexpr bool in_kin = DsimContactsInKin<Ctx, Exec::NL>::value;  // contacts were done by the kinematics phase
+    if ((c.d.C == 0 || in_kin) && c.d.NS == 0) return;
     ex.run([&](int lane) {
-        for (int k = lane; k < c.d.C; k += Exec::NL) {
-            int b;
-            if constexpr (DsimContactRegs<Ctx, Exec::NL>::value) b = ex.topo(lane).cbody_f;
-            else b = CI(cbody)[k];
-            const v3 xp = ld3(WF(xsc) + 7 * b);
-            const q4 xq = ldq(WF(xsc) + 7 * b + 3);
-            const sv6 vb = ldsv(WF(v) + 6 * b);
-            const float* mat = CF(cmat) + 4 * k;
-            const float ke = mat[0], kd = mat[1], kf = mat[2], mu = mat[3];
-            v3 p = xp + rotate(xq, ld3(CF(cpoint) + 3 * k));
-            p.y -= CF(cdist)[k];
-            const v3 dpdt = vb.v + cross(vb.w, p);
-            const float cc = p.y;
-            sv6 wr = zerosv();
-            if (cc < 0.0f) {
-                const float vn = dpdt.y;
-                const v3 vt = mk3(dpdt.x, 0.f, dpdt.z);
-                const float fn = cc * ke;
-                const float fd = (vn < 0.0f ? vn : 0.0f) * kd * (0.0f - cc);
-                const float lt = sqrtf(dot(vt, vt));
-                const float a1 = kf * lt, a2 = 0.0f - mu * cc * ke;
-                const float smin = a1 < a2 ? a1 : a2;
-                v3 ft = zero3();
-                if (lt > 0.0f) ft = vt * (smin / lt);
-                const v3 ftot = mk3(ft.x, fn + fd, ft.z);
-                wr = mksv(cross(p, ftot), ftot);
+        if constexpr (!in_kin) {
+            for (int k = lane; k < c.d.C; k += Exec::NL) {
+                int b;
+                if constexpr (DsimContactRegs<Ctx, Exec::NL>::value) b = ex.topo(lane).cbody_f;
+                else b = CI(cbody)[k];
+                const v3 xp = ld3(WF(xsc) + 7 * b);
+                const q4 xq = ldq(WF(xsc) + 7 * b + 3);
+                const sv6 vb = ldsv(WF(v) + 6 * b);
+                stsv(WF(cw) + 6 * k, dsim_contact_wrench(c, k, xp, xq, vb));
             }
-            stsv(WF(cw) + 6 * k, wr);
         }
         for (int s = lane; s < c.d.NS; s += Exec::NL) {
             const int w = CI(seg_wp)[s];

@@ -37,8 +37,6 @@ namespace {
 // what lets checkpoint traffic overlap with compute.
 __device__ __forceinline__ void dsim_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-#define DSIM_PF 6  // prefetch registers per lane (16 bytes each): rows up to 1536 floats (Humanoid: 1016)
-
 template <int N, int NW> __device__ __forceinline__ void dsim_wave_gj(float* H) {
     const int lane = (int)threadIdx.x;
     if (NW > 1 && lane >= DSIM_NL) return;
@@ -67,8 +65,10 @@ template <int N, int NW> __device__ __forceinline__ void dsim_wave_gj(float* H) 
 // NW wavefronts per environment (workgroup of 64 * NW lanes).  NW == 1: a phase boundary is the s_waitcnt above;
 // NW > 1: a workgroup barrier (phases whose item count exceeds 64 -- muscles, contacts, matrix entries of the bigger
 // models -- are spread over the waves, which sit on different SIMDs of the CU).
-template <int NW> struct DevExec {
+// PF: 16-byte prefetch registers per lane for one checkpoint row (specialised kernels: exactly what the model's row needs)
+template <int NW, int PF = 6> struct DevExec {
     static constexpr int NL = DSIM_NL * NW;
+    static constexpr int DSIM_PF = PF;
     __device__ __forceinline__ void sync() {
         if constexpr (NW == 1) dsim_wave_sync();
         else __syncthreads();
@@ -96,12 +96,15 @@ template <int NW> struct DevExec {
     __device__ __forceinline__ DsimTopoRegs& topo(int) { return topo_; }
     // software prefetch of one checkpoint row: global loads are issued here and stay in flight (registers) until
     // commit() stores them to LDS one adjoint substep later; rows longer than 64*DSIM_PF lanes*regs are read at commit
-    dsim_f4 pf[DSIM_PF];
+    // (a native vector type: the may_alias struct dsim_f4 of the copy loops is not promoted to registers -- an array of
+    // it ended up in scratch memory with an s_waitcnt vmcnt(0) right behind every prefetch load)
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f pf[DSIM_PF];
     const float* pf_src;
     __device__ __forceinline__ void prefetch(const float* row, int words) {
         pf_src = row;
         if (words > 4 * NL * DSIM_PF) return;
-        const dsim_f4* r4 = reinterpret_cast<const dsim_f4*>(row);
+        const v4f* r4 = reinterpret_cast<const v4f*>(row);
 #pragma unroll
         for (int r = 0; r < DSIM_PF; ++r) {
             const int k = (int)threadIdx.x + NL * r;
@@ -113,7 +116,7 @@ template <int NW> struct DevExec {
             for (int k = lane; k < words; k += NL) dst[k] = pf_src[k];
             return;
         }
-        dsim_f4* d4 = reinterpret_cast<dsim_f4*>(dst);
+        v4f* d4 = reinterpret_cast<v4f*>(dst);
 #pragma unroll
         for (int r = 0; r < DSIM_PF; ++r) {
             const int k = lane + NL * r;
@@ -131,6 +134,16 @@ template <class O, class D> struct KCommonT {
     long long ckpt_stride;  // floats per environment (dsim_ckpt_words)
 };
 
+// prefetch registers a model's checkpoint row needs (compile-time layouts), or the generic default of 6 (rows up to 1536 floats
+// at one wavefront per environment; longer rows are read at commit time)
+template <class O, int NW, bool LEAN> constexpr int dsim_pf_regs() {
+    if constexpr (std::is_empty<O>::value) {
+        constexpr int words = LEAN ? O::xsc - O::q : O::save_words;
+        return (words / 4 + DSIM_NL * NW - 1) / (DSIM_NL * NW);
+    } else {
+        return 6;
+    }
+}
 template <int NW, bool LEAN, class O, class D> __device__ __forceinline__ DsimCtxT<O, D, LEAN> start_env(float* lds, const KCommonT<O, D>& k) {
     // 16 bytes per lane and load (const_words is a multiple of 4, both sides are 16-byte aligned)
     dsim_f4* l = reinterpret_cast<dsim_f4*>(lds);
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_fwd_kernel(KCommonT<O, D> k
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
     auto c = start_env<NW, LEAN>(lds, k);
-    DevExec<NW> ex;
+    DevExec<NW, dsim_pf_regs<O, NW, LEAN>()> ex;
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_sim_step_forward(c, ex, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, act + e * nd,
                           M ? mact + e * M : nullptr, q_out + e * nq, qd_out + e * nd,
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_bwd_kernel(KCommonT<O, D> k
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
     auto c = start_env<NW, LEAN>(lds, k);
-    DevExec<NW> ex;
+    DevExec<NW, dsim_pf_regs<O, NW, LEAN>()> ex;
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_sim_step_backward(c, ex, k.substeps, k.mm_freq, ckpt + (size_t)e * k.ckpt_stride, act + e * nd,
                            M ? mact + e * M : nullptr, gq_out + e * nq, gqd_out + e * nd, gq_in + e * nq,
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_fwd_kernel(KCommonT<O, 
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
     auto c = start_env<NW, LEAN>(lds, k);
-    DevExec<NW> ex;
+    DevExec<NW, dsim_pf_regs<O, NW, LEAN>()> ex;
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_forward(c, ex, sp, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, actions + (size_t)e * sp.n_act,
                            q_out + e * nq, qd_out + e * nd, obs + (size_t)e * sp.n_obs, rew + e,
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_bwd_kernel(KCommonT<O, 
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
     auto c = start_env<NW, LEAN>(lds, k);
-    DevExec<NW> ex;
+    DevExec<NW, dsim_pf_regs<O, NW, LEAN>()> ex;
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_backward(c, ex, sp, k.substeps, k.mm_freq, ckpt + (size_t)e * k.ckpt_stride,
                             actions + (size_t)e * sp.n_act, gq_out ? gq_out + e * nq : nullptr,
