@@ -306,13 +306,50 @@ template <int I, int N, class F> DSIM_FN void dsim_static_for(F&& f) {
 // types that do not occur there -- and their loads -- are not even compiled)
 template <class D, int P> constexpr int dsim_pos_mask() { return P < DSIM_PMASK_N ? D::pmask[P] : D::tmask; }
 // number of joint coordinates / dofs a lane must fetch for a joint whose type is in `mask`
-DSIM_FN constexpr int dsim_mask_nq(int mask) {
+constexpr int dsim_mask_nq(int mask) {
     return (mask & DSIM_TM(DSIM_JOINT_FREE)) ? 7 : (mask & DSIM_TM(DSIM_JOINT_BALL)) ? 4
            : (mask & (DSIM_TM(DSIM_JOINT_PRISMATIC) | DSIM_TM(DSIM_JOINT_REVOLUTE))) ? 1 : 0;
 }
-DSIM_FN constexpr int dsim_mask_nd(int mask) {
+constexpr int dsim_mask_nd(int mask) {
     return (mask & DSIM_TM(DSIM_JOINT_FREE)) ? 6 : (mask & DSIM_TM(DSIM_JOINT_BALL)) ? 3
            : (mask & (DSIM_TM(DSIM_JOINT_PRISMATIC) | DSIM_TM(DSIM_JOINT_REVOLUTE))) ? 1 : 0;
+}
+
+// constants of ground contact k (material, body-fixed point, offset along the normal), loaded as a block
+struct DsimContactConst {
+    float ke, kd, kf, mu, cdist;
+    v3 cp;
+};
+template <class Ctx> DSIM_FN DsimContactConst dsim_contact_load(const Ctx& c, int k) {
+    const float* mat = CF(cmat) + 4 * k;
+    DsimContactConst cc;
+    cc.ke = mat[0]; cc.kd = mat[1]; cc.kf = mat[2]; cc.mu = mat[3];
+    cc.cp = ld3(CF(cpoint) + 3 * k);
+    cc.cdist = CF(cdist)[k];
+    return cc;
+}
+// wrench of a ground contact on its body with pose (xp, xq) and twist vb (sim.py:1137-1206)
+DSIM_FN sv6 dsim_contact_wrench(const DsimContactConst& k, v3 xp, q4 xq, sv6 vb) {
+    const float ke = k.ke, kd = k.kd, kf = k.kf, mu = k.mu;
+    v3 p = xp + rotate(xq, k.cp);
+    p.y -= k.cdist;
+    const v3 dpdt = vb.v + cross(vb.w, p);
+    const float cc = p.y;
+    sv6 wr = zerosv();
+    if (cc < 0.0f) {
+        const float vn = dpdt.y;
+        const v3 vt = mk3(dpdt.x, 0.f, dpdt.z);
+        const float fn = cc * ke;
+        const float fd = (vn < 0.0f ? vn : 0.0f) * kd * (0.0f - cc);
+        const float lt = sqrtf(dot(vt, vt));
+        const float a1 = kf * lt, a2 = 0.0f - mu * cc * ke;
+        const float smin = a1 < a2 ? a1 : a2;
+        v3 ft = zero3();
+        if (lt > 0.0f) ft = vt * (smin / lt);
+        const v3 ftot = mk3(ft.x, fn + fd, ft.z);
+        wr = mksv(cross(p, ftot), ftot);
+    }
+    return wr;
 }
 
 // What a link's lane carries along its ancestor chain, and what it keeps of its OWN (last) position.
@@ -332,17 +369,55 @@ struct DsimFkWalk {
 // writes its results once, after the walk, so that no load of a later position has to wait behind a store.
 // FIRST: the chain's root position (parent pose = identity, v = a = 0 before it): X_sj = X_pj, v = v_j, and the bias
 // acceleration v x v_j of a vector with itself is exactly zero.
-template <int MASK, bool FIRST, class Ctx> DSIM_FN void dsim_fk_position(const Ctx& c, DsimFkWalk& w, int j, int type, int cs, int ds) {
-    constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
-    const float *q = WF(q), *qd = WF(qd);
-    const v3 ppj = ld3(CF(xpj) + 7 * j);
-    const q4 rpj = ldq(CF(xpj) + 7 * j + 3);
-    const v3 axis = ld3(CF(axis) + 3 * j);
+// inputs of one chain position (joint constants + the joint's coordinates / velocities), loaded as a block
+template <int MASK> struct DsimFkIn {
+    static constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
+    v3 ppj, axis;
+    q4 rpj;
     float qv[NQ > 0 ? NQ : 1], qdv[NDF > 0 ? NDF : 1];
+};
+template <int MASK, class Ctx> DSIM_FN DsimFkIn<MASK> dsim_fk_load(const Ctx& c, int j, int cs, int ds) {
+    DsimFkIn<MASK> in;
+    const float *q = WF(q), *qd = WF(qd);
+    in.ppj = ld3(CF(xpj) + 7 * j);
+    in.rpj = ldq(CF(xpj) + 7 * j + 3);
+    in.axis = ld3(CF(axis) + 3 * j);
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) qv[k] = q[cs + k];
+    for (int k = 0; k < DsimFkIn<MASK>::NQ; ++k) in.qv[k] = q[cs + k];
 #pragma unroll
-    for (int k = 0; k < NDF; ++k) qdv[k] = qd[ds + k];
+    for (int k = 0; k < DsimFkIn<MASK>::NDF; ++k) in.qdv[k] = qd[ds + k];
+    return in;
+}
+// all positions of a lane's chain, loaded up front (specialised kernels: the chain records of positions past the end of
+// the chain repeat entry 0, so the loads need no predicate); one LDS round trip for the whole walk
+template <class D, int P, int N> struct DsimFkPre {
+    DsimFkIn<dsim_pos_mask<D, P>()> in;
+    DsimFkPre<D, P + 1, N> rest;
+};
+template <class D, int N> struct DsimFkPre<D, N, N> {};
+template <class D, int P, int N, class Ctx> DSIM_FN void dsim_fk_load_all(const Ctx& c, const int* ch, DsimFkPre<D, P, N>& pre) {
+    if constexpr (P < N) {
+        pre.in = dsim_fk_load<dsim_pos_mask<D, P>()>(c, ch[4 * P], ch[4 * P + 2], ch[4 * P + 3]);
+        dsim_fk_load_all<D, P + 1, N>(c, ch, pre.rest);
+    }
+}
+template <int MASK, bool FIRST> DSIM_FN void dsim_fk_compute(DsimFkWalk& w, const DsimFkIn<MASK>& in, int type);
+template <class D, int P, int N> DSIM_FN void dsim_fk_compute_all(DsimFkWalk& w, const int* ch, int n, const DsimFkPre<D, P, N>& pre) {
+    if constexpr (P < N) {
+        int ty = ch[4 * P + 1];
+        DSIM_OPAQUE(ty);
+        if (P < n) dsim_fk_compute<dsim_pos_mask<D, P>(), P == 0>(w, pre.in, ty);
+        dsim_fk_compute_all<D, P + 1, N>(w, ch, n, pre.rest);
+    }
+}
+
+template <int MASK, bool FIRST, class Ctx> DSIM_FN void dsim_fk_position(const Ctx& c, DsimFkWalk& w, int j, int type, int cs, int ds) {
+    dsim_fk_compute<MASK, FIRST>(w, dsim_fk_load<MASK>(c, j, cs, ds), type);
+}
+template <int MASK, bool FIRST> DSIM_FN void dsim_fk_compute(DsimFkWalk& w, const DsimFkIn<MASK>& in, int type) {
+    const v3 ppj = in.ppj, axis = in.axis;
+    const q4 rpj = in.rpj;
+    const float *qv = in.qv, *qdv = in.qdv;
     v3 pj = ppj;
     q4 rj = rpj;
     if constexpr (!FIRST) {
@@ -418,18 +493,34 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
             w.v = zerosv();
             w.a = zerosv();
             w.s0 = w.s1 = w.s2 = zerosv();
+            // body constants of the link (contact lanes: of link 0, unused), requested together with the chain inputs
+            const int ib = i < c.d.L ? i : 0;
+            const v3 com = ld3(CF(com) + 3 * ib);
+            const float* icp = CF(ic6) + 6 * ib;
+            const float ic0 = icp[0], ic1 = icp[1], ic2 = icp[2], ic3 = icp[3], ic4 = icp[4], ic5 = icp[5];
+            const float m = CF(mass)[ib];
+            const v3 grav = ld3(CF(grav));
+            DsimContactConst ccst{};
+            if constexpr (with_contacts) ccst = dsim_contact_load(c, i >= c.d.L ? i - c.d.L : 0);
             int own_type, own_ds;
             if constexpr (DsimChainRegs<Ctx>::value) {
                 using D = decltype(c.d);
                 const int* ch = ex.topo(lane).chain;
                 int n = ch[4 * DSIM_CHAIN_MAX];
                 DSIM_OPAQUE(n);
-                dsim_static_for<0, D::D>([&](auto P) {
-                    constexpr int p = decltype(P)::value;
-                    int ty = ch[4 * p + 1];
-                    DSIM_OPAQUE(ty);
-                    if (p < n) dsim_fk_position<dsim_pos_mask<D, p>(), p == 0>(c, w, ch[4 * p], ty, ch[4 * p + 2], ch[4 * p + 3]);
-                });
+                if constexpr (D::D <= 4) {
+                    // short chains: every position's inputs in ONE round trip (3 positions of an Ant leg: ~45 registers)
+                    DsimFkPre<D, 0, D::D> pre;
+                    dsim_fk_load_all<D, 0, D::D>(c, ch, pre);
+                    dsim_fk_compute_all<D, 0, D::D>(w, ch, n, pre);
+                } else {
+                    dsim_static_for<0, D::D>([&](auto P) {
+                        constexpr int p = decltype(P)::value;
+                        int ty = ch[4 * p + 1];
+                        DSIM_OPAQUE(ty);
+                        if (p < n) dsim_fk_position<dsim_pos_mask<D, p>(), p == 0>(c, w, ch[4 * p], ty, ch[4 * p + 2], ch[4 * p + 3]);
+                    });
+                }
                 own_type = ex.topo(lane).own_type;
                 own_ds = ex.topo(lane).own_ds;
                 DSIM_OPAQUE(own_type);
@@ -447,19 +538,13 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
             if constexpr (with_contacts) {
                 if (i >= c.d.L) {
                     // contact lane: the walk ended at the contact's body; its pose and twist are in registers
-                    const int k = i - c.d.L;
-                    stsv(WF(cw) + 6 * k, dsim_contact_wrench(c, k, w.psp, w.rsp, w.v));
+                    stsv(WF(cw) + 6 * (i - c.d.L), dsim_contact_wrench(ccst, w.psp, w.rsp, w.v));
                     continue;
                 }
             }
             // COM, world inertia and body force of link i from the values still in registers
             const v3 pc = w.psp;
             const q4 rc = w.rsp;
-            const v3 com = ld3(CF(com) + 3 * i);
-            const float* icp = CF(ic6) + 6 * i;
-            const float ic0 = icp[0], ic1 = icp[1], ic2 = icp[2], ic3 = icp[3], ic4 = icp[4], ic5 = icp[5];
-            const float m = CF(mass)[i];
-            const v3 grav = ld3(CF(grav));
             const v3 cm = rotate(rc, com) + pc;
             // world-frame inertia about the origin: Theta = R Ic R^T, A = Theta + m(c.c 1 - c c^T), h = m c
             v3 rx, ry, rz;
@@ -500,31 +585,6 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
     });
 }
 
-// wrench of ground contact k on its body with pose (xp, xq) and twist vb (sim.py:1137-1206)
-template <class Ctx> DSIM_FN sv6 dsim_contact_wrench(const Ctx& c, int k, v3 xp, q4 xq, sv6 vb) {
-    const float* mat = CF(cmat) + 4 * k;
-    const float ke = mat[0], kd = mat[1], kf = mat[2], mu = mat[3];
-    v3 p = xp + rotate(xq, ld3(CF(cpoint) + 3 * k));
-    p.y -= CF(cdist)[k];
-    const v3 dpdt = vb.v + cross(vb.w, p);
-    const float cc = p.y;
-    sv6 wr = zerosv();
-    if (cc < 0.0f) {
-        const float vn = dpdt.y;
-        const v3 vt = mk3(dpdt.x, 0.f, dpdt.z);
-        const float fn = cc * ke;
-        const float fd = (vn < 0.0f ? vn : 0.0f) * kd * (0.0f - cc);
-        const float lt = sqrtf(dot(vt, vt));
-        const float a1 = kf * lt, a2 = 0.0f - mu * cc * ke;
-        const float smin = a1 < a2 ? a1 : a2;
-        v3 ft = zero3();
-        if (lt > 0.0f) ft = vt * (smin / lt);
-        const v3 ftot = mk3(ft.x, fn + fd, ft.z);
-        wr = mksv(cross(p, ftot), ftot);
-    }
-    return wr;
-}
-
 // ground contacts (sim.py:1137-1206) and muscle segments (sim.py:1209-1242): per-item wrenches
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Exec& ex) {
     ex.mark(2);
@@ -539,7 +599,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Ex
                 const v3 xp = ld3(WF(xsc) + 7 * b);
                 const q4 xq = ldq(WF(xsc) + 7 * b + 3);
                 const sv6 vb = ldsv(WF(v) + 6 * b);
-                stsv(WF(cw) + 6 * k, dsim_contact_wrench(c, k, xp, xq, vb));
+                stsv(WF(cw) + 6 * k, dsim_contact_wrench(dsim_contact_load(c, k), xp, xq, vb));
             }
         }
         for (int s = lane; s < c.d.NS; s += Exec::NL) {
@@ -1368,12 +1428,16 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             }
             const sv6 v = ldsv(WF(v) + 6 * i), A = ldsv(WF(aatot) + 6 * i);
             sv6 a_v = ldsv(WF(av) + 6 * i), a_vj;
-            // vj = S qd of the link's own joint (not stored by the forward pass)
+            // vj = S qd of the link's own joint (not stored by the forward pass).  Operands of the hinge and free cases are
+            // fetched unconditionally, together with the loads above (one round trip; unused words are harmless)
+            const sv6 S0 = ldsv(WF(S) + 6 * ds);
+            const float qd0 = WF(qd)[ds];
             sv6 vj = zerosv();
             if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
-                if (type == DSIM_JOINT_FREE) vj = ldsv(WF(qd) + ds);
+                const sv6 qd6 = mksv(mk3(qd0, WF(qd)[ds + 1], WF(qd)[ds + 2]), ld3(WF(qd) + ds + 3));
+                if (type == DSIM_JOINT_FREE) vj = qd6;
             }
-            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) vj = ldsv(WF(S) + 6 * ds) * WF(qd)[ds];
+            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) vj = S0 * qd0;
             if constexpr ((MASK & DSIM_TM(DSIM_JOINT_BALL)) != 0) {
                 if (type == DSIM_JOINT_BALL)
                     for (int k = 0; k < 3; ++k) vj += ldsv(WF(S) + 6 * (ds + k)) * WF(qd)[ds + k];
@@ -1411,18 +1475,17 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             if (c.d.NS > 0) Z += ldsv(WF(agx) + 6 * i);
             sv6 Wp = zerosv();
             float* aqd = WF(aqd);
+            // operands of the hinge and free cases, fetched unconditionally with the loads above (one round trip)
+            const sv6 S0 = ldsv(WF(S) + 6 * ds), aS0 = ldsv(WF(aS) + 6 * ds);
+            const float qd0 = WF(qd)[ds], g0 = aqd[ds];
             // vj = S qd: cotangents of qd and of S; S is attached to the joint frame X_sj: W_par = sum S x* adj_S
             if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
-                if (type == DSIM_JOINT_FREE) {
-                    const sv6 g = ldsv(aqd + ds);
-                    stsv(aqd + ds, g + a_vj);
-                }
+                const sv6 g6 = mksv(mk3(g0, aqd[ds + 1], aqd[ds + 2]), ld3(aqd + ds + 3));
+                if (type == DSIM_JOINT_FREE) stsv(aqd + ds, g6 + a_vj);
             }
             if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
-                const sv6 S = ldsv(WF(S) + 6 * ds), aS = ldsv(WF(aS) + 6 * ds);
-                const float qd = WF(qd)[ds], g = aqd[ds];
-                Wp = scross_dual(S, aS + a_vj * qd);
-                aqd[ds] = g + sdot(S, a_vj);
+                Wp = scross_dual(S0, aS0 + a_vj * qd0);
+                aqd[ds] = g0 + sdot(S0, a_vj);
             }
             if constexpr ((MASK & DSIM_TM(DSIM_JOINT_BALL)) != 0) {
                 if (type == DSIM_JOINT_BALL) {
@@ -1461,11 +1524,9 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             }
             const sv6 Wt = ldsv(WF(azs) + 6 * i) - ldsv(WF(awp) + 6 * i);
             float* aq = WF(aq);
-            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
-                const sv6 S = ldsv(WF(S) + 6 * ds);
-                const float g = aq[cs];
-                aq[cs] = g + sdot(S, Wt);
-            }
+            const sv6 S0 = ldsv(WF(S) + 6 * ds);   // hinge operands, fetched unconditionally with the loads above
+            const float g0 = aq[cs];
+            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) aq[cs] = g0 + sdot(S0, Wt);
             if constexpr ((MASK & DSIM_TM(DSIM_JOINT_BALL)) != 0) {
                 if (type == DSIM_JOINT_BALL) {
                     const q4 r = ldq(WF(q) + cs), g = ldq(aq + cs);
@@ -1482,7 +1543,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
                     const q4 rpj = ldq(CF(xpj) + 7 * i + 3);
                     q4 rj = rpj;
                     if (par >= 0) rj = qmul(ldq(WF(xsc) + 7 * par + 3), rpj);
-                    const v3 gp = ld3(aq + cs);
+                    const v3 gp = mk3(g0, aq[cs + 1], aq[cs + 2]);
                     const q4 gr = ldq(aq + cs + 3);
                     const v3 tc = Wt.w - cross(pc, Wt.v);
                     st3(aq + cs, gp + rotate_inv(rj, Wt.v));
