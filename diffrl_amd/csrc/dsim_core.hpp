@@ -77,6 +77,11 @@ DSIM_FN float dsim_gather_sum(const float* data, int stride, int comp, const dsi
 DSIM_FN float dsim_range_sum(const float* data, int stride, int comp, int first, int count, float acc) {
     const float* p = data + stride * first + comp;
     int e = 0;
+    for (; e + 8 <= count; e += 8) {  // long ranges (muscle rows of a body): eight loads per LDS round trip
+        const float x0 = p[stride * e], x1 = p[stride * (e + 1)], x2 = p[stride * (e + 2)], x3 = p[stride * (e + 3)],
+                    x4 = p[stride * (e + 4)], x5 = p[stride * (e + 5)], x6 = p[stride * (e + 6)], x7 = p[stride * (e + 7)];
+        acc = (((((((acc + x0) + x1) + x2) + x3) + x4) + x5) + x6) + x7;
+    }
     for (; e + 4 <= count; e += 4) {
         const float x0 = p[stride * e], x1 = p[stride * (e + 1)], x2 = p[stride * (e + 2)], x3 = p[stride * (e + 3)];
         acc = (((acc + x0) + x1) + x2) + x3;
@@ -611,19 +616,22 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Ex
             const float l = sqrtf(dot(d, d));
             v3 f = zero3();
             if (l > 0.0f) f = d * (WF(mact)[CI(seg_m)[s]] / l);
-            // wrenches on the two links, signs applied: entry code 2s+side indexes 6-float rows
-            float* o = WF(mus) + 12 * s;
-            st3(o, -cross(pos0, f));
-            st3(o + 3, -f);
-            st3(o + 6, cross(pos1, f));
-            st3(o + 9, f);
+            // wrenches on the two links, signs applied, into the rows of their bodies (rows are sorted by body, so that the
+            // per-body gather below is a contiguous range sum without index loads)
+            float* o0 = WF(mus) + 6 * CI(seg_slot)[2 * s];
+            float* o1 = WF(mus) + 6 * CI(seg_slot)[2 * s + 1];
+            st3(o0, -cross(pos0, f));
+            st3(o0 + 3, -f);
+            st3(o1, cross(pos1, f));
+            st3(o1 + 3, f);
         }
     });
     if (c.d.NS > 0) {
         ex.run([&](int lane) {
             for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
                 const int i = it / 6, k = it - 6 * i;
-                WF(f)[it] = dsim_gather_sum(WF(mus), 6, k, CI(ml_list), CI(ml_start)[i], CI(ml_start)[i + 1], WF(f)[it]);
+                const int e0 = CI(ml_start)[i];
+                WF(f)[it] = dsim_range_sum(WF(mus), 6, k, e0, CI(ml_start)[i + 1] - e0, WF(f)[it]);
             }
         });
     }
@@ -1221,10 +1229,10 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external_items(const Ctx&
             a_p1 += a_d;
             a_p0 -= a_d;
         }
-        float* o = WF(mus) + 13 * s;  // the forward wrench rows are dead by now: same buffer
-        stsv(o, mksv(cross(pos0, a_p0), a_p0));
-        stsv(o + 6, mksv(cross(pos1, a_p1), a_p1));
-        o[12] = a_act;
+        // the forward wrench rows are dead by now: same buffer, same body-sorted rows + one activation cotangent per segment
+        stsv(WF(mus) + 6 * CI(seg_slot)[2 * s], mksv(cross(pos0, a_p0), a_p0));
+        stsv(WF(mus) + 6 * CI(seg_slot)[2 * s + 1], mksv(cross(pos1, a_p1), a_p1));
+        WF(mus)[12 * c.d.NS + s] = a_act;
     }
 }
 
@@ -1384,7 +1392,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             // a muscle's active segments are consecutive rows of `mus`: batched range sum, not a serial chain of loads
             const int s0 = CI(ms_start)[m], s1 = CI(ms_start)[m + 1];
             const float g = WF(amact)[m];
-            WF(amact)[m] = g + dsim_range_sum(WF(mus), 13, 12, s0, s1 - s0, 0.f);
+            WF(amact)[m] = g + dsim_range_sum(WF(mus) + 12 * c.d.NS, 1, 0, s0, s1 - s0, 0.f);
         }
         for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
             const int i = it / 6, k = it - 6 * i;
@@ -1396,22 +1404,9 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
         if (c.d.NS > 0)
             for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
                 const int i = it / 6, r = it - 6 * i;
-                // entry code 2 s + side -> row s, wrench `side` of the 13-float adjoint rows; four entries per round trip
-                float acc = 0.f;
-                const dsim_int_a* lst = CI(ml_list);
-                const float* mus = WF(mus) + r;
-                int e = CI(ml_start)[i];
-                const int e1 = CI(ml_start)[i + 1];
-                for (; e + 4 <= e1; e += 4) {
-                    const int c0 = lst[e], c1 = lst[e + 1], c2 = lst[e + 2], c3 = lst[e + 3];
-                    const float x0 = mus[6 * c0 + (c0 >> 1)], x1 = mus[6 * c1 + (c1 >> 1)], x2 = mus[6 * c2 + (c2 >> 1)],
-                                x3 = mus[6 * c3 + (c3 >> 1)];
-                    acc = (((acc + x0) + x1) + x2) + x3;
-                }
-                for (; e < e1; ++e) {
-                    const int code = lst[e];
-                    acc += mus[6 * code + (code >> 1)];
-                }
+                // the rows of a body are consecutive (seg_slot): contiguous range sum
+                const int e0 = CI(ml_start)[i];
+                const float acc = dsim_range_sum(WF(mus), 6, r, e0, CI(ml_start)[i + 1] - e0, 0.f);
                 WF(agx)[it] = acc;
             }
     });

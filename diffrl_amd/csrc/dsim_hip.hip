@@ -355,7 +355,9 @@ struct dsim_model {
     int lean = 0;    // checkpoint mode (dsim_model_set_ckpt_mode)
     int row_words() const { return lean ? lay.o.xsc - lay.o.q : lay.o.save_words; }
 };
-#define DSIM_WAVES_WIDE 4
+#ifndef DSIM_WAVES_WIDE
+#define DSIM_WAVES_WIDE 4   // (-DDSIM_WAVES_WIDE=2 builds the A/B variant)
+#endif
 
 namespace {
 

@@ -38,6 +38,7 @@ struct DsimOff {
     int cbody;
     int seg_wp, seg_m;          // active muscle segment -> first waypoint index / muscle index
     int ml_start, ml_list;      // link -> list of (segment*2 + side)
+    int seg_slot;               // [2*NS] (segment, side) -> position in ml_list: wrench rows are kept sorted by body
     int ms_start;               // muscle -> [first, last) active segment
     int mlinks;
     // ---- constant block: floats
@@ -247,6 +248,9 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.seg_m = put_i(seg_m.data(), NS);
     o.ml_start = put_i(ml_start.data(), L + 1);
     o.ml_list = put_i(ml_list.data(), ml_list.size());
+    std::vector<int> seg_slot(2 * NS, 0);
+    for (size_t e = 0; e < ml_list.size(); ++e) seg_slot[ml_list[e]] = (int)e;
+    o.seg_slot = put_i(seg_slot.data(), seg_slot.size());
     o.ms_start = put_i(ms_start.data(), M + 1);
     o.mlinks = put_i(m.muscle_links, W);
     o.xpj = put_f(m.joint_X_pj, 7 * L);
@@ -296,7 +300,7 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.ua = take(M > nd ? M : nd); o.obs = take(16 + nq + nd + (M > nd ? M : nd));
     o.f = take(6 * L); o.cw = take(6 * C); o.tau = take(nd);
     o.ic10 = take(10 * L); o.F = take(6 * nd); o.hinv = take(nd * nd); o.prow = take(nd); o.pcol = take(nd);
-    o.mus = take(13 * NS);  // forward: 12 floats/segment (signed wrenches); adjoint: 13 floats/segment (two wrench cotangents + activation)
+    o.mus = take(13 * NS);  // 2 NS wrench rows of 6 floats, sorted by body (seg_slot), + (adjoint) NS activation cotangents
     o.epf = take(4);
     o.fwd_words = cur;
     o.aq = take(nq); o.aqd = take(nd);
