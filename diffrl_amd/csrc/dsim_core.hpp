@@ -631,11 +631,28 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Ex
             for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
                 const int i = it / 6, k = it - 6 * i;
                 const int e0 = CI(ml_start)[i];
-                WF(f)[it] = dsim_range_sum(WF(mus), 6, k, e0, CI(ml_start)[i + 1] - e0, WF(f)[it]);
+                float acc = dsim_range_sum(WF(mus), 6, k, e0, CI(ml_start)[i + 1] - e0, WF(f)[it]);
+                acc = dsim_body_contact_sum(c, i, WF(cw), 6, k, acc);   // + the body's own contact wrenches
+                WF(f)[it] = acc;
             }
         });
     }
 }
+
+// sum over the contacts of body i of a per-contact component (models with muscles gather per body anyway: their contact
+// terms ride along in that phase, and the subtree sums that follow are sums over links only)
+template <class Ctx> DSIM_FN float dsim_body_contact_sum(const Ctx& c, int i, const float* cdata, int cstride, int ck, float acc) {
+    const int b0 = CI(cb_start)[i], b1 = CI(cb_start)[i + 1];
+    if (c.d.flags & DSIM_F_RANGES) {
+        if constexpr (DsimIsStatic<Ctx>::value)
+            return dsim_range_sum_b<dsim_cap_body_contacts<decltype(c.d)>()>(cdata, cstride, ck, b0, b1 - b0, acc);
+        else
+            return dsim_range_sum(cdata, cstride, ck, b0, b1 - b0, acc);
+    }
+    return dsim_gather_sum(cdata, cstride, ck, CI(cb_list), b0, b1, acc);
+}
+// true: contact terms are gathered per body in the muscle-gather phases; false: inside the subtree sums
+template <class Ctx> DSIM_FN bool dsim_contacts_per_body(const Ctx& c) { return c.d.NS > 0; }
 
 // sum over subtree(i) of a per-link 6-vector component + sum over the contacts of all bodies in subtree(i) of a
 // per-contact component (forward: body forces + contact wrenches; adjoint: twist / pose-wrench cotangents)
@@ -643,6 +660,11 @@ template <class Ctx, class Exec>
 DSIM_FN float dsim_subtree_contact_sum(const Ctx& c, Exec& ex, int lane, int i, const float* ldata, int k,
                                        const float* cdata, int cstride, int ck) {
     float acc;
+    if (dsim_contacts_per_body(c)) {   // contact terms are already inside the per-link data
+        int n_known = -1;
+        if constexpr (DsimSixRegs<Ctx, Exec::NL>::value) n_known = ex.topo(lane).six_n;
+        return dsim_subtree_sum(c, ldata, 6, k, i, n_known);
+    }
     if (c.d.flags & DSIM_F_RANGES) {
         DsimLinkInfo li;
         if constexpr (DsimSixRegs<Ctx, Exec::NL>::value) {
@@ -1402,12 +1424,16 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
         }
         // per-body gather of the muscle pose wrenches (contact cotangents go straight into the subtree sums below)
         if (c.d.NS > 0)
-            for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
-                const int i = it / 6, r = it - 6 * i;
-                // the rows of a body are consecutive (seg_slot): contiguous range sum
-                const int e0 = CI(ml_start)[i];
-                const float acc = dsim_range_sum(WF(mus), 6, r, e0, CI(ml_start)[i + 1] - e0, 0.f);
-                WF(agx)[it] = acc;
+            for (int it = lane; it < 12 * c.d.L; it += Exec::NL) {
+                const int i = it / 12, r = it - 12 * i;
+                // r < 6: pose wrench of the body = its muscle rows (consecutive, seg_slot) + its contacts; r >= 6: the twist
+                // cotangent of its contacts
+                float acc = 0.f;
+                if (r < 6) {
+                    const int e0 = CI(ml_start)[i];
+                    acc = dsim_range_sum(WF(mus), 6, r, e0, CI(ml_start)[i + 1] - e0, 0.f);
+                }
+                WF(agx)[it] = dsim_body_contact_sum(c, i, WF(acx), 12, r, acc);
             }
     });
     ex.run([&](int lane) {
@@ -1423,6 +1449,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             }
             const sv6 v = ldsv(WF(v) + 6 * i), A = ldsv(WF(aatot) + 6 * i);
             sv6 a_v = ldsv(WF(av) + 6 * i), a_vj;
+            if (c.d.NS > 0) a_v += ldsv(WF(agx) + 12 * i + 6);   // contact twist cotangents gathered per body
             // vj = S qd of the link's own joint (not stored by the forward pass).  Operands of the hinge and free cases are
             // fetched unconditionally, together with the loads above (one round trip; unused words are harmless)
             const sv6 S0 = ldsv(WF(S) + 6 * ds);
@@ -1467,7 +1494,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             }
             const sv6 a_vj = ldsv(WF(avj) + 6 * i) + ldsv(WF(avtot) + 6 * i);
             sv6 Z = ldsv(WF(aw) + 6 * i);
-            if (c.d.NS > 0) Z += ldsv(WF(agx) + 6 * i);
+            if (c.d.NS > 0) Z += ldsv(WF(agx) + 12 * i);
             sv6 Wp = zerosv();
             float* aqd = WF(aqd);
             // operands of the hinge and free cases, fetched unconditionally with the loads above (one round trip)

@@ -313,7 +313,7 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.awp = take(6 * L);    // the same for the link's joint frame X_sj (what its motion subspace is attached to)
     o.azs = take(6 * L);    // subtree sums of aw + awp
     o.ai10m = take(10 * L); o.aic10 = take(10 * (nd > L ? nd : L)); o.aH = take(nd * nd);
-    o.gua = take(M > nd ? M : nd); o.agx = take(6 * L);  // per-body sums of the muscle pose wrenches
+    o.gua = take(M > nd ? M : nd); o.agx = take(12 * L);  // per-body sums (models with muscles): pose wrench of muscles + contacts (6), twist cotangent of contacts (6)
     o.total_words = cur;
 
     out.o = o;
