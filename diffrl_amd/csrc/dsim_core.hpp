@@ -872,6 +872,142 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_integrate(const Ctx& c, E
     });
 }
 
+// ---- forward dynamics of a substep in ONE phase (small models, one wavefront per environment) -----------------------------
+// f_tot (subtree sums) -> tau -> qdd = H^-1 tau -> checkpoint copy -> integrate used to be four phases whose only
+// connection is a handful of values that change lanes: the 6 components of f_tot[link(d)] go from the (link, component)
+// lanes to dof lane d, tau_j goes from dof lane j to every dof lane, qdd of a link's dofs goes to the link's lane.  With
+// the wavefront's cross-lane primitives (Exec::shfl = ds_bpermute, Exec::bcast = v_readlane) these exchanges stay in
+// registers, and three LDS store -> phase boundary -> load round trips disappear (forward substep of Ant: 5 phases -> 2).
+// Same arithmetic in the same order as dsim_fwd_tau / dsim_fwd_solve / dsim_fwd_integrate.
+template <class Ctx, class Exec> struct DsimWaveDyn {
+    static constexpr bool value = []() {
+        if constexpr (std::is_empty<decltype(Ctx::d)>::value && Exec::WAVE_OPS) {
+            using D = decltype(Ctx::d);
+            return 6 * D::L <= Exec::NL && D::nd <= 32 && D::NS == 0 && (D::flags & DSIM_F_RANGES) != 0;
+        } else {
+            return false;
+        }
+    }();
+};
+template <class Ctx, class Exec>
+DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float* g_hinv, bool update_mass) {
+    ex.mark(3);
+    using D = decltype(c.d);
+    constexpr int nd = D::nd, L = D::L;
+    ex.run([&](int lane) {
+        constexpr int MASK = dsim_tmask_static<Ctx>();
+        constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
+        const float h = c.h;
+        const DsimTopoRegs& tp = ex.topo(lane);
+        const bool is_dof = lane < nd, is_link = lane < L;
+        // ---- loads of all three roles, issued together
+        // dof role
+        int dtype = tp.dof_type;
+        DSIM_OPAQUE(dtype);
+        const int di = tp.dof_link, dcs = tp.dof_cs, dds = tp.dof_ds, d = is_dof ? lane : 0;
+        const bool hinge = dtype == DSIM_JOINT_PRISMATIC || dtype == DSIM_JOINT_REVOLUTE;
+        const int qi = hinge ? dcs : (dtype == DSIM_JOINT_BALL ? dcs + (d - dds) : 0);
+        const sv6 Sd = ldsv(WF(S) + 6 * d);
+        const float q_d = WF(q)[qi], qd_d = WF(qd)[d], act_d = WF(act)[d];
+        const float lower = CF(lower)[qi], upper = CF(upper)[qi], target = CF(target)[qi];
+        const float lke = CF(lke)[di], tke = CF(tke)[di], tkd = CF(tkd)[di], lkd = CF(lkd)[di];
+        float hrow[nd];
+#pragma unroll
+        for (int j = 0; j < nd; ++j) hrow[j] = WF(hinv)[d * nd + j];
+        // link role
+        int ltype = tp.own_type;
+        DSIM_OPAQUE(ltype);
+        const int lcs = tp.own_cs, lds_ = tp.own_ds;
+        float qv[NQ > 0 ? NQ : 1], qdv[NDF > 0 ? NDF : 1];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) qv[k] = WF(q)[lcs + k];
+#pragma unroll
+        for (int k = 0; k < NDF; ++k) qdv[k] = WF(qd)[lds_ + k];
+        // ---- (link, component) role: f_tot = subtree sums of the body forces and contact wrenches
+        float ft = 0.f;
+        if (lane < 6 * L) {
+            ft = dsim_subtree_contact_sum(c, ex, lane, lane / 6, WF(f), lane - 6 * (lane / 6), WF(cw), 6, lane - 6 * (lane / 6));
+            WF(ftot)[lane] = ft;   // the adjoint reads it from the checkpoint
+        }
+        // ---- f_tot[link(d)] -> dof lane d
+        sv6 F;
+        F.w.x = ex.shfl(ft, 6 * di + 0); F.w.y = ex.shfl(ft, 6 * di + 1); F.w.z = ex.shfl(ft, 6 * di + 2);
+        F.v.x = ex.shfl(ft, 6 * di + 3); F.v.y = ex.shfl(ft, 6 * di + 4); F.v.z = ex.shfl(ft, 6 * di + 5);
+        // ---- dof role: tau (sim.py:1421-1502)
+        float t = 0.0f - sdot(Sd, F);
+        if (hinge) {
+            float limit_f = 0.0f;
+            if (q_d < lower) limit_f = lke * (lower - q_d);
+            if (q_d > upper) limit_f = lke * (upper - q_d);
+            t = t - tke * (q_d - target) - tkd * qd_d + act_d + limit_f - lkd * qd_d;
+        } else if (dtype == DSIM_JOINT_BALL) {
+            t = t - qd_d * tkd - q_d * tke;
+        }
+        // ---- qdd = H^-1 tau: tau_j travels by v_readlane
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < nd; ++j) acc += hrow[j] * ex.bcast(t, j);
+        if (is_dof) {
+            WF(tau)[lane] = t;
+            WF(qdd)[lane] = acc;
+        }
+        // ---- qdd of a link's dofs -> the link's lane
+        float av[NDF > 0 ? NDF : 1];
+#pragma unroll
+        for (int k = 0; k < NDF; ++k) av[k] = ex.shfl(acc, lds_ + k);
+        // ---- checkpoint row (needs f_tot and qdd of all lanes in LDS, and q / qd before integrate overwrites them)
+        if (g_row) {
+            ex.lds_fence();
+            const dsim_f4* src = reinterpret_cast<const dsim_f4*>(WF(q));
+            dsim_f4* dst = reinterpret_cast<dsim_f4*>(g_row);
+            for (int k = lane; k < dsim_row(c) / 4; k += Exec::NL) dst[k] = src[k];
+            if (update_mass && g_hinv)
+                for (int k = lane; k < nd * nd; k += Exec::NL) g_hinv[k] = WF(hinv)[k];
+            ex.lds_fence();
+        }
+        // ---- link role: semi-implicit Euler (sim.py:1505-1636), in place on q, qd
+        if (is_link) {
+            float *q = WF(q), *qd = WF(qd);
+            if (ltype == DSIM_JOINT_PRISMATIC || ltype == DSIM_JOINT_REVOLUTE) {
+                const float qdn = qdv[0] + av[0] * h;
+                qd[lds_] = qdn;
+                q[lcs] = qv[0] + qdn * h;
+            }
+            if constexpr ((MASK & (DSIM_TM(DSIM_JOINT_BALL) | DSIM_TM(DSIM_JOINT_FREE))) != 0) {
+                if (ltype == DSIM_JOINT_BALL || ltype == DSIM_JOINT_FREE) {
+                    const bool fr = ltype == DSIM_JOINT_FREE;
+                    const v3 w = mk3(qdv[0], qdv[1], qdv[2]) + mk3(av[0], av[1], av[2]) * h;
+                    q4 r;
+                    v3 pn = zero3(), vn = zero3();
+                    if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
+                        if (fr) {
+                            vn = mk3(qdv[3], qdv[4], qdv[5]) + mk3(av[3], av[4], av[5]) * h;
+                            const v3 p = mk3(qv[0], qv[1], qv[2]);
+                            pn = p + (vn + cross(w, p)) * h;
+                            r = mkq(qv[3], qv[4], qv[5], qv[6]);
+                        } else {
+                            r = mkq(qv[0], qv[1], qv[2], qv[3]);
+                        }
+                    } else {
+                        r = mkq(qv[0], qv[1], qv[2], qv[3]);
+                    }
+                    const q4 dr = qmul(mkq(w.x, w.y, w.z, 0.f), r) * 0.5f;
+                    const q4 rt = r + dr * h;
+                    const float l = sqrtf(qdot(rt, rt));
+                    q4 rn = mkq(0.f, 0.f, 0.f, 1.f);
+                    if (l > 0.0f) rn = rt * (1.0f / l);
+                    if (fr) {
+                        st3(q + lcs, pn);
+                        st3(qd + lds_ + 3, vn);
+                    }
+                    stq(q + lcs + (fr ? 3 : 0), rn);
+                    st3(qd + lds_, w);
+                }
+            }
+        }
+    });
+}
+
 // ---- checkpoint = what the adjoint launch needs from the forward launch, kept in HBM instead of recomputed ----
 // per environment: [substeps][save_words] saved blocks (q, qd, X_sj, X_sc, COM, S, v_j, v, a, inertias, f_tot, qdd of the
 // substep) followed by [groups][hinv_words] inverses of the mass matrix (one per refresh).  288 GB of HBM are otherwise
@@ -891,6 +1027,11 @@ template <class Ctx, class Exec>
 DSIM_FN void dsim_fwd_substep(const Ctx& c, Exec& ex, bool update_mass, float* g_row = nullptr, float* g_hinv = nullptr) {
     dsim_fwd_kinematics(c, ex);
     dsim_fwd_external(c, ex);
+    if constexpr (DsimWaveDyn<Ctx, Exec>::value) {
+        if (update_mass) dsim_fwd_mass(c, ex);   // H depends on the kinematics only
+        dsim_fwd_dynamics_wave(c, ex, g_row, g_hinv, update_mass);
+        return;
+    }
     dsim_fwd_tau(c, ex);
     if (update_mass) dsim_fwd_mass(c, ex);
     dsim_fwd_solve(c, ex);

@@ -69,6 +69,20 @@ template <int N, int NW> __device__ __forceinline__ void dsim_wave_gj(float* H) 
 template <int NW, int PF = 6> struct DevExec {
     static constexpr int NL = DSIM_NL * NW;
     static constexpr int DSIM_PF = PF;
+    // Cross-lane primitives of the wavefront (one wave per environment only): the phase code uses them for the small
+    // point-to-point exchanges between lanes that would otherwise be an LDS store, a phase boundary and an LDS load.
+    static constexpr bool WAVE_OPS = NW == 1;
+    // value of v in lane `src` (any lane): ds_bpermute_b32 -- the LDS crossbar, no LDS memory, no phase boundary.  All
+    // lanes of the wave must execute it (uniform control flow); values of lanes that hold nothing meaningful are ignored.
+    __device__ __forceinline__ float shfl(float v, int src) {
+        return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
+    }
+    // value of v in lane `src`, src uniform across the wave (a compile-time constant after unrolling): v_readlane_b32
+    __device__ __forceinline__ float bcast(float v, int src) {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+    }
+    // this wave's earlier LDS stores are visible to its later LDS loads (DS operations of a wave execute in order)
+    __device__ __forceinline__ void lds_fence() { dsim_wave_sync(); }
     __device__ __forceinline__ void sync() {
         if constexpr (NW == 1) dsim_wave_sync();
         else __syncthreads();
@@ -257,6 +271,14 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_obs_kernel(KCommonT<O, 
 // developer tool (tools/phase_timer.py): per-phase cycle stamps of workgroup 0; NOT compiled into the product library
 template <int NW> struct TimingExec {
     static constexpr int NL = DSIM_NL * NW;
+    static constexpr bool WAVE_OPS = NW == 1;
+    __device__ __forceinline__ float shfl(float v, int src) {
+        return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
+    }
+    __device__ __forceinline__ float bcast(float v, int src) {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+    }
+    __device__ __forceinline__ void lds_fence() { __syncthreads(); }
     long long* buf;
     int idx, cap;
     int tag = 0;

@@ -3,20 +3,85 @@
 // unit-tested in the GPU-less build container.  It is NOT a CPU fallback: nothing in diffrl_amd/
 // loads it, and it is built only by tests/emu/Makefile.  The GPU tests (-m gpu) exercise the real
 // HIP kernels through the C ABI.
+#include <ucontext.h>
+
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #define DSIM_FN static inline
 #include "../../diffrl_amd/csrc/dsim_core.hpp"
 #include "../../diffrl_amd/csrc/dsim_static_layouts.hpp"
 
-// NW wavefronts per environment: NL = 64 * NW lanes, run one after another (the library's kernels use 1 or 4)
+// NW wavefronts per environment: NL = 64 * NW lanes (the library's kernels use 1 or 4).
+//
+// One wavefront (NW == 1): the lanes of a phase run as 64 coroutines in lock step, so that the phase code may use the
+// wavefront's cross-lane primitives -- shfl (ds_bpermute on the GPU), bcast (v_readlane), lds_fence -- exactly where the
+// kernels use them: a lane that reaches a collective deposits its value and yields; once every lane still running has
+// arrived, each continues with the value of its source lane.  Four wavefronts: plain lane-serial execution, no
+// cross-lane primitives (the kernels have none across wavefronts either; WAVE_OPS is false).
 template <int NW> struct HostExecT {
     static constexpr int NL = DSIM_NL * NW;
-    template <class F> void run(F&& f) {
-        for (int lane = 0; lane < NL; ++lane) f(lane);
+    static constexpr bool WAVE_OPS = NW == 1;
+    static constexpr size_t STACK = 512 * 1024;
+    ucontext_t main_ctx_, lane_ctx_[NL];
+    std::vector<char> stacks_;
+    std::function<void(int)> body_;
+    bool done_[NL];
+    int cur_ = 0, parity_[NL];
+    float slot_[2][NL];
+    static HostExecT*& self() {
+        static thread_local HostExecT* p = nullptr;
+        return p;
     }
+    static void tramp(int lane) {
+        HostExecT* e = self();
+        e->body_(lane);
+        e->done_[lane] = true;
+        swapcontext(&e->lane_ctx_[lane], &e->main_ctx_);
+    }
+    template <class F> void run(F&& f) {
+        if constexpr (!WAVE_OPS) {
+            for (int lane = 0; lane < NL; ++lane) f(lane);
+        } else {
+            if (stacks_.empty()) stacks_.resize(STACK * NL);
+            body_ = [&f](int lane) { f(lane); };
+            self() = this;
+            for (int lane = 0; lane < NL; ++lane) {
+                done_[lane] = false;
+                parity_[lane] = 0;
+                getcontext(&lane_ctx_[lane]);
+                lane_ctx_[lane].uc_stack.ss_sp = stacks_.data() + STACK * lane;
+                lane_ctx_[lane].uc_stack.ss_size = STACK;
+                lane_ctx_[lane].uc_link = &main_ctx_;
+                makecontext(&lane_ctx_[lane], (void (*)())tramp, 1, lane);
+            }
+            for (int left = NL; left > 0;) {
+                left = 0;
+                for (int lane = 0; lane < NL; ++lane) {
+                    if (done_[lane]) continue;
+                    cur_ = lane;
+                    swapcontext(&main_ctx_, &lane_ctx_[lane]);  // runs until the lane's next collective or its end
+                    if (!done_[lane]) ++left;
+                }
+            }
+        }
+    }
+    // collectives (only meaningful inside run(), NW == 1).  Every lane that is still running must call the same sequence.
+    void arrive() {
+        const int lane = cur_;
+        swapcontext(&lane_ctx_[lane], &main_ctx_);  // back to the scheduler; resumed when all running lanes have arrived
+    }
+    float shfl(float v, int src) {
+        const int lane = cur_, p = parity_[lane];
+        slot_[p][lane] = v;
+        parity_[lane] ^= 1;
+        arrive();
+        return slot_[p][src & (NL - 1)];
+    }
+    float bcast(float v, int src) { return shfl(v, src); }
+    void lds_fence() { arrive(); }
     template <class F> void fire(F&& f) { run(f); }
     // host form of the register / v_readlane Gauss-Jordan of the kernels (dsim_hip.hip: dsim_wave_gj): same formulas
     template <int N> void wave_gj(float* H) {
