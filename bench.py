@@ -102,6 +102,46 @@ def time_backward_kernel(env, name, n, H, reps, device):
     return t_bwd
 
 
+def measure_other_config(name, n, H, mm, device, steps=2):
+    """fwd+adjoint env-steps/s of another BASELINE.json configuration on this GPU: the same rollout (H x DFlexEnv.step, loss =
+    -sum(rew), one backward), captured as a HIP graph, `steps` timed replays after one warm-up; adjoint / forward kernel
+    times by HIP events.  Informational: the headline `value` is the workload named in config.workload."""
+    saved = MM_FREQ[name]
+    MM_FREQ[name] = mm
+    try:
+        from diffrl_amd.graph import GraphedRollout
+        env = make_env(name, n, str(device))
+        gen = torch.Generator().manual_seed(1)
+        actions = torch.tanh(2.0 * torch.rand((H, n, env.num_actions), generator=gen) - 1.0).to(device)
+        acts = actions.detach().clone().requires_grad_(True)
+
+        def body(e):
+            e.initialize_trajectory()
+            return reward_loss([e.step(a_t)[1] for a_t in acts.unbind(0)])
+
+        env.clear_grad()
+        env.reset()
+        roll = GraphedRollout(env, body, leaves=[acts], carry_state=False)
+        roll.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            roll.replay()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        assert torch.isfinite(acts.grad).all()
+        t_bwd = time_backward_kernel(env, name, n, H, 10, device)
+        eng = env.model.engine()
+        return {"workload": "%s %d envs x H=%d, MM_caching_frequency %d" % (name, n, H, mm), "value": steps * n * H / el,
+                "unit": "env-steps/s", "ms_per_rollout": el / steps * 1e3, "kernel_ms": t_bwd * 1e3,
+                "fwd_kernel_ms": time_backward_kernel.fwd_s * 1e3,
+                "ckpt_bytes_per_env_step": 4 * int(eng._lib.dsim_ckpt_floats_mm(eng._h, env.sim_substeps, mm))}
+    except Exception as ex:
+        return {"workload": "%s %d envs x H=%d" % (name, n, H), "value": None, "error": str(ex)[:200]}
+    finally:
+        MM_FREQ[name] = saved
+
+
 def cpu_baseline(name, budget_s=12.0):
     """CPU baseline beside the GPU number (oracle/cpu_baseline.py, a subprocess so that nothing GPU-related is forked):
     the reference's own CPU path when its checkout is present (kind "reference"), otherwise the multi-threaded scalar
@@ -136,6 +176,9 @@ def parse_args(argv=None):
     ap.add_argument("--horizon", type=int, default=32)
     ap.add_argument("--mm-freq", type=int, default=0, help="MM_caching_frequency (0: the examples/cfg/shac value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short measurements of the other BASELINE.json configurations (Humanoid 1024 x 32, SNUHumanoid "
+                         "512 x 32, Ant with MM_caching_frequency 1) that the default single-GPU Ant run appends as `other_configs`")
     ap.add_argument("--eager", action="store_true", help="time the Python-driven step loop instead of the graph replay")
     ap.add_argument("--strict", action="store_true", help="exit non-zero if the graph capture fell back to the eager loop")
     ap.add_argument("--launcher", action="store_true",
@@ -359,6 +402,15 @@ def main(argv=None):
                 q, qd, _, _, _ = eng.env_forward(spec, q, qd, actions[t % H], env.sim_dt, env.sim_substeps, mm, False)
             torch.cuda.synchronize()
             out["no_grad_forward_env_steps_per_s"] = 100 * n / (time.perf_counter() - t0)
+        if not a.no_other_configs and world == 1 and a.env == "ant" and not a.eager:
+            # BASELINE.json configs[2], configs[3] and the MM_caching_frequency = 1 variant of configs[1] (SURVEY.md 8(d):
+            # "also report 1"), each a few seconds: driver-visible numbers next to the headline
+            del env, roll
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["other_configs"] = [measure_other_config("humanoid", 1024, H, MM_FREQ["humanoid"], device),
+                                    measure_other_config("snu", 512, H, MM_FREQ["snu"], device),
+                                    measure_other_config("ant", n, H, 1, device)]
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.env)
         print(json.dumps(out))
