@@ -416,6 +416,21 @@ template <class D, int P, int N> DSIM_FN void dsim_fk_compute_all(DsimFkWalk& w,
     }
 }
 
+// chunked walk of a long chain: positions [P, P + 3) are in `cur`; the following chunk is loaded first, then `cur` is evaluated
+template <class D, int P, class Ctx, class Pre>
+DSIM_FN void dsim_fk_walk_chunks(const Ctx& c, DsimFkWalk& w, const int* ch, int n, const Pre& cur) {
+    constexpr int E = P + 3 < D::D ? P + 3 : D::D;        // end of the current chunk
+    if constexpr (E < D::D) {
+        constexpr int E2 = E + 3 < D::D ? E + 3 : D::D;
+        DsimFkPre<D, E, E2> nxt;
+        dsim_fk_load_all<D, E, E2>(c, ch, nxt);
+        dsim_fk_compute_all<D, P, E>(w, ch, n, cur);
+        dsim_fk_walk_chunks<D, E>(c, w, ch, n, nxt);
+    } else {
+        dsim_fk_compute_all<D, P, E>(w, ch, n, cur);
+    }
+}
+
 template <int MASK, bool FIRST, class Ctx> DSIM_FN void dsim_fk_position(const Ctx& c, DsimFkWalk& w, int j, int type, int cs, int ds) {
     dsim_fk_compute<MASK, FIRST>(w, dsim_fk_load<MASK>(c, j, cs, ds), type);
 }
@@ -519,12 +534,11 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
                     dsim_fk_load_all<D, 0, D::D>(c, ch, pre);
                     dsim_fk_compute_all<D, 0, D::D>(w, ch, n, pre);
                 } else {
-                    dsim_static_for<0, D::D>([&](auto P) {
-                        constexpr int p = decltype(P)::value;
-                        int ty = ch[4 * p + 1];
-                        DSIM_OPAQUE(ty);
-                        if (p < n) dsim_fk_position<dsim_pos_mask<D, p>(), p == 0>(c, w, ch[4 * p], ty, ch[4 * p + 2], ch[4 * p + 3]);
-                    });
+                    // long chains (Humanoid: 10 positions): chunks of three positions, the next chunk's inputs requested
+                    // before the current chunk is evaluated
+                    DsimFkPre<D, 0, 3> pre;
+                    dsim_fk_load_all<D, 0, 3>(c, ch, pre);
+                    dsim_fk_walk_chunks<D, 0>(c, w, ch, n, pre);
                 }
                 own_type = ex.topo(lane).own_type;
                 own_ds = ex.topo(lane).own_ds;
