@@ -58,5 +58,8 @@ def test_bench_through_the_launcher_rccl_group_of_one():
     assert out.returncode == 0, out.stderr[-1500:]
     j = _json_line(out)
     assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1 and j["steps"] == 2
+    # the other BASELINE.json configurations ride along in the default single-GPU line
+    oc = {o["workload"].split()[0] + ("_mm1" if o["workload"].endswith("frequency 1") else ""): o for o in j["other_configs"]}
+    assert set(oc) == {"humanoid", "snu", "ant_mm1"} and all(o["value"] and o["value"] > 1e5 for o in oc.values()), oc
     assert j["config"]["submission_fallback"] is False
     assert j["value"] > 1e5 and j["roofline"]["traffic"] > j["roofline"]["alg_bytes_per_launch"]
