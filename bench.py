@@ -411,7 +411,7 @@ def main(argv=None):
             out["other_configs"] = [measure_other_config("humanoid", 1024, H, MM_FREQ["humanoid"], device),
                                     measure_other_config("snu", 512, H, MM_FREQ["snu"], device),
                                     measure_other_config("ant", n, H, 1, device)]
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # reported at N = 1 only (the host cores are the same for every N)
             out["cpu_baseline"] = cpu_baseline(a.env)
         print(json.dumps(out))
     if dist:
