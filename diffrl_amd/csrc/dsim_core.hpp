@@ -96,12 +96,15 @@ DSIM_FN float dsim_range_sum(const float* data, int stride, int comp, int first,
 template <class Ctx> struct DsimIsStatic {
     static constexpr bool value = std::is_empty<decltype(Ctx::d)>::value;
 };
+// The loads are unconditional and unclamped -- entry e is at a compile-time offset from the range's first element, so its
+// address costs no instruction -- and may therefore run past the end of the range (and of the array: the LDS image ends
+// with DSIM_TAIL_PAD spare words, dsim_layout.hpp); what they fetch there is discarded by the select.
 template <int B>
 DSIM_FN float dsim_range_sum_b(const float* data, int stride, int comp, int first, int count, float acc) {
-    const float* p = data + comp + stride * (count > 0 ? first : 0);
+    const float* p = data + comp + stride * first;
     float x[B];
 #pragma unroll
-    for (int e = 0; e < B; ++e) x[e] = p[stride * (e < count ? e : 0)];
+    for (int e = 0; e < B; ++e) x[e] = p[stride * e];
 #pragma unroll
     for (int e = 0; e < B; ++e) acc += (e < count) ? x[e] : 0.f;
     if (count > B) acc = dsim_range_sum(data, stride, comp, first + B, count - B, acc);

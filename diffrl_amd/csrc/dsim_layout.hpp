@@ -15,6 +15,7 @@
 #include "../../include/dsim.h"
 
 #define DSIM_PMASK_N 10
+#define DSIM_TAIL_PAD 384
 struct DsimDims {
     int L, nq, nd, C, M, W, NS, D;  // links, coords, dofs, contacts, muscles, waypoints, active muscle segments, tree levels
     int flags;                      // DSIM_F_*
@@ -314,6 +315,9 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.azs = take(6 * L);    // subtree sums of aw + awp
     o.ai10m = take(10 * L); o.aic10 = take(10 * (nd > L ? nd : L)); o.aH = take(nd * nd);
     o.gua = take(M > nd ? M : nd); o.agx = take(12 * L);  // per-body sums (models with muscles): pose wrench of muscles + contacts (6), twist cotangent of contacts (6)
+    // spare words behind the last array: the bounded range sums of the specialised kernels load a fixed number of entries
+    // from a range's first element without clamping (dsim_range_sum_b); the longest overrun is < 32 rows of 12 floats
+    cur += DSIM_TAIL_PAD;
     o.total_words = cur;
 
     out.o = o;

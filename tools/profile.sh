@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/prof_${TAG}_$ENVN
 RAW=/tmp/prof_raw_$ENVN
 mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --env $ENVN --envs-per-gpu $ENVS"
+CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --env $ENVN --envs-per-gpu $ENVS"
 echo "$CMD" > $OUT/command.txt
 python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(bench.csrc_hash())" > $OUT/csrc_hash.txt 2>/dev/null
 run() { timeout 240 rocprofv3 --output-format csv "$@" < /dev/null; }
