@@ -679,7 +679,10 @@ DSIM_FN float dsim_subtree_contact_sum(const Ctx& c, Exec& ex, int lane, int i, 
     float acc;
     if (dsim_contacts_per_body(c)) {   // contact terms are already inside the per-link data
         int n_known = -1;
-        if constexpr (DsimSixRegs<Ctx, Exec::NL>::value) n_known = ex.topo(lane).six_n;
+        if constexpr (DsimSixRegs<Ctx, Exec::NL>::value) {
+            n_known = ex.topo(lane).six_n;
+            DSIM_OPAQUE(n_known);
+        }
         return dsim_subtree_sum(c, ldata, 6, k, i, n_known);
     }
     if (c.d.flags & DSIM_F_RANGES) {
@@ -687,6 +690,8 @@ DSIM_FN float dsim_subtree_contact_sum(const Ctx& c, Exec& ex, int lane, int i, 
         if constexpr (DsimSixRegs<Ctx, Exec::NL>::value) {
             const DsimTopoRegs& tp = ex.topo(lane);
             li.nsub = tp.six_n; li.c0 = tp.six_c0; li.nc = tp.six_nc;
+            DSIM_OPAQUE(li.nsub);   // the per-entry "e < count" masks are recomputed here, not kept in (spilled) SGPR pairs
+            DSIM_OPAQUE(li.nc);
         } else {
             li = dsim_link_info(c, i);
         }
@@ -1577,7 +1582,10 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
         for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
             const int i = it / 6, k = it - 6 * i;
             int n_known = -1;
-            if constexpr (DsimSixRegs<Ctx, Exec::NL>::value) n_known = ex.topo(lane).six_n;
+            if constexpr (DsimSixRegs<Ctx, Exec::NL>::value) {
+                n_known = ex.topo(lane).six_n;
+                DSIM_OPAQUE(n_known);
+            }
             WF(aatot)[it] = dsim_subtree_sum(c, WF(aa), 6, k, i, n_known);
         }
         // per-body gather of the muscle pose wrenches (contact cotangents go straight into the subtree sums below)
