@@ -110,6 +110,22 @@ DSIM_FN float dsim_range_sum_b(const float* data, int stride, int comp, int firs
     if (count > B) acc = dsim_range_sum(data, stride, comp, first + B, count - B, acc);
     return acc;
 }
+// The same with a per-entry weight m[e] in {1.0f, 0.0f} instead of the comparison + select: x * 1 is exact and
+// acc + 0 leaves acc alone, so the result is that of dsim_range_sum_b (up to the sign of a zero) for one fused
+// multiply-add per entry instead of three instructions.  The weights are per-lane constants of the launch kept in
+// registers (DsimTopoRegs::lmask / cmask).  Entries past the end of the range must be FINITE for this to work: they are
+// other rows of the same array or, past its end, whatever array follows in the LDS image, which is why the kernels
+// clear the work area of the image once per launch (dsim_hip.hip: start_env).
+template <int B>
+DSIM_FN float dsim_range_sum_m(const float* data, int stride, int comp, int first, const float* m, float acc) {
+    const float* p = data + comp + stride * first;
+    float x[B];
+#pragma unroll
+    for (int e = 0; e < B; ++e) x[e] = p[stride * e];
+#pragma unroll
+    for (int e = 0; e < B; ++e) acc = __builtin_fmaf(x[e], m[e], acc);
+    return acc;
+}
 // Bounds: whole lists for small trees (each lane makes one pass over its items); 8 for larger models, where the lanes
 // loop over several items and loading a long mostly-unused tail per item costs more issue slots than it saves latency.
 template <class D> constexpr int dsim_cap_links() { return D::L <= 10 ? D::L : 8; }
@@ -192,6 +208,7 @@ struct DsimTopoRegs {
     int dof_link, dof_type, dof_cs, dof_ds;  // joint that dof `lane` belongs to
     int cbody_f, cbody_b;                    // body of contact `lane` / of contact `63 - lane`
     int six_n, six_c0, six_nc;               // link `lane / 6` (the (link, component) phases): subtree size, subtree contact range
+    float lmask[10], cmask[32];              // ... and the 1 / 0 weights of the entries of its two range sums (dsim_range_sum_m)
     int adof[16], adof_n;                    // dofs of the ancestors-or-self of link `(63 - lane) / 6` (adjoint of tau)
 };
 template <class Ctx> struct DsimChainRegs {
@@ -205,6 +222,13 @@ template <class Ctx, int NL> struct DsimSixRegs {
     static constexpr bool value = []() {
         if constexpr (std::is_empty<decltype(Ctx::d)>::value)
             return 6 * decltype(Ctx::d)::L <= NL && (decltype(Ctx::d)::flags & DSIM_F_RANGES) != 0;
+        else return false;
+    }();
+};
+// ... whose range sums cover the whole subtree / contact range with one bounded pass: weights instead of selects
+template <class Ctx, int NL> struct DsimSumMasks {
+    static constexpr bool value = []() {
+        if constexpr (DsimSixRegs<Ctx, NL>::value) return decltype(Ctx::d)::L <= 10 && decltype(Ctx::d)::C <= 32;
         else return false;
     }();
 };
@@ -292,13 +316,29 @@ template <class Ctx, class Exec> DSIM_FN void dsim_topo_init(const Ctx& c, Exec&
         tp.six_n = li.nsub;
         tp.six_c0 = li.c0;
         tp.six_nc = li.nc;
+        if constexpr (DsimSumMasks<Ctx, Exec::NL>::value) {
+#pragma unroll
+            for (int e = 0; e < decltype(c.d)::L; ++e) {
+                tp.lmask[e] = e < li.nsub ? 1.f : 0.f;
+                DSIM_OPAQUE(tp.lmask[e]);   // a register, not a comparison the compiler re-derives at every use
+            }
+#pragma unroll
+            for (int e = 0; e < (decltype(c.d)::C > 0 ? decltype(c.d)::C : 1); ++e) {
+                tp.cmask[e] = e < li.nc ? 1.f : 0.f;
+                DSIM_OPAQUE(tp.cmask[e]);
+            }
+        }
         if constexpr (DsimAdofRegs<Ctx, Exec::NL>::value) {
             const int it = Exec::NL - 1 - lane;
             const int j = it < 6 * c.d.L ? it / 6 : 0;
             const int e0 = CI(adof_start)[j], cnt = CI(adof_start)[j + 1] - e0;
             tp.adof_n = cnt;
 #pragma unroll
-            for (int u = 0; u < decltype(c.d)::nd; ++u) tp.adof[u] = CI(adof_list)[e0 + (u < cnt ? u : 0)];
+            // entries past the end of the list name the "zero dof" nd: atau[nd] is a spare word that stays 0 (dsim_layout.hpp)
+            for (int u = 0; u < decltype(c.d)::nd; ++u) {
+                const int dof = CI(adof_list)[e0 + (u < cnt ? u : 0)];
+                tp.adof[u] = u < cnt ? dof : (int)decltype(c.d)::nd;
+            }
         }
     }
 }
@@ -677,6 +717,15 @@ template <class Ctx, class Exec>
 DSIM_FN float dsim_subtree_contact_sum(const Ctx& c, Exec& ex, int lane, int i, const float* ldata, int k,
                                        const float* cdata, int cstride, int ck) {
     float acc;
+    if constexpr (DsimSumMasks<Ctx, Exec::NL>::value) {
+        using D = decltype(c.d);
+        const DsimTopoRegs& tp = ex.topo(lane);
+        acc = dsim_range_sum_m<D::L>(ldata, 6, k, i, tp.lmask, 0.f);
+        if (!dsim_contacts_per_body(c)) {
+            if constexpr (D::C > 0) acc = dsim_range_sum_m<D::C>(cdata, cstride, ck, tp.six_c0, tp.cmask, acc);
+        }
+        return acc;
+    }
     if (dsim_contacts_per_body(c)) {   // contact terms are already inside the per-link data
         int n_known = -1;
         if constexpr (DsimSixRegs<Ctx, Exec::NL>::value) {
@@ -1080,6 +1129,8 @@ DSIM_FN void dsim_sim_step_forward(const Ctx& c, Exec& ex, int substeps, int mm_
                                    const float* g_qd, const float* g_act, const float* g_mact, float* g_q_out,
                                    float* g_qd_out, float* g_ckpt) {
     const int nq = c.d.nq, nd = c.d.nd, M = c.d.M;
+    ex.begin_request();
+    ex.begin();
     dsim_init_static(c, ex);
     ex.run([&](int lane) {
         dsim_topo_init(c, ex, lane);
@@ -1285,7 +1336,10 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
                     tv[u] = WF(atau)[tp.adof[u]];
                 }
 #pragma unroll
-                for (int u = 0; u < B; ++u) acc -= (u < tp.adof_n) ? sv[u] * tv[u] : 0.f;
+                for (int u = 0; u < B; ++u) {
+                    const float term = sv[u] * tv[u];   // the zero dof contributes (finite S word) * 0
+                    acc -= term;
+                }
                 WF(af)[it] = acc;
                 continue;
             }
@@ -1586,7 +1640,10 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
                 n_known = ex.topo(lane).six_n;
                 DSIM_OPAQUE(n_known);
             }
-            WF(aatot)[it] = dsim_subtree_sum(c, WF(aa), 6, k, i, n_known);
+            if constexpr (DsimSumMasks<Ctx, Exec::NL>::value)
+                WF(aatot)[it] = dsim_range_sum_m<decltype(c.d)::L>(WF(aa), 6, k, i, ex.topo(lane).lmask, 0.f);
+            else
+                WF(aatot)[it] = dsim_subtree_sum(c, WF(aa), 6, k, i, n_known);
         }
         // per-body gather of the muscle pose wrenches (contact cotangents go straight into the subtree sums below)
         if (c.d.NS > 0)
@@ -1764,6 +1821,8 @@ DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
                                     const float* g_gqd_out, float* g_gq_in, float* g_gqd_in, float* g_gact,
                                     float* g_gmact) {
     const int nq = c.d.nq, nd = c.d.nd, M = c.d.M;
+    ex.begin_request();
+    ex.begin();
     dsim_init_static(c, ex);
     ex.run([&](int lane) {
         dsim_topo_init(c, ex, lane);
@@ -1882,24 +1941,76 @@ DSIM_FN void dsim_philox4(unsigned long long seed, unsigned e, unsigned n, unsig
 #define DSIM_EP_DONE 1.0f
 #define DSIM_EP_INVALID 3.0f  // finished because the state blew up: reward forced to 0 (humanoid.py:340-356)
 
+// ---- early loads -------------------------------------------------------------------------------------------------------
+// The prologue of a launch reads a handful of small rows from global memory (state, actions, action scales, cotangents).
+// Read where they are used, every one of them is a full memory latency on the critical path of a launch that lasts only
+// ~30 of them (measured: 17.5 k of the Ant adjoint's 245 k cycles, 5.5 k of the forward's 131 k).  The specialised kernels
+// therefore REQUEST them all first, into per-lane registers (Exec::io), then let the model constants arrive (Exec::begin),
+// and the prologue phases find their inputs in registers: one latency for everything.  Row lengths are compile-time
+// bounds there; the generic kernels (run-time sizes) read at the point of use as before.
+#define DSIM_IO_MAX 24
+template <class Ctx, class Exec> struct DsimIo {
+    static constexpr bool PRE = DsimIsStatic<Ctx>::value;
+    static constexpr int NL = Exec::NL;
+    static constexpr int dim(int which) {
+        if constexpr (DsimIsStatic<Ctx>::value) {
+            using D = decltype(Ctx::d);
+            return which == 0 ? D::nq : (which == 1 ? D::nd : (D::M > D::nd ? D::M : D::nd));
+        } else {
+            return 0;
+        }
+    }
+    static constexpr int cdiv(int a) { return (a + NL - 1) / NL; }
+    static constexpr int CQ = cdiv(dim(0)), CD = cdiv(dim(1)), CA = cdiv(dim(2)), CO = cdiv(16 + dim(0) + dim(1) + dim(2));
+    // register map (floats per lane)
+    static constexpr int Q = 0, QD = Q + CQ, GQ = QD + CD, GQD = GQ + CQ, ACT = GQD + CD, SCALE = ACT + CA, GOBS = SCALE + CA,
+                         GOBSB = GOBS + CO, GREW = GOBSB + CO, END = GREW + 1;
+    static_assert(!PRE || END <= DSIM_IO_MAX, "early-load registers: raise DSIM_IO_MAX");
+};
+// f(k, u) for this lane's entries k = lane + NL u < n of a row.  CAP > 0: compile-time trip count, so that u is a constant
+// after unrolling and io[... + u] a register (a run-time index would put the whole array into scratch memory);
+// CAP == 0 (generic kernels): the run-time loop, u unused.
+template <int CAP, int NL, class F> DSIM_FN void dsim_io_each(int n, int lane, F&& f) {
+    if constexpr (CAP > 0) {
+#pragma unroll
+        for (int u = 0; u < CAP; ++u) {
+            const int k = lane + NL * u;
+            if (k < n) f(k, u);
+        }
+    } else {
+        for (int k = lane; k < n; k += NL) f(k, 0);
+    }
+}
+// r[u] = g[lane + NL u] (0 where the row ends or g is null)
+template <int CAP, int NL> DSIM_FN void dsim_io_fetch(float* r, const float* g, int n, int lane) {
+#pragma unroll
+    for (int u = 0; u < CAP; ++u) {
+        const int k = lane + NL * u;
+        r[u] = (g && k < n) ? g[k] : 0.f;
+    }
+}
+
 // actions -> LDS: ua (what the env stores as self.actions), act / mact
 template <class Ctx, class Exec>
-DSIM_FN void dsim_env_load_actions(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, const float* g_actions) {
+DSIM_FN void dsim_env_load_actions(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, const float* g_actions, bool early = false) {
+    using IO = DsimIo<Ctx, Exec>;
     ex.run([&](int lane) {
         for (int k = lane; k < c.d.nd; k += Exec::NL) WF(act)[k] = 0.f;
     });
     ex.run([&](int lane) {
-        for (int k = lane; k < sp.n_act; k += Exec::NL) {
-            float a = g_actions[k];
+        const float* io = ex.io(lane);
+        auto one = [&](int k, float a, float sc) {
             a = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
             if (sp.act_muscle) {
                 a = a * 0.5f + 0.5f;
-                WF(mact)[k] = a * sp.act_scale[k];
+                WF(mact)[k] = a * sc;
             } else {
-                WF(act)[sp.act_offset + k] = a * sp.act_scale[k];
+                WF(act)[sp.act_offset + k] = a * sc;
             }
             WF(ua)[k] = a;
-        }
+        };
+        if (IO::PRE && early) dsim_io_each<IO::CA, Exec::NL>(sp.n_act, lane, [&](int k, int u) { one(k, io[IO::ACT + u], io[IO::SCALE + u]); });
+        else dsim_io_each<0, Exec::NL>(sp.n_act, lane, [&](int k, int) { one(k, g_actions[k], sp.act_scale[k]); });
     });
 }
 
@@ -2004,22 +2115,33 @@ DSIM_FN void dsim_env_observe(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, flo
 // obs/reward^T: adds into aqn/aqdn (cotangents of the step's output state) and writes gua (d/d stored action)
 template <class Ctx, class Exec>
 DSIM_FN void dsim_env_observe_adjoint(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, const float* g_gobs,
-                                      const float* g_grew, const float* g_gobs_before, float ep_flags) {
+                                      const float* g_grew, const float* g_gobs_before, float ep_flags, bool early = false) {
+    using IO = DsimIo<Ctx, Exec>;
     const int nq = c.d.nq, nd = c.d.nd;
     // q/qd in LDS hold the step's end state (before any reset), ua the stored actions.  Any cotangent pointer may be
     // null (= zeros).  An environment that was restarted by this step returned the observation of its NEW state as obs
     // (no dependence on this step) and the old one as obs_before_reset; an invalid state had its reward overwritten.
     const bool live = ep_flags == 0.f;
     ex.run([&](int lane) {
-        for (int k = lane; k < sp.n_obs; k += Exec::NL) {  // obs buffer reused for its cotangent
-            float g = (live && g_gobs) ? g_gobs[k] : 0.f;
-            if (g_gobs_before) g += g_gobs_before[k];
-            WF(obs)[k] = g;
-        }
+        const float* io = ex.io(lane);
+        // obs buffer reused for its cotangent
+        if (IO::PRE && early)
+            dsim_io_each<IO::CO, Exec::NL>(sp.n_obs, lane, [&](int k, int u) {
+                WF(obs)[k] = (live ? io[IO::GOBS + u] : 0.f) + io[IO::GOBSB + u];   // 0 where there is no such cotangent
+            });
+        else
+            dsim_io_each<0, Exec::NL>(sp.n_obs, lane, [&](int k, int) {
+                float g = (live && g_gobs) ? g_gobs[k] : 0.f;
+                if (g_gobs_before) g += g_gobs_before[k];
+                WF(obs)[k] = g;
+            });
     });
     ex.run([&](int lane) {
         const float *q = WF(q), *qd = WF(qd);
-        const float gr = (g_grew && ep_flags != DSIM_EP_INVALID) ? g_grew[0] : 0.f;
+        float gr_in;
+        if (IO::PRE && early) gr_in = ex.io(lane)[IO::GREW];
+        else gr_in = g_grew ? g_grew[0] : 0.f;
+        const float gr = ep_flags != DSIM_EP_INVALID ? gr_in : 0.f;
         float* go = WF(obs);
         if (sp.kind == DSIM_ENV_LOCOMOTION) {
             const int nj = nq - 7, njd = nd - 6, iu = 11 + nj + njd;
@@ -2116,17 +2238,30 @@ DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& s
                                     float* g_qd_out, float* g_obs, float* g_rew, float* g_ckpt, const DsimEpisode& ep,
                                     int e, int n_envs) {
     const int nq = c.d.nq, nd = c.d.nd;
-    // requested first: these global loads complete while the substeps run
+    using IO = DsimIo<Ctx, Exec>;
+    ex.begin_request();   // model constants first: memory returns loads in the order of their requests
+    if constexpr (IO::PRE) {
+        ex.fire([&](int lane) {   // early loads: requested now, used after the constants have arrived
+            float* io = ex.io(lane);
+            dsim_io_fetch<IO::CQ, Exec::NL>(io + IO::Q, g_q, nq, lane);
+            dsim_io_fetch<IO::CD, Exec::NL>(io + IO::QD, g_qd, nd, lane);
+            dsim_io_fetch<IO::CA, Exec::NL>(io + IO::ACT, g_actions, sp.n_act, lane);
+            dsim_io_fetch<IO::CA, Exec::NL>(io + IO::SCALE, sp.act_scale, sp.n_act, lane);
+        });
+    }
+    // requested last, needed last: these loads complete while the substeps run
     const long long p1 = ep.progress ? ep.progress[e] + 1 : 0;
     const int cnt = ep.progress ? ep.reset_count[e] : 0;
+    ex.begin();
     dsim_init_static(c, ex);
     ex.run([&](int lane) {
         dsim_topo_init(c, ex, lane);
-        for (int k = lane; k < nq; k += Exec::NL) WF(q)[k] = g_q[k];
-        for (int k = lane; k < nd; k += Exec::NL) WF(qd)[k] = g_qd[k];
+        const float* io = ex.io(lane);
+        dsim_io_each<IO::CQ, Exec::NL>(nq, lane, [&](int k, int u) { WF(q)[k] = IO::PRE ? io[IO::Q + u] : g_q[k]; });
+        dsim_io_each<IO::CD, Exec::NL>(nd, lane, [&](int k, int u) { WF(qd)[k] = IO::PRE ? io[IO::QD + u] : g_qd[k]; });
         if (lane == 0) WF(epf)[0] = 0.f;
     });
-    dsim_env_load_actions(c, ex, sp, g_actions);
+    dsim_env_load_actions(c, ex, sp, g_actions, true);
     for (int s = 0; s < substeps; ++s)
         dsim_fwd_substep(c, ex, (s % mm_freq) == 0, g_ckpt ? g_ckpt + (size_t)s * dsim_row(c) : nullptr,
                          g_ckpt ? dsim_ckpt_hinv(c, g_ckpt, substeps, s / mm_freq) : nullptr);
@@ -2251,9 +2386,29 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
                                      const float* g_gqd_out, const float* g_gobs, const float* g_grew,
                                      const float* g_gobs_before, float* g_gq_in, float* g_gqd_in, float* g_gactions) {
     const int nq = c.d.nq, nd = c.d.nd, M = c.d.M;
+    ex.begin_request();   // model constants first: memory returns loads in the order of their requests
     const float* tail = dsim_ckpt_tail(c, const_cast<float*>(g_ckpt), substeps, mm_freq);
     const float ep_flags = tail[nq + nd];
     const bool live = ep_flags == 0.f;  // not restarted by this step: the returned state is the end state
+    using IO = DsimIo<Ctx, Exec>;
+    if constexpr (IO::PRE) {
+        // early loads (requested before the flags above are looked at): end state, cotangents, actions, and the checkpoint
+        // row of the last substep, which the first adjoint substep would otherwise wait for on the spot
+        ex.fire([&](int lane) {
+            float* io = ex.io(lane);
+            dsim_io_fetch<IO::CQ, Exec::NL>(io + IO::Q, tail, nq, lane);
+            dsim_io_fetch<IO::CD, Exec::NL>(io + IO::QD, tail + nq, nd, lane);
+            dsim_io_fetch<IO::CQ, Exec::NL>(io + IO::GQ, g_gq_out, nq, lane);
+            dsim_io_fetch<IO::CD, Exec::NL>(io + IO::GQD, g_gqd_out, nd, lane);
+            dsim_io_fetch<IO::CA, Exec::NL>(io + IO::ACT, g_actions, sp.n_act, lane);
+            dsim_io_fetch<IO::CA, Exec::NL>(io + IO::SCALE, sp.act_scale, sp.n_act, lane);
+            dsim_io_fetch<IO::CO, Exec::NL>(io + IO::GOBS, g_gobs, sp.n_obs, lane);
+            dsim_io_fetch<IO::CO, Exec::NL>(io + IO::GOBSB, g_gobs_before, sp.n_obs, lane);
+            io[IO::GREW] = g_grew ? g_grew[0] : 0.f;
+        });
+        ex.prefetch(g_ckpt + (size_t)(substeps - 1) * dsim_row(c), dsim_row(c));
+    }
+    ex.begin();
     if (ep_flags == DSIM_EP_INVALID) {
         // The step ended in a non-finite / exploded state: its reward was overwritten and its successor state replaced, so
         // only obs_before_reset could carry a cotangent -- through intermediates that are inf / NaN.  The reference
@@ -2268,19 +2423,30 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
     dsim_init_static(c, ex);
     ex.run([&](int lane) {
         dsim_topo_init(c, ex, lane);
-        for (int k = lane; k < nq; k += Exec::NL) {
-            WF(q)[k] = tail[k];
-            WF(aqn)[k] = (live && g_gq_out) ? g_gq_out[k] : 0.f;
-        }
-        for (int k = lane; k < nd; k += Exec::NL) {
-            WF(qd)[k] = tail[nq + k];
-            WF(aqdn)[k] = (live && g_gqd_out) ? g_gqd_out[k] : 0.f;
+        const float* io = ex.io(lane);
+        dsim_io_each<IO::CQ, Exec::NL>(nq, lane, [&](int k, int u) {
+            if constexpr (IO::PRE) {
+                WF(q)[k] = io[IO::Q + u];
+                WF(aqn)[k] = live ? io[IO::GQ + u] : 0.f;
+            } else {
+                WF(q)[k] = tail[k];
+                WF(aqn)[k] = (live && g_gq_out) ? g_gq_out[k] : 0.f;
+            }
+        });
+        dsim_io_each<IO::CD, Exec::NL>(nd, lane, [&](int k, int u) {
+            if constexpr (IO::PRE) {
+                WF(qd)[k] = io[IO::QD + u];
+                WF(aqdn)[k] = live ? io[IO::GQD + u] : 0.f;
+            } else {
+                WF(qd)[k] = tail[nq + k];
+                WF(aqdn)[k] = (live && g_gqd_out) ? g_gqd_out[k] : 0.f;
+            }
             WF(aact)[k] = 0.f;
-        }
+        });
         for (int k = lane; k < M; k += Exec::NL) WF(amact)[k] = 0.f;
     });
-    dsim_env_load_actions(c, ex, sp, g_actions);
-    dsim_env_observe_adjoint(c, ex, sp, g_gobs, g_grew, g_gobs_before, ep_flags);
+    dsim_env_load_actions(c, ex, sp, g_actions, true);
+    dsim_env_observe_adjoint(c, ex, sp, g_gobs, g_grew, g_gobs_before, ep_flags, true);
     const int groups = (substeps + mm_freq - 1) / mm_freq;
     for (int g = groups - 1; g >= 0; --g) {
         const int s0 = g * mm_freq, s1 = (s0 + mm_freq < substeps) ? s0 + mm_freq : substeps;
@@ -2289,7 +2455,7 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
             // The row was requested one substep earlier (ex.prefetch keeps it in flight in registers while the
             // previous adjoint substep computes), so this phase only moves registers to LDS.
             const float* hv = (s == s1 - 1) ? dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, g) : nullptr;
-            if (s == substeps - 1) ex.prefetch(g_ckpt + (size_t)s * dsim_row(c), dsim_row(c));
+            if (!IO::PRE && s == substeps - 1) ex.prefetch(g_ckpt + (size_t)s * dsim_row(c), dsim_row(c));
             ex.run([&](int lane) {
                 ex.commit(WF(q), dsim_row(c), lane);
                 if (hv) {
@@ -2309,12 +2475,14 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
     ex.run([&](int lane) {
         for (int k = lane; k < nq; k += Exec::NL) g_gq_in[k] = WF(aqn)[k];
         for (int k = lane; k < nd; k += Exec::NL) g_gqd_in[k] = WF(aqdn)[k];
-        for (int k = lane; k < sp.n_act; k += Exec::NL) {
-            const float a = g_actions[k];
+        const float* io = ex.io(lane);
+        dsim_io_each<IO::CA, Exec::NL>(sp.n_act, lane, [&](int k, int u) {
+            const float a = IO::PRE ? io[IO::ACT + u] : g_actions[k];
+            const float sc = IO::PRE ? io[IO::SCALE + u] : sp.act_scale[k];
             float g = WF(gua)[k];
-            if (sp.act_muscle) g = 0.5f * (g + sp.act_scale[k] * WF(amact)[k]);
-            else g += sp.act_scale[k] * WF(aact)[sp.act_offset + k];
+            if (sp.act_muscle) g = 0.5f * (g + sc * WF(amact)[k]);
+            else g += sc * WF(aact)[sp.act_offset + k];
             g_gactions[k] = (a >= -1.0f && a <= 1.0f) ? g : 0.f;
-        }
+        });
     });
 }

@@ -30,12 +30,18 @@
 
 namespace {
 
-// The workgroup IS one wavefront (64 threads, enforced at launch): a phase boundary needs no s_barrier, only
-// (a) the compiler must not move / cache LDS accesses across it and (b) this wave's LDS operations must have
-// completed -- DS instructions of one wave execute in order, `s_waitcnt lgkmcnt(0)` + a memory clobber is the whole
-// synchronisation.  Unlike __syncthreads() this does NOT wait for outstanding global loads / stores (vmcnt), which is
-// what lets checkpoint traffic overlap with compute.
-__device__ __forceinline__ void dsim_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// The workgroup IS one wavefront (64 threads, enforced at launch): a phase boundary needs no s_barrier and no wait at all.
+// The DS instructions of one wave are executed by the LDS in issue order, so a load issued after a store observes it
+// whichever lanes are involved; the only requirement is that the COMPILER does not move or cache LDS accesses across the
+// boundary -- an empty asm with a memory clobber.  (Round 1 / early round 2 drained the queue with `s_waitcnt lgkmcnt(0)`
+// here: every phase then paid the latency of its last store before the next phase's loads could even be issued; without
+// it the results are bit-identical and Ant 1024 runs 1.7 % faster.  -DDSIM_WAVE_SYNC_ASM='"s_waitcnt lgkmcnt(0)"' builds
+// the draining variant for A/B runs.)  Global loads / stores (vmcnt) are never waited for here either, which is what
+// lets checkpoint traffic overlap with compute.
+#ifndef DSIM_WAVE_SYNC_ASM
+#define DSIM_WAVE_SYNC_ASM ""
+#endif
+__device__ __forceinline__ void dsim_wave_sync() { asm volatile(DSIM_WAVE_SYNC_ASM ::: "memory"); }
 
 template <int N, int NW> __device__ __forceinline__ void dsim_wave_gj(float* H) {
     const int lane = (int)threadIdx.x;
@@ -62,11 +68,53 @@ template <int N, int NW> __device__ __forceinline__ void dsim_wave_gj(float* H) 
     }
 }
 
-// NW wavefronts per environment (workgroup of 64 * NW lanes).  NW == 1: a phase boundary is the s_waitcnt above;
+// The LDS image of one environment: [model constants | work arrays].  load(): the constants are copied from global memory
+// (16 bytes per lane and load: const_words is a multiple of 4, both sides are 16-byte aligned) and the work area starts
+// out as zeros, not as what the previous workgroup on this CU left behind: the weighted range sums (dsim_core.hpp:
+// dsim_range_sum_m) multiply entries past the end of a range by 0, which needs them to be finite, and a few spare words
+// (the "zero dof" behind atau) are constants 0 that no phase ever writes.
+// request() / land(): the copy in two halves, so that the step functions can put their own early loads between them --
+// memory returns loads in the order they were issued: constants first (needed first), then the step's inputs.  CW is the
+// compile-time const_words of a specialised kernel (the constants wait in CW / 4 / lanes 16-byte registers) or 0 (generic
+// kernels: request() does nothing, land() copies).
+template <int NW, int CW> struct DsimImage {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    static constexpr int NLW = DSIM_NL * NW, REGS = (CW / 4 + NLW - 1) / NLW;
+    float* lds;
+    const uint32_t* cblob;
+    int const_words, image_words;   // image_words: forward kernels fwd_words, adjoint kernels total_words
+    v4f regs[REGS > 0 ? REGS : 1];
+    __device__ __forceinline__ void request() {
+        if constexpr (CW > 0) {
+            const v4f* g = reinterpret_cast<const v4f*>(cblob);
+#pragma unroll
+            for (int r = 0; r < REGS; ++r) {
+                const int i = (int)threadIdx.x + NLW * r;
+                if (i < CW / 4) regs[r] = g[i];
+            }
+        }
+    }
+    __device__ __forceinline__ void land() {
+        v4f* l = reinterpret_cast<v4f*>(lds);
+        if constexpr (CW > 0) {
+#pragma unroll
+            for (int r = 0; r < REGS; ++r) {
+                const int i = (int)threadIdx.x + NLW * r;
+                if (i < CW / 4) l[i] = regs[r];
+            }
+        } else {
+            const v4f* g = reinterpret_cast<const v4f*>(cblob);
+            for (int i = threadIdx.x; i < const_words / 4; i += NLW) l[i] = g[i];
+        }
+        for (int i = const_words / 4 + threadIdx.x; i < image_words / 4; i += NLW) l[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+};
+
+// NW wavefronts per environment (workgroup of 64 * NW lanes).  NW == 1: a phase boundary is the compiler fence above;
 // NW > 1: a workgroup barrier (phases whose item count exceeds 64 -- muscles, contacts, matrix entries of the bigger
 // models -- are spread over the waves, which sit on different SIMDs of the CU).
 // PF: 16-byte prefetch registers per lane for one checkpoint row (specialised kernels: exactly what the model's row needs)
-template <int NW, int PF = 6> struct DevExec {
+template <int NW, int PF = 6, int CW = 0> struct DevExec {
     static constexpr int NL = DSIM_NL * NW;
     static constexpr int DSIM_PF = PF;
     // Cross-lane primitives of the wavefront (one wave per environment only): the phase code uses them for the small
@@ -99,6 +147,15 @@ template <int NW, int PF = 6> struct DevExec {
         if constexpr (NW > 1) __syncthreads();
     }
     __device__ __forceinline__ void mark(int) {}
+    // begin(): the model constants arrive in LDS and the work area is cleared (see DsimImage).  The step functions call it
+    // AFTER they have requested their own inputs from global memory (dsim_core.hpp: early loads), so that the launch
+    // pays ONE memory latency for all of them instead of one per prologue phase.
+    DsimImage<NW, CW> img_;
+    __device__ __forceinline__ void begin_request() { img_.request(); }
+    __device__ __forceinline__ void begin() { img_.land(); sync(); }
+    // per-lane registers of the early loads
+    float io_[DSIM_IO_MAX];
+    __device__ __forceinline__ float* io(int) { return io_; }
     // Gauss-Jordan inverse of the N x N matrix at H (LDS, row-major), in place, by the first wavefront: lane i holds row i
     // in registers, the pivot row travels through v_readlane (dsim_core.hpp: dsim_fwd_mass has the formulas).
     template <int N> __device__ __forceinline__ void wave_gj(float* H) { dsim_wave_gj<N, NW>(H); sync(); }
@@ -150,6 +207,10 @@ template <class O, class D> struct KCommonT {
 
 // prefetch registers a model's checkpoint row needs (compile-time layouts), or the generic default of 6 (rows up to 1536 floats
 // at one wavefront per environment; longer rows are read at commit time)
+template <class O> constexpr int dsim_const_words() {
+    if constexpr (std::is_empty<O>::value) return O::const_words;
+    else return 0;
+}
 template <class O, int NW, bool LEAN> constexpr int dsim_pf_regs() {
     if constexpr (std::is_empty<O>::value) {
         constexpr int words = LEAN ? O::xsc - O::q : O::save_words;
@@ -158,13 +219,13 @@ template <class O, int NW, bool LEAN> constexpr int dsim_pf_regs() {
         return 6;
     }
 }
-template <int NW, bool LEAN, class O, class D> __device__ __forceinline__ DsimCtxT<O, D, LEAN> start_env(float* lds, const KCommonT<O, D>& k) {
-    // 16 bytes per lane and load (const_words is a multiple of 4, both sides are 16-byte aligned)
-    dsim_f4* l = reinterpret_cast<dsim_f4*>(lds);
-    const dsim_f4* g = reinterpret_cast<const dsim_f4*>(k.cblob);
-    for (int i = threadIdx.x; i < k.o.const_words / 4; i += DSIM_NL * NW) l[i] = g[i];
-    if constexpr (NW == 1) dsim_wave_sync();
-    else __syncthreads();
+// context of this workgroup's environment; the executor gets the image description and loads it in begin()
+template <bool LEAN, class Exec, class O, class D>
+__device__ __forceinline__ DsimCtxT<O, D, LEAN> start_env(float* lds, const KCommonT<O, D>& k, int image_words, Exec& ex) {
+    ex.img_.lds = lds;
+    ex.img_.cblob = k.cblob;
+    ex.img_.const_words = k.o.const_words;
+    ex.img_.image_words = image_words;
     DsimCtxT<O, D, LEAN> c;
     c.s = lds;
     c.o = k.o;
@@ -182,8 +243,8 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_fwd_kernel(KCommonT<O, D> k
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    auto c = start_env<NW, LEAN>(lds, k);
-    DevExec<NW, dsim_pf_regs<O, NW, LEAN>()> ex;
+    DevExec<NW, dsim_pf_regs<O, NW, LEAN>(), dsim_const_words<O>()> ex;
+    auto c = start_env<LEAN>(lds, k, k.o.fwd_words, ex);
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_sim_step_forward(c, ex, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, act + e * nd,
                           M ? mact + e * M : nullptr, q_out + e * nq, qd_out + e * nd,
@@ -200,8 +261,8 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_bwd_kernel(KCommonT<O, D> k
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    auto c = start_env<NW, LEAN>(lds, k);
-    DevExec<NW, dsim_pf_regs<O, NW, LEAN>()> ex;
+    DevExec<NW, dsim_pf_regs<O, NW, LEAN>(), dsim_const_words<O>()> ex;
+    auto c = start_env<LEAN>(lds, k, k.o.total_words, ex);
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_sim_step_backward(c, ex, k.substeps, k.mm_freq, ckpt + (size_t)e * k.ckpt_stride, act + e * nd,
                            M ? mact + e * M : nullptr, gq_out + e * nq, gqd_out + e * nd, gq_in + e * nq,
@@ -217,8 +278,8 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_fwd_kernel(KCommonT<O, 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    auto c = start_env<NW, LEAN>(lds, k);
-    DevExec<NW, dsim_pf_regs<O, NW, LEAN>()> ex;
+    DevExec<NW, dsim_pf_regs<O, NW, LEAN>(), dsim_const_words<O>()> ex;
+    auto c = start_env<LEAN>(lds, k, k.o.fwd_words, ex);
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_forward(c, ex, sp, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, actions + (size_t)e * sp.n_act,
                            q_out + e * nq, qd_out + e * nd, obs + (size_t)e * sp.n_obs, rew + e,
@@ -238,8 +299,8 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_bwd_kernel(KCommonT<O, 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    auto c = start_env<NW, LEAN>(lds, k);
-    DevExec<NW, dsim_pf_regs<O, NW, LEAN>()> ex;
+    DevExec<NW, dsim_pf_regs<O, NW, LEAN>(), dsim_const_words<O>()> ex;
+    auto c = start_env<LEAN>(lds, k, k.o.total_words, ex);
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_backward(c, ex, sp, k.substeps, k.mm_freq, ckpt + (size_t)e * k.ckpt_stride,
                             actions + (size_t)e * sp.n_act, gq_out ? gq_out + e * nq : nullptr,
@@ -282,6 +343,11 @@ template <int NW> struct TimingExec {
     long long* buf;
     int idx, cap;
     int tag = 0;
+    DsimImage<NW, 0> img_;
+    __device__ __forceinline__ void begin_request() {}
+    __device__ __forceinline__ void begin() { img_.land(); __syncthreads(); }
+    float io_[DSIM_IO_MAX];
+    __device__ __forceinline__ float* io(int) { return io_; }
     __device__ __forceinline__ void mark(int t) { tag = t * 100; }
     template <class F> __device__ __forceinline__ void run(F&& f) {
         f((int)threadIdx.x);
@@ -320,8 +386,8 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_timer_kernel(KCommonT<O, D>
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    auto c = start_env<NW, false>(lds, k);
     TimingExec<NW> ex{stamps, 1, cap};
+    auto c = start_env<false>(lds, k, k.o.total_words, ex);
     if (blockIdx.x == 0 && threadIdx.x == 0) stamps[0] = clock64();
     const size_t nq = k.d.nq, nd = k.d.nd;
     float* ck = ckpt + (size_t)e * k.ckpt_stride;

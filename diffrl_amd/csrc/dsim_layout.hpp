@@ -307,7 +307,7 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.aq = take(nq); o.aqd = take(nd);
     o.aqn = o.aq; o.aqdn = o.aqd;  // integrate^T turns the output cotangents into the input cotangents in place (per-link lanes)
     o.aact = take(nd); o.amact = take(M);
-    o.aqdd = take(nd); o.atau = take(nd); o.aS = take(6 * nd); o.af = take(6 * L);
+    o.aqdd = take(nd); o.atau = take(nd + 1);  /* + the "zero dof": a word that stays 0 (padding of the register-resident ancestor-dof lists) */ o.aS = take(6 * nd); o.af = take(6 * L);
     o.acx = take(12 * C);   // per contact: cotangent wrench of the body's pose (6) + cotangent of the body's twist (6)
     o.av = take(6 * L); o.aa = take(6 * L); o.aatot = take(6 * L); o.avtot = take(6 * L); o.avj = take(6 * L);
     o.aw = take(6 * L);     // pose cotangent of a link as a world-frame wrench (torque about the origin, force)

@@ -98,6 +98,10 @@ template <int NW> struct HostExecT {
         }
     }
     void mark(int) {}
+    void begin_request() {}
+    void begin() {}   // the host image is set up by make_ctx (constants copied, work area zero)
+    float io_[NL][DSIM_IO_MAX];   // early-load registers of the specialised kernels
+    float* io(int lane) { return io_[lane]; }
     float hacc_[NL][DSIM_HACC_MAX];  // what a lane keeps in registers across phases on the GPU
     float* hacc(int lane) { return hacc_[lane]; }
     DsimTopoRegs topo_[NL];

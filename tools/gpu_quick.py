@@ -12,6 +12,7 @@ CASES = [("ant", 1024), ("ant", 8192), ("humanoid", 1024), ("snu", 512), ("cartp
 if len(sys.argv) > 2:   # python tools/gpu_quick.py ant 64,256,512,1024,2048
     CASES = [(sys.argv[1], int(x)) for x in sys.argv[2].split(",")]
 for env, N in CASES:
+    torch.manual_seed(0)
     t = template_from_golden(env); g = golden(env + "_step")
     S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
     reps = N // g["q_in"].shape[0] + 1
@@ -35,4 +36,6 @@ for env, N in CASES:
         b = eng.backward(ck, a, m, dt, S, mm, gq, gqd)
     e2.record(); torch.cuda.synchronize()
     tf, tb = e0.elapsed_time(e1) / K, e1.elapsed_time(e2) / K
-    print("%-9s N=%5d S=%2d  fwd %.3f ms  bwd %.3f ms  -> %.3e env-steps/s (kernels only)" % (env, N, S, tf, tb, N / ((tf + tb) * 1e-3)))
+    import hashlib
+    hsh = hashlib.sha1(b"".join(x.detach().cpu().numpy().tobytes() for x in (qo, qdo) + tuple(y for y in b if y is not None))).hexdigest()[:10]
+    print("%-9s N=%5d S=%2d  fwd %.3f ms  bwd %.3f ms  -> %.3e env-steps/s (kernels only)  outputs sha1 %s" % (env, N, S, tf, tb, N / ((tf + tb) * 1e-3), hsh))

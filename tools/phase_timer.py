@@ -15,8 +15,9 @@ from emu_lib import env_spec_for
 from oracle_lib import golden, template_from_golden
 
 so = os.path.join(ROOT, "tools", "libdsim_timer.so")
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
-                       "-DDSIM_ENABLE_PHASE_TIMER", os.path.join(ROOT, "diffrl_amd", "csrc", "dsim_hip.hip"), "-o", so])
+if not os.environ.get("DSIM_TIMER_PREBUILT"):   # (the GPU box has no time to spare for a 2-minute compile: build it beforehand with tools/dev_build.sh timer all -DDSIM_ENABLE_PHASE_TIMER and copy it)
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+                           "-DDSIM_ENABLE_PHASE_TIMER", os.path.join(ROOT, "diffrl_amd", "csrc", "dsim_hip.hip"), "-o", so])
 L = C.CDLL(so)
 L.dsim_last_error.restype = C.c_char_p
 env = sys.argv[1] if len(sys.argv) > 1 else "ant"
