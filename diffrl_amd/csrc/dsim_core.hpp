@@ -196,6 +196,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_init_static(const Ctx& c, Exe
 // LDS tables once per launch (dsim_topo_init) instead of as an index -> record -> data chain of three dependent LDS round
 // trips per position in every substep.
 #define DSIM_CHAIN_MAX 10
+#define DSIM_TR_PASSES 2   // passes of the light items of a trunk-decomposed model over one wavefront
 // Per-lane topology records kept in REGISTERS by the specialised kernels (the executor owns one per lane).  A lane plays
 // the same roles in every substep -- link `lane`, dof `lane`, contact `lane` (forward) or `63 - lane` (adjoint) -- and the
 // index records of those roles never change, so they are read from the LDS tables once per launch (dsim_topo_init)
@@ -209,6 +210,11 @@ struct DsimTopoRegs {
     int cbody_f, cbody_b;                    // body of contact `lane` / of contact `63 - lane`
     int six_n, six_c0, six_nc;               // link `lane / 6` (the (link, component) phases): subtree size, subtree contact range
     float lmask[10], cmask[32];              // ... and the 1 / 0 weights of the entries of its two range sums (dsim_range_sum_m)
+    // trunk decomposition (DsimTrunk): the light (link, component) item of this lane in pass p -- row 6 i + k (-1: none), k,
+    // subtree size, subtree contact range; for the ancestor sums: row of the first light ancestor-or-self, row of the nearest
+    // trunk ancestor, bit e set <=> link top + e is an ancestor-or-self, first own dof (-1: none)
+    int tl_row[DSIM_TR_PASSES], tl_k[DSIM_TR_PASSES], tl_n[DSIM_TR_PASSES], tl_c0[DSIM_TR_PASSES], tl_nc[DSIM_TR_PASSES];
+    int ta_top[DSIM_TR_PASSES], ta_tp[DSIM_TR_PASSES], ta_m[DSIM_TR_PASSES], tu_d[DSIM_TR_PASSES];
     int adof[16], adof_n;                    // dofs of the ancestors-or-self of link `(63 - lane) / 6` (adjoint of tau)
 };
 template <class Ctx> struct DsimChainRegs {
@@ -230,6 +236,18 @@ template <class Ctx, int NL> struct DsimSumMasks {
     static constexpr bool value = []() {
         if constexpr (DsimSixRegs<Ctx, NL>::value) return decltype(Ctx::d)::L <= 10 && decltype(Ctx::d)::C <= 32;
         else return false;
+    }();
+};
+// Trunk decomposition of the subtree / ancestor sums (deep trees: dsim_layout.hpp DsimDims::NT): specialised kernels with one
+// wavefront per environment (the steps of a sum are ordered by the wavefront's in-order LDS queue, not by barriers)
+template <class Ctx, class Exec> struct DsimTrunk {
+    static constexpr bool value = []() {
+        if constexpr (std::is_empty<decltype(Ctx::d)>::value && Exec::WAVE_OPS) {
+            using D = decltype(Ctx::d);
+            return D::NT > 0 && 6 * D::NLT <= DSIM_TR_PASSES * Exec::NL;
+        } else {
+            return false;
+        }
     }();
 };
 template <class Ctx, int NL> struct DsimAdofRegs {  // ... and few enough dofs for the ancestor-dof list of an item to sit in registers
@@ -263,6 +281,40 @@ template <class Ctx, int NL> struct DsimContactsInKin {
     }();
 };
 template <class Ctx, class Exec> DSIM_FN void dsim_topo_init(const Ctx& c, Exec& ex, int lane) {
+    if constexpr (DsimTrunk<Ctx, Exec>::value) {
+        using D = decltype(c.d);
+        DsimTopoRegs& tp = ex.topo(lane);
+#pragma unroll
+        for (int p = 0; p < DSIM_TR_PASSES; ++p) {
+            const int item = lane + Exec::NL * p;
+            const bool on = item < 6 * D::NLT;
+            const int i = CI(light_list)[on ? item / 6 : 0], k = on ? item - 6 * (item / 6) : 0;
+            const DsimLinkInfo li = dsim_link_info(c, i);
+            tp.tl_row[p] = on ? 6 * i + k : -1;
+            tp.tl_k[p] = k;
+            tp.tl_n[p] = li.nsub;
+            tp.tl_c0[p] = li.c0;
+            tp.tl_nc[p] = li.nc;
+            // ancestors-or-self of i, root first: trunk links, then light ones
+            const int e0 = CI(anc_start)[i], e1 = CI(anc_start)[i + 1];
+            int top = i, tpl = 0, mask = 0;
+            for (int e = e0; e < e1; ++e) {
+                const int a = CI(anc_list)[e];
+                bool trunk = false;
+                for (int u = 0; u < D::NT; ++u) trunk = trunk || a == D::trunk[u];
+                if (trunk) tpl = a;
+                else if (a < top) top = a;
+            }
+            for (int e = e0; e < e1; ++e) {
+                const int a = CI(anc_list)[e];
+                if (a >= top) mask |= 1 << (a - top);
+            }
+            tp.ta_top[p] = 6 * top + k;
+            tp.ta_tp[p] = 6 * tpl + k;
+            tp.ta_m[p] = mask;
+            tp.tu_d[p] = (CI(qdstart)[i + 1] > CI(qdstart)[i]) ? CI(qdstart)[i] : -1;
+        }
+    }
     if constexpr (DsimChainRegs<Ctx>::value) {
         constexpr int DEPTH = decltype(c.d)::D;
         int* ch = ex.topo(lane).chain;
@@ -758,11 +810,68 @@ DSIM_FN float dsim_subtree_contact_sum(const Ctx& c, Exec& ex, int lane, int i, 
     return acc;
 }
 
+// Subtree sums of a per-link 6-vector array (+ per-contact rows) for ALL links of a trunk-decomposed model, inside one phase:
+//   light links   out[i] = rows [i, i + n_i) of ldata + contact rows [c0_i, c0_i + nc_i): one bounded pass, no remainder loops
+//                 (n_i <= LCAP, nc_i <= CCAP), DSIM_TR_PASSES items per lane;
+//   trunk links   deepest first, lanes 0..5: out[t] = ldata[t] + its own contact rows + out[children]; each step sees the
+//                 previous one through the wavefront's in-order LDS queue (Exec::lds_fence: a compiler fence on the GPU).
+// Replaces, for a 22-link humanoid, flat sums of up to 22 + 35 entries per item in three passes (of which the entries
+// past a cap of 8 ran in run-time loops of dependent loads).  cdata may be null (links only).
+template <class Ctx, class Exec>
+DSIM_FN void dsim_trunk_sum(const Ctx& c, Exec& ex, int lane, const float* ldata, const float* cdata, int cstride, int coff,
+                            float* out) {
+    using D = decltype(c.d);
+    const DsimTopoRegs& tp = ex.topo(lane);
+    constexpr int PASSES = (6 * D::NLT + Exec::NL - 1) / Exec::NL;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        int row = tp.tl_row[p], n = tp.tl_n[p], nc = tp.tl_nc[p];
+        DSIM_OPAQUE(n);    // the "e < n" masks are recomputed here, not kept as loop invariants in (spilled) SGPR pairs
+        DSIM_OPAQUE(nc);
+        const int r0 = row < 0 ? 0 : row;
+        float x[D::LCAP], y[D::CCAP > 0 ? D::CCAP : 1];
+#pragma unroll
+        for (int e = 0; e < D::LCAP; ++e) x[e] = ldata[r0 + 6 * e];
+        const float* cp = cdata ? cdata + cstride * tp.tl_c0[p] + coff + tp.tl_k[p] : nullptr;
+        if (cdata) {
+#pragma unroll
+            for (int e = 0; e < D::CCAP; ++e) y[e] = cp[cstride * e];
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < D::LCAP; ++e) acc += (e < n) ? x[e] : 0.f;
+        if (cdata) {
+#pragma unroll
+            for (int e = 0; e < D::CCAP; ++e) acc += (e < nc) ? y[e] : 0.f;
+        }
+        if (row >= 0) out[row] = acc;
+    }
+    ex.lds_fence();
+    dsim_static_for<0, D::NT>([&](auto uu) {
+        constexpr int u = D::NT - 1 - decltype(uu)::value, t = D::trunk[u];
+        if (lane < 6) {
+            float acc = ldata[6 * t + lane];
+            if (cdata) {
+#pragma unroll
+                for (int e = 0; e < D::tr_ncb[u]; ++e) acc += cdata[cstride * (D::tr_cb0[u] + e) + coff + lane];
+            }
+#pragma unroll
+            for (int e = 0; e < D::tr_nch[u]; ++e) acc += out[6 * D::tr_ch[DSIM_TRUNK_CH * u + e] + lane];
+            out[6 * t + lane] = acc;
+        }
+        ex.lds_fence();
+    });
+}
+
 // joint-space forces (sim.py:1421-1502, 1792-1842)
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_tau(const Ctx& c, Exec& ex) {
     ex.mark(3);
     // f_tot[i] = sum over subtree(i) of (inverse-dynamics force [+ muscle wrenches, gathered per body]) + contact wrenches
     ex.run([&](int lane) {
+        if constexpr (DsimTrunk<Ctx, Exec>::value) {
+            dsim_trunk_sum(c, ex, lane, WF(f), WF(cw), 6, 0, WF(ftot));
+            return;
+        }
         for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
             const int i = it / 6, k = it - 6 * i;
             WF(ftot)[it] = dsim_subtree_contact_sum(c, ex, lane, i, WF(f), k, WF(cw), 6, k);
@@ -1322,7 +1431,49 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
         // cotangent of body_f_s[j]: f_tot of every ancestor-or-self i of j contains f[j] and tau_d = -S_d . f_tot[link(d)], so
         // af[j] = -sum over the dofs d of all ancestors-or-self of j of S_d atau_d (same phase: reads only S and atau;
         // items are dealt from the top lane down so that they do not pile onto the lanes of the per-dof loop above)
-        for (int it = Exec::NL - 1 - lane; it < 6 * c.d.L; it += Exec::NL) {
+        if constexpr (DsimTrunk<Ctx, Exec>::value) {
+            // Trunk decomposition of the ancestor sums: u_j = sum over the own dofs of link j of S_d atau_d; a trunk link's
+            // prefix P_t = P_parent + u_t is evaluated by lanes 0..5 straight from S and atau (the trunk is a handful of
+            // links whose dofs are compile-time constants); a light link gets af_j = -(P of its nearest trunk ancestor +
+            // the u rows of its light ancestors-or-self), at most LCAP of them.  The u rows live in avtot, which is dead here.
+            using D = decltype(c.d);
+            const DsimTopoRegs& tp = ex.topo(lane);
+            constexpr int PASSES = (6 * D::NLT + Exec::NL - 1) / Exec::NL;
+            float* urow = WF(avtot);
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int row = tp.tl_row[p], d = tp.tu_d[p];
+                const int dd = d < 0 ? 0 : d;
+                const float sv = WF(S)[6 * dd + tp.tl_k[p]], tv = WF(atau)[dd];
+                if (row >= 0) urow[row] = d < 0 ? 0.f : sv * tv;
+            }
+            if (lane < 6) {
+                float P[D::NT];
+                dsim_static_for<0, D::NT>([&](auto uu) {
+                    constexpr int u = decltype(uu)::value;
+                    float acc = D::tr_par[u] >= 0 ? P[D::tr_par[u] >= 0 ? D::tr_par[u] : 0] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < D::tr_nd[u]; ++e) acc += WF(S)[6 * (D::tr_d0[u] + e) + lane] * WF(atau)[D::tr_d0[u] + e];
+                    P[u] = acc;
+                    WF(af)[6 * D::trunk[u] + lane] = 0.f - acc;
+                });
+            }
+            ex.lds_fence();
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int row = tp.tl_row[p], top = tp.ta_top[p];
+                int m = tp.ta_m[p];
+                DSIM_OPAQUE(m);
+                float x[D::LCAP];
+#pragma unroll
+                for (int e = 0; e < D::LCAP; ++e) x[e] = urow[top + 6 * e];
+                float acc = WF(af)[tp.ta_tp[p]];
+#pragma unroll
+                for (int e = 0; e < D::LCAP; ++e) acc -= ((m >> e) & 1) ? x[e] : 0.f;
+                if (row >= 0) WF(af)[row] = acc;
+            }
+        }
+        for (int it = Exec::NL - 1 - lane; it < (DsimTrunk<Ctx, Exec>::value ? 0 : 6 * c.d.L); it += Exec::NL) {
             const int j = it / 6, k = it - 6 * j;
             float acc = 0.f;
             if constexpr (DsimAdofRegs<Ctx, Exec::NL>::value) {
@@ -1633,7 +1784,8 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             const float g = WF(amact)[m];
             WF(amact)[m] = g + dsim_range_sum(WF(mus) + 12 * c.d.NS, 1, 0, s0, s1 - s0, 0.f);
         }
-        for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
+        if constexpr (DsimTrunk<Ctx, Exec>::value) dsim_trunk_sum(c, ex, lane, WF(aa), nullptr, 0, 0, WF(aatot));
+        for (int it = lane; it < (DsimTrunk<Ctx, Exec>::value ? 0 : 6 * c.d.L); it += Exec::NL) {
             const int i = it / 6, k = it - 6 * i;
             int n_known = -1;
             if constexpr (DsimSixRegs<Ctx, Exec::NL>::value) {
@@ -1696,6 +1848,10 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
         }
     });
     ex.run([&](int lane) {
+        if constexpr (DsimTrunk<Ctx, Exec>::value) {
+            dsim_trunk_sum(c, ex, lane, WF(av), WF(acx), 12, 6, WF(avtot));
+            return;
+        }
         for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
             const int i = it / 6, k = it - 6 * i;
             int n_known = -1;
@@ -1747,6 +1903,10 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
         }
     });
     ex.run([&](int lane) {
+        if constexpr (DsimTrunk<Ctx, Exec>::value) {
+            dsim_trunk_sum(c, ex, lane, WF(aw), WF(acx), 12, 0, WF(azs));
+            return;
+        }
         for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
             const int i = it / 6, k = it - 6 * i;
             int n_known = -1;

@@ -15,12 +15,26 @@
 #include "../../include/dsim.h"
 
 #define DSIM_PMASK_N 10
+#define DSIM_TRUNK_MAX 6
+#define DSIM_TRUNK_CH 4
+#define DSIM_LIGHT_CAP 8    // register budget of the light sums: LCAP, CCAP <= this
 #define DSIM_TAIL_PAD 384
 struct DsimDims {
     int L, nq, nd, C, M, W, NS, D;  // links, coords, dofs, contacts, muscles, waypoints, active muscle segments, tree levels
     int flags;                      // DSIM_F_*
     int tmask;                      // bit t set: some joint has type t
     int pmask[DSIM_PMASK_N];        // bit t set: some link has a joint of type t at position p of its ancestor chain (root = 0)
+    // Trunk decomposition of a deep tree (NT == 0: none; dsim_core.hpp: dsim_trunk_sum).  Links whose subtree is larger
+    // than LCAP form the "trunk" (an ancestor-closed set around the root); every other ("light") link has a subtree of
+    // at most LCAP links / CCAP contacts, summed flat in one bounded pass; a trunk link then adds its own row, its own
+    // contacts and the finished sums of its children, deepest trunk link first.
+    int NT, NLT, LCAP, CCAP;                       // trunk links, light links, caps of the light sums
+    int trunk[DSIM_TRUNK_MAX];                     // ascending (pre-order: parents first)
+    int tr_par[DSIM_TRUNK_MAX];                    // position of the parent in trunk[], -1 for the root
+    int tr_nch[DSIM_TRUNK_MAX];                    // number of children
+    int tr_ch[DSIM_TRUNK_MAX * DSIM_TRUNK_CH];     // their link indices
+    int tr_cb0[DSIM_TRUNK_MAX], tr_ncb[DSIM_TRUNK_MAX];  // the link's own contacts [cb0, cb0 + ncb)
+    int tr_d0[DSIM_TRUNK_MAX], tr_nd[DSIM_TRUNK_MAX];    // its own dofs [d0, d0 + nd)
 };
 #define DSIM_TM(t) (1 << (t))
 #define DSIM_F_RANGES 1  // subtree(i) == links [i, i+n_i) and its contacts == one contiguous contact range (pre-order numbering)
@@ -33,6 +47,7 @@ struct DsimOff {
     int adof_start, adof_list;  // dofs of all ancestors-or-self of link i
     int sub_start, sub_list;    // subtree of link i (self first, then descendants ascending)
     int child_start, child_list;
+    int light_list;             // links outside the trunk, ascending (trunk decomposition, DsimDims::NT > 0)
     int cb_start, cb_list;      // contacts of body i
     int scb_start, scb_list;    // contacts of all bodies in subtree(i) (ascending contact index)
     int rel;                    // [nd*nd] 0 unrelated, 1: link(b) in subtree(link(a)), 2: link(a) strictly below link(b)
@@ -191,6 +206,65 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     std::vector<int> scb_start(L + 1, 0), scb_list;
     flatten(scb, scb_start, scb_list);
 
+    // ---- trunk decomposition (deep pre-order trees without muscles; multi-dof joints only at the root)
+    DsimDims dd;
+    memset(&dd, 0, sizeof(dd));
+    for (int u = 0; u < DSIM_TRUNK_MAX; ++u) dd.trunk[u] = dd.tr_par[u] = -1;
+    std::vector<int> light_list;
+    {
+        bool pre = true, root_only = true;
+        for (int i = 0; i < L; ++i) {
+            for (size_t k = 0; k < sub[i].size(); ++k) pre = pre && sub[i][k] == i + (int)k;
+            for (size_t k = 0; k + 1 < scb[i].size(); ++k) pre = pre && scb[i][k + 1] == scb[i][k] + 1;
+            for (size_t k = 0; k + 1 < cb[i].size(); ++k) pre = pre && cb[i][k + 1] == cb[i][k] + 1;
+            if (i > 0 && m.joint_qd_start[i + 1] - m.joint_qd_start[i] > 1) root_only = false;
+            if (i > 0 && m.joint_parent[i] < 0) root_only = false;   // one tree
+        }
+        long best = -1;
+        int best_c = 0;
+        if (pre && root_only && L > 10 && M == 0) {
+            for (int cap = 1; cap <= DSIM_LIGHT_CAP; ++cap) {
+                int nt = 0, ccap = 0;
+                bool ok = true;
+                for (int i = 0; i < L; ++i) {
+                    if ((int)sub[i].size() > cap) {
+                        ++nt;
+                        if ((int)child[i].size() > DSIM_TRUNK_CH) ok = false;
+                    } else if ((int)scb[i].size() > ccap) {
+                        ccap = (int)scb[i].size();
+                    }
+                }
+                if (!ok || nt == 0 || nt > DSIM_TRUNK_MAX || ccap > DSIM_LIGHT_CAP) continue;
+                const int passes = (6 * (L - nt) + 63) / 64;
+                const long cost = (long)passes * (cap + ccap) * 14 + (long)nt * 150;   // ~cycles: issue slots of the light pass + one LDS round trip per trunk link
+                if (best < 0 || cost < best) { best = cost; best_c = cap; }
+            }
+        }
+        if (best >= 0) {
+            int nt = 0;
+            for (int i = 0; i < L; ++i) {
+                if ((int)sub[i].size() > best_c) {
+                    const int u = nt++;
+                    dd.trunk[u] = i;
+                    for (int v = 0; v < u; ++v)
+                        if (dd.trunk[v] == m.joint_parent[i]) dd.tr_par[u] = v;
+                    dd.tr_nch[u] = (int)child[i].size();
+                    for (size_t k = 0; k < child[i].size(); ++k) dd.tr_ch[DSIM_TRUNK_CH * u + k] = child[i][k];
+                    dd.tr_cb0[u] = cb[i].empty() ? 0 : cb[i][0];
+                    dd.tr_ncb[u] = (int)cb[i].size();
+                    dd.tr_d0[u] = m.joint_qd_start[i];
+                    dd.tr_nd[u] = m.joint_qd_start[i + 1] - m.joint_qd_start[i];
+                } else {
+                    light_list.push_back(i);
+                    if ((int)scb[i].size() > dd.CCAP) dd.CCAP = (int)scb[i].size();
+                }
+            }
+            dd.NT = nt;
+            dd.NLT = L - nt;
+            dd.LCAP = best_c;
+        }
+    }
+
     DsimOff o;
     memset(&o, 0, sizeof(o));
     std::vector<uint32_t>& blob = out.cblob;
@@ -239,6 +313,7 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.sub_list = put_i(sub_list.data(), sub_list.size());
     o.child_start = put_i(child_start.data(), L + 1);
     o.child_list = put_i(child_list.data(), child_list.size());
+    o.light_list = put_i(light_list.data(), light_list.size());
     o.cb_start = put_i(cb_start.data(), L + 1);
     o.cb_list = put_i(cb_list.data(), cb_list.size());
     o.scb_start = put_i(scb_start.data(), L + 1);
@@ -321,8 +396,6 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.total_words = cur;
 
     out.o = o;
-    DsimDims dd;
-    memset(&dd, 0, sizeof(dd));
     dd.L = L; dd.nq = nq; dd.nd = nd; dd.C = C; dd.M = M; dd.W = W; dd.NS = NS; dd.D = D;
     dd.flags = ranges ? DSIM_F_RANGES : 0;
     for (int i = 0; i < L; ++i) {

@@ -60,11 +60,19 @@ def layout(t):
     desc, keep = make_desc(t)
     names = _off_names()
     off = np.zeros(len(names) + 8, np.int32)
-    dims = np.zeros(24, np.int32)
+    dims = np.zeros(128, np.int32)
     n = layout_lib().dsim_emu_layout(C.byref(desc), _p(off), C.c_int(off.size), _p(dims))
     assert n == len(names), (n, len(names))
     d = dict(zip("L nq nd C M W NS D flags tmask".split(), dims.tolist()))
     d["pmask"] = dims[10:20].tolist()
+    # trunk decomposition (DsimDims behind pmask, struct order)
+    pos = 20
+    for name, cnt in [("NT", 0), ("NLT", 0), ("LCAP", 0), ("CCAP", 0), ("trunk", 6), ("tr_par", 6), ("tr_nch", 6), ("tr_ch", 24),
+                      ("tr_cb0", 6), ("tr_ncb", 6), ("tr_d0", 6), ("tr_nd", 6)]:
+        if cnt == 0:
+            d[name] = int(dims[pos]); pos += 1
+        else:
+            d[name] = dims[pos:pos + cnt].tolist(); pos += cnt
     return dict(zip(names, off[:n].tolist())), d
 
 
