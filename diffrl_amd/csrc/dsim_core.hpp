@@ -598,10 +598,13 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
     // level-synchronous form), then goes straight on to the world inertia and the body force from registers.
     // Nothing is stored before the end of the walk: LDS stores in between would serialise the next position's loads
     // behind them (the compiler cannot prove that they do not alias).
-    ex.run([&](int lane) {
+    // role 0: every walker; 1: link lanes only; 2: contact lanes only (the two blocks of the phase when there is a helper wave)
+    auto walk = [&](int lane, int role) {
         constexpr bool with_contacts = DsimContactsInKin<Ctx, Exec::NL>::value;
         const int n_walkers = with_contacts ? c.d.L + c.d.C : c.d.L;
         for (int i = lane; i < n_walkers; i += Exec::NL) {
+            if (role == 1 && i >= c.d.L) continue;
+            if (role == 2 && i < c.d.L) continue;
             DsimFkWalk w;
             w.psp = zero3();
             w.rsp = mkq(0.f, 0.f, 0.f, 1.f);
@@ -696,7 +699,11 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
                 stsv(S + 12, w.s2);
             }
         }
-    });
+    };
+    if constexpr (Exec::HAS_HELPER && DsimContactsInKin<Ctx, Exec::NL>::value)
+        ex.fork_join([&](int lane) { walk(lane, 1); }, [&](int lane) { walk(lane, 2); });
+    else
+        ex.run([&](int lane) { walk(lane, 0); });
 }
 
 // ground contacts (sim.py:1137-1206) and muscle segments (sim.py:1209-1242): per-item wrenches
@@ -1241,8 +1248,8 @@ DSIM_FN void dsim_sim_step_forward(const Ctx& c, Exec& ex, int substeps, int mm_
     ex.begin_request();
     ex.begin();
     dsim_init_static(c, ex);
+    ex.run_both([&](int lane) { dsim_topo_init(c, ex, lane); });   // every wave keeps its own topology records
     ex.run([&](int lane) {
-        dsim_topo_init(c, ex, lane);
         for (int k = lane; k < nq; k += Exec::NL) WF(q)[k] = g_q[k];
         for (int k = lane; k < nd; k += Exec::NL) {
             WF(qd)[k] = g_qd[k];
@@ -1372,30 +1379,9 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
             WF(atau)[i] = dsim_dot_n(WF(hinv) + i * nd, WF(aqdd), nd);  // hinv is symmetric
         }
     });
-    ex.run([&](int lane) {
-        bool in_regs = false;
-        if constexpr (DsimIsStatic<Ctx>::value) {
-            constexpr int NN = decltype(c.d)::nd * decltype(c.d)::nd, ACC = (NN + Exec::NL - 1) / Exec::NL;
-            if constexpr (ACC <= DSIM_HACC_MAX) {
-                in_regs = true;
-                float* acc = ex.hacc(lane);
-#pragma unroll
-                for (int m = 0; m < ACC; ++m) {
-                    const int it = lane + Exec::NL * m;
-                    if (it < NN) {
-                        const int i = it / decltype(c.d)::nd, j = it - decltype(c.d)::nd * i;
-                        acc[m] -= WF(atau)[i] * WF(qdd)[j];
-                        if (update_mass) WF(aH)[it] = acc[m];
-                    }
-                }
-            }
-        }
-        if (!in_regs) {
-            for (int it = lane; it < nd * nd; it += Exec::NL) {
-                const int i = it / nd, j = it - nd * i;
-                WF(aH)[it] -= WF(atau)[i] * WF(qdd)[j];
-            }
-        }
+    // Two blocks that touch disjoint LDS words: (main) the mass-matrix cotangent accumulators and af, (side) the per-dof
+    // cotangents of tau -- handed to the helper wavefront where there is one (Exec::fork_join)
+    auto tau_adjoint_per_dof = [&](int lane) {
         for (int d = lane; d < nd; d += Exec::NL) {
             int i, type, cs, ds;
             if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
@@ -1426,6 +1412,31 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
             } else if (ball) {
                 WF(aq)[qi] = g_q + (-tke) * at;
                 WF(aqd)[d] = g_qd + (-tkd) * at;
+            }
+        }
+    };
+    ex.fork_join([&](int lane) {
+        bool in_regs = false;
+        if constexpr (DsimIsStatic<Ctx>::value) {
+            constexpr int NN = decltype(c.d)::nd * decltype(c.d)::nd, ACC = (NN + Exec::NL - 1) / Exec::NL;
+            if constexpr (ACC <= DSIM_HACC_MAX) {
+                in_regs = true;
+                float* acc = ex.hacc(lane);
+#pragma unroll
+                for (int m = 0; m < ACC; ++m) {
+                    const int it = lane + Exec::NL * m;
+                    if (it < NN) {
+                        const int i = it / decltype(c.d)::nd, j = it - decltype(c.d)::nd * i;
+                        acc[m] -= WF(atau)[i] * WF(qdd)[j];
+                        if (update_mass) WF(aH)[it] = acc[m];
+                    }
+                }
+            }
+        }
+        if (!in_regs) {
+            for (int it = lane; it < nd * nd; it += Exec::NL) {
+                const int i = it / nd, j = it - nd * i;
+                WF(aH)[it] -= WF(atau)[i] * WF(qdd)[j];
             }
         }
         // cotangent of body_f_s[j]: f_tot of every ancestor-or-self i of j contains f[j] and tau_d = -S_d . f_tot[link(d)], so
@@ -1526,7 +1537,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
             for (; e < e1; ++e) acc -= WF(S)[6 * lst[e] + k] * WF(atau)[lst[e]];
             WF(af)[it] = acc;
         }
-    });
+    }, tau_adjoint_per_dof);
 }
 
 // contacts^T and muscles^T.  The cotangent with respect to the POSE of a body is kept as a world-frame wrench (torque
@@ -1750,7 +1761,9 @@ DSIM_FN sv6 inertia_pose_wrench(const inertia10& I, const float* g) {
 // "Quaternion radial component") is zero here.
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec& ex, bool update_mass) {
     ex.mark(10);
-    ex.run([&](int lane) {
+    // (main) per-link cotangents, (side) contacts^T / muscles^T per item: both only read af and forward quantities, and
+    // write disjoint arrays -- the side block goes to the helper wavefront where there is one
+    ex.fork_join([&](int lane) {
         for (int i = lane; i < c.d.L; i += Exec::NL) {
             const inertia10 I = ld_i10(WF(i10) + 10 * i);
             const sv6 v = ldsv(WF(v) + 6 * i), a = ldsv(WF(a) + 6 * i), r = ldsv(WF(af) + 6 * i);
@@ -1775,8 +1788,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             stsv(WF(av) + 6 * i, a_v);  // contact cotangents are added by the item-parallel gather below
             stsv(WF(aw) + 6 * i, W);
         }
-        dsim_bwd_external_items(c, ex, lane);
-    });
+    }, [&](int lane) { dsim_bwd_external_items(c, ex, lane); });
     ex.run([&](int lane) {
         for (int m = lane; m < c.d.M; m += Exec::NL) {
             // a muscle's active segments are consecutive rows of `mus`: batched range sum, not a serial chain of loads
@@ -1984,8 +1996,8 @@ DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
     ex.begin_request();
     ex.begin();
     dsim_init_static(c, ex);
+    ex.run_both([&](int lane) { dsim_topo_init(c, ex, lane); });   // every wave keeps its own topology records
     ex.run([&](int lane) {
-        dsim_topo_init(c, ex, lane);
         for (int k = lane; k < nq; k += Exec::NL) WF(aqn)[k] = g_gq_out[k];
         for (int k = lane; k < nd; k += Exec::NL) {
             WF(aqdn)[k] = g_gqd_out[k];
@@ -2414,8 +2426,8 @@ DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& s
     const int cnt = ep.progress ? ep.reset_count[e] : 0;
     ex.begin();
     dsim_init_static(c, ex);
+    ex.run_both([&](int lane) { dsim_topo_init(c, ex, lane); });   // every wave keeps its own topology records
     ex.run([&](int lane) {
-        dsim_topo_init(c, ex, lane);
         const float* io = ex.io(lane);
         dsim_io_each<IO::CQ, Exec::NL>(nq, lane, [&](int k, int u) { WF(q)[k] = IO::PRE ? io[IO::Q + u] : g_q[k]; });
         dsim_io_each<IO::CD, Exec::NL>(nd, lane, [&](int k, int u) { WF(qd)[k] = IO::PRE ? io[IO::QD + u] : g_qd[k]; });
@@ -2581,8 +2593,8 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
         return;
     }
     dsim_init_static(c, ex);
+    ex.run_both([&](int lane) { dsim_topo_init(c, ex, lane); });   // every wave keeps its own topology records
     ex.run([&](int lane) {
-        dsim_topo_init(c, ex, lane);
         const float* io = ex.io(lane);
         dsim_io_each<IO::CQ, Exec::NL>(nq, lane, [&](int k, int u) {
             if constexpr (IO::PRE) {

@@ -114,7 +114,23 @@ template <int NW, int CW> struct DsimImage {
 // NW > 1: a workgroup barrier (phases whose item count exceeds 64 -- muscles, contacts, matrix entries of the bigger
 // models -- are spread over the waves, which sit on different SIMDs of the CU).
 // PF: 16-byte prefetch registers per lane for one checkpoint row (specialised kernels: exactly what the model's row needs)
-template <int NW, int PF = 6, int CW = 0> struct DevExec {
+// HELPER: a second wavefront per environment that executes nothing but the side tasks the phase code hands it with
+// fork_join (contacts next to links in the kinematics, contacts^T next to the body-level cotangents, ...): those are
+// blocks of a phase that run on OTHER LANES WITH DIFFERENT CODE than the phase's main block, which a single wavefront
+// can only execute one after the other.  Unlike NW > 1 (every wave runs every phase on its share of the items) the
+// helper skips all ordinary phases, so it adds almost nothing to the issue load of the SIMD it shares with another
+// environment's main wave; a workgroup barrier of two waves costs ~30 cycles (measured), two per fork_join.
+template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
+    static_assert(!HELPER || NW == 1, "the helper wavefront belongs to the one-wave mapping");
+    static constexpr bool HAS_HELPER = HELPER;
+    const bool helper_ = HELPER && threadIdx.x >= DSIM_NL;
+    __device__ __forceinline__ int lane_() const { return HELPER ? (int)(threadIdx.x & (DSIM_NL - 1)) : (int)threadIdx.x; }
+    // both waves: LDS operations of this wave done, workgroup barrier (no wait for global memory)
+    __device__ __forceinline__ void group_barrier() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
     static constexpr int NL = DSIM_NL * NW;
     static constexpr int DSIM_PF = PF;
     // Cross-lane primitives of the wavefront (one wave per environment only): the phase code uses them for the small
@@ -136,14 +152,33 @@ template <int NW, int PF = 6, int CW = 0> struct DevExec {
         else __syncthreads();
     }
     template <class F> __device__ __forceinline__ void run(F&& f) {
-        f((int)threadIdx.x);
+        if (!helper_) f(lane_());
         sync();
+    }
+    // phase executed by the helper as well (register-only set-up such as the topology records: each wave keeps its own)
+    template <class F> __device__ __forceinline__ void run_both(F&& f) {
+        f(lane_());
+        sync();
+    }
+    // fm and fh are two blocks of one phase that touch disjoint LDS words.  With a helper: barrier (everything earlier is
+    // visible to both waves), main wave fm / helper wave fh, barrier.  Without: one after the other, as a single wave must.
+    template <class FM, class FH> __device__ __forceinline__ void fork_join(FM&& fm, FH&& fh) {
+        if constexpr (HELPER) {
+            group_barrier();
+            if (helper_) fh(lane_());
+            else fm(lane_());
+            group_barrier();
+        } else {
+            fm((int)threadIdx.x);
+            fh((int)threadIdx.x);
+            sync();
+        }
     }
     // phase that only writes global memory nobody in this launch reads back: no vmcnt wait.  One wave: no barrier either
     // (its LDS reads precede, in program order, whatever the next phase stores); several waves: the LDS words it reads
     // must not be overwritten by a wave that runs ahead, hence a barrier.
     template <class F> __device__ __forceinline__ void fire(F&& f) {
-        f((int)threadIdx.x);
+        if (!helper_) f(lane_());
         if constexpr (NW > 1) __syncthreads();
     }
     __device__ __forceinline__ void mark(int) {}
@@ -151,14 +186,23 @@ template <int NW, int PF = 6, int CW = 0> struct DevExec {
     // AFTER they have requested their own inputs from global memory (dsim_core.hpp: early loads), so that the launch
     // pays ONE memory latency for all of them instead of one per prologue phase.
     DsimImage<NW, CW> img_;
-    __device__ __forceinline__ void begin_request() { img_.request(); }
-    __device__ __forceinline__ void begin() { img_.land(); sync(); }
+    __device__ __forceinline__ void begin_request() {
+        if (!helper_) img_.request();
+    }
+    __device__ __forceinline__ void begin() {
+        if (!helper_) img_.land();
+        if constexpr (HELPER) group_barrier();
+        else sync();
+    }
     // per-lane registers of the early loads
     float io_[DSIM_IO_MAX];
     __device__ __forceinline__ float* io(int) { return io_; }
     // Gauss-Jordan inverse of the N x N matrix at H (LDS, row-major), in place, by the first wavefront: lane i holds row i
     // in registers, the pivot row travels through v_readlane (dsim_core.hpp: dsim_fwd_mass has the formulas).
-    template <int N> __device__ __forceinline__ void wave_gj(float* H) { dsim_wave_gj<N, NW>(H); sync(); }
+    template <int N> __device__ __forceinline__ void wave_gj(float* H) {
+        if (!helper_) dsim_wave_gj<N, NW>(H);
+        sync();
+    }
     // lane-private accumulators of the mass-matrix cotangent (dsim_core.hpp: DSIM_HACC_MAX registers per lane)
     float hacc_[DSIM_HACC_MAX];
     __device__ __forceinline__ float* hacc(int) { return hacc_; }
@@ -174,11 +218,11 @@ template <int NW, int PF = 6, int CW = 0> struct DevExec {
     const float* pf_src;
     __device__ __forceinline__ void prefetch(const float* row, int words) {
         pf_src = row;
-        if (words > 4 * NL * DSIM_PF) return;
+        if (helper_ || words > 4 * NL * DSIM_PF) return;
         const v4f* r4 = reinterpret_cast<const v4f*>(row);
 #pragma unroll
         for (int r = 0; r < DSIM_PF; ++r) {
-            const int k = (int)threadIdx.x + NL * r;
+            const int k = lane_() + NL * r;
             if (4 * k < words) pf[r] = r4[k];
         }
     }
@@ -207,6 +251,23 @@ template <class O, class D> struct KCommonT {
 
 // prefetch registers a model's checkpoint row needs (compile-time layouts), or the generic default of 6 (rows up to 1536 floats
 // at one wavefront per environment; longer rows are read at commit time)
+// models that get a helper wavefront: specialised one-wave kernels of models with ground contacts and without muscles
+template <class D, int NW> constexpr bool dsim_has_helper() {
+#ifdef DSIM_NO_HELPER
+    return false;
+#else
+    if constexpr (std::is_empty<D>::value) return NW == 1 && D::C > 0 && D::NS == 0 && D::L + D::C <= DSIM_NL;
+    else return false;
+#endif
+}
+// f(lean, help) with the two launch-time choices as compile-time constants.  `help` is false for models without helper
+// kernels, so they instantiate nothing extra.
+template <class D, int NW, class F> int dsim_with_flags(bool lean, bool help, F&& f) {
+    if constexpr (dsim_has_helper<D, NW>()) {
+        if (help) return lean ? f(std::true_type{}, std::true_type{}) : f(std::false_type{}, std::true_type{});
+    }
+    return lean ? f(std::true_type{}, std::false_type{}) : f(std::false_type{}, std::false_type{});
+}
 template <class O> constexpr int dsim_const_words() {
     if constexpr (std::is_empty<O>::value) return O::const_words;
     else return 0;
@@ -234,8 +295,8 @@ __device__ __forceinline__ DsimCtxT<O, D, LEAN> start_env(float* lds, const KCom
     return c;
 }
 
-template <class O, class D, int NW, bool LEAN>
-__global__ __launch_bounds__(DSIM_NL * NW) void dsim_fwd_kernel(KCommonT<O, D> k, const float* __restrict__ q_in,
+template <class O, class D, int NW, bool LEAN, bool HELP>
+__global__ __launch_bounds__((DSIM_NL * NW * (HELP ? 2 : 1))) void dsim_fwd_kernel(KCommonT<O, D> k, const float* __restrict__ q_in,
                                                            const float* __restrict__ qd_in,
                                                            const float* __restrict__ act,
                                                            const float* __restrict__ mact, float* q_out,
@@ -243,7 +304,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_fwd_kernel(KCommonT<O, D> k
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    DevExec<NW, dsim_pf_regs<O, NW, LEAN>(), dsim_const_words<O>()> ex;
+    DevExec<NW, dsim_pf_regs<O, NW, LEAN>(), dsim_const_words<O>(), HELP> ex;
     auto c = start_env<LEAN>(lds, k, k.o.fwd_words, ex);
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_sim_step_forward(c, ex, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, act + e * nd,
@@ -251,8 +312,8 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_fwd_kernel(KCommonT<O, D> k
                           ckpt ? ckpt + (size_t)e * k.ckpt_stride : nullptr);
 }
 
-template <class O, class D, int NW, bool LEAN>
-__global__ __launch_bounds__(DSIM_NL * NW) void dsim_bwd_kernel(KCommonT<O, D> k, const float* __restrict__ ckpt,
+template <class O, class D, int NW, bool LEAN, bool HELP>
+__global__ __launch_bounds__((DSIM_NL * NW * (HELP ? 2 : 1))) void dsim_bwd_kernel(KCommonT<O, D> k, const float* __restrict__ ckpt,
                                                            const float* __restrict__ act,
                                                            const float* __restrict__ mact,
                                                            const float* __restrict__ gq_out,
@@ -261,7 +322,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_bwd_kernel(KCommonT<O, D> k
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    DevExec<NW, dsim_pf_regs<O, NW, LEAN>(), dsim_const_words<O>()> ex;
+    DevExec<NW, dsim_pf_regs<O, NW, LEAN>(), dsim_const_words<O>(), HELP> ex;
     auto c = start_env<LEAN>(lds, k, k.o.total_words, ex);
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_sim_step_backward(c, ex, k.substeps, k.mm_freq, ckpt + (size_t)e * k.ckpt_stride, act + e * nd,
@@ -269,8 +330,8 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_bwd_kernel(KCommonT<O, D> k
                            gqd_in + e * nd, gact ? gact + e * nd : nullptr, (gmact && M) ? gmact + e * M : nullptr);
 }
 
-template <class O, class D, int NW, bool LEAN>
-__global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_fwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp, DsimEpisode ep,
+template <class O, class D, int NW, bool LEAN, bool HELP>
+__global__ __launch_bounds__((DSIM_NL * NW * (HELP ? 2 : 1))) void dsim_env_fwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp, DsimEpisode ep,
                                                                const float* __restrict__ q_in,
                                                                const float* __restrict__ qd_in,
                                                                const float* __restrict__ actions, float* q_out,
@@ -278,7 +339,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_fwd_kernel(KCommonT<O, 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    DevExec<NW, dsim_pf_regs<O, NW, LEAN>(), dsim_const_words<O>()> ex;
+    DevExec<NW, dsim_pf_regs<O, NW, LEAN>(), dsim_const_words<O>(), HELP> ex;
     auto c = start_env<LEAN>(lds, k, k.o.fwd_words, ex);
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_forward(c, ex, sp, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, actions + (size_t)e * sp.n_act,
@@ -286,8 +347,8 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_fwd_kernel(KCommonT<O, 
                            ckpt ? ckpt + (size_t)e * k.ckpt_stride : nullptr, ep, e, k.n_envs);
 }
 
-template <class O, class D, int NW, bool LEAN>
-__global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_bwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp,
+template <class O, class D, int NW, bool LEAN, bool HELP>
+__global__ __launch_bounds__((DSIM_NL * NW * (HELP ? 2 : 1))) void dsim_env_bwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp,
                                                                const float* __restrict__ ckpt,
                                                                const float* __restrict__ actions,
                                                                const float* __restrict__ gq_out,
@@ -299,7 +360,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_bwd_kernel(KCommonT<O, 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
-    DevExec<NW, dsim_pf_regs<O, NW, LEAN>(), dsim_const_words<O>()> ex;
+    DevExec<NW, dsim_pf_regs<O, NW, LEAN>(), dsim_const_words<O>(), HELP> ex;
     auto c = start_env<LEAN>(lds, k, k.o.total_words, ex);
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_backward(c, ex, sp, k.substeps, k.mm_freq, ckpt + (size_t)e * k.ckpt_stride,
@@ -343,6 +404,14 @@ template <int NW> struct TimingExec {
     long long* buf;
     int idx, cap;
     int tag = 0;
+    static constexpr bool HAS_HELPER = false;
+    template <class F> __device__ __forceinline__ void run_both(F&& f) { run(f); }
+    template <class FM, class FH> __device__ __forceinline__ void fork_join(FM&& fm, FH&& fh) {
+        run([&](int lane) {
+            fm(lane);
+            fh(lane);
+        });
+    }
     DsimImage<NW, 0> img_;
     __device__ __forceinline__ void begin_request() {}
     __device__ __forceinline__ void begin() { img_.land(); __syncthreads(); }
@@ -442,6 +511,11 @@ struct dsim_model {
     int waves = 1;   // wavefronts per environment: 1 or DSIM_WAVES_WIDE
     int lean = 0;    // checkpoint mode (dsim_model_set_ckpt_mode)
     int row_words() const { return lean ? lay.o.xsc - lay.o.q : lay.o.save_words; }
+    // Helper-wave kernels (DevExec<..., HELPER>) are used while every environment of the launch is resident at once: the
+    // helper takes a wave slot of its SIMD, so beyond that point (several rounds of workgroups) it would halve the
+    // number of environments in flight -- measured: Ant 8192 envs 13.4 M env-steps/s without, 8.1 M with.
+    int helper_max_envs = 0;
+    bool helper_ok(int n_envs) const { return n_envs <= helper_max_envs; }
 };
 #ifndef DSIM_WAVES_WIDE
 #define DSIM_WAVES_WIDE 4   // (-DDSIM_WAVES_WIDE=2 builds the A/B variant)
@@ -581,17 +655,24 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
             using O = decltype(o);
             using D = decltype(d);
             constexpr int NW = decltype(nw)::value;
-            const void* fns[] = {reinterpret_cast<const void*>(dsim_bwd_kernel<O, D, NW, false>),
-                                 reinterpret_cast<const void*>(dsim_env_bwd_kernel<O, D, NW, false>),
-                                 reinterpret_cast<const void*>(dsim_fwd_kernel<O, D, NW, false>),
-                                 reinterpret_cast<const void*>(dsim_env_fwd_kernel<O, D, NW, false>),
-                                 reinterpret_cast<const void*>(dsim_bwd_kernel<O, D, NW, true>),
-                                 reinterpret_cast<const void*>(dsim_env_bwd_kernel<O, D, NW, true>),
-                                 reinterpret_cast<const void*>(dsim_fwd_kernel<O, D, NW, true>),
-                                 reinterpret_cast<const void*>(dsim_env_fwd_kernel<O, D, NW, true>),
-                                 reinterpret_cast<const void*>(dsim_env_obs_kernel<O, D, NW>)};
-            for (const void* fn : fns)
-                if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            auto raise = [&](auto help_c) {
+                constexpr bool HELP = decltype(help_c)::value;
+                const void* fns[] = {reinterpret_cast<const void*>(dsim_bwd_kernel<O, D, NW, false, HELP>),
+                                     reinterpret_cast<const void*>(dsim_env_bwd_kernel<O, D, NW, false, HELP>),
+                                     reinterpret_cast<const void*>(dsim_fwd_kernel<O, D, NW, false, HELP>),
+                                     reinterpret_cast<const void*>(dsim_env_fwd_kernel<O, D, NW, false, HELP>),
+                                     reinterpret_cast<const void*>(dsim_bwd_kernel<O, D, NW, true, HELP>),
+                                     reinterpret_cast<const void*>(dsim_env_bwd_kernel<O, D, NW, true, HELP>),
+                                     reinterpret_cast<const void*>(dsim_fwd_kernel<O, D, NW, true, HELP>),
+                                     reinterpret_cast<const void*>(dsim_env_fwd_kernel<O, D, NW, true, HELP>)};
+                for (const void* fn : fns)
+                    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            };
+            raise(std::false_type{});
+            if constexpr (dsim_has_helper<D, NW>()) raise(std::true_type{});
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsim_env_obs_kernel<O, D, NW>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             return 0;
         });
     }
@@ -600,6 +681,23 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
         delete m;
         return hip_fail(e, "dsim_model_create");
     }
+    // helper-wave kernels: how many environments are resident at once (the adjoint kernel has the larger image and the
+    // most registers); DSIM_HELPER=0 / 1 forces the choice (A/B runs)
+    dispatch(m, [&](auto o, auto d, auto nw) {
+        using O = decltype(o);
+        using D = decltype(d);
+        constexpr int NW = decltype(nw)::value;
+        if constexpr (dsim_has_helper<D, NW>()) {
+            int dev = 0, cus = 0, per_cu = 0;
+            if (hipGetDevice(&dev) == hipSuccess &&
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dsim_env_bwd_kernel<O, D, NW, false, true>, 2 * DSIM_NL,
+                                                             (size_t)m->lay.o.total_words * 4) == hipSuccess)
+                m->helper_max_envs = cus * per_cu;
+            if (const char* f = getenv("DSIM_HELPER")) m->helper_max_envs = atoi(f) ? (1 << 30) : 0;
+        }
+        return 0;
+    });
     *out = m;
     return DSIM_OK;
 }
@@ -636,12 +734,12 @@ int dsim_step_forward(const dsim_model* m, int n_envs, const float* q_in, const 
     return dispatch(m, [&](auto o, auto d, auto nw) {
         constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        if (m->lean)
-            hipLaunchKernelGGL((dsim_fwd_kernel<decltype(o), decltype(d), NW, true>), dim3(n_envs), dim3(DSIM_NL * NW),
+        dsim_with_flags<decltype(d), NW>(m->lean, m->helper_ok(n_envs), [&](auto lean_c, auto help_c) {
+            constexpr bool LEAN = decltype(lean_c)::value, HELP = decltype(help_c)::value;
+            hipLaunchKernelGGL((dsim_fwd_kernel<decltype(o), decltype(d), NW, LEAN, HELP>), dim3(n_envs), dim3(DSIM_NL * NW * (HELP ? 2 : 1)),
                            (size_t)m->lay.o.fwd_words * 4, st, k, q_in, qd_in, act, muscle_act, q_out, qd_out, ckpt);
-        else
-            hipLaunchKernelGGL((dsim_fwd_kernel<decltype(o), decltype(d), NW, false>), dim3(n_envs), dim3(DSIM_NL * NW),
-                           (size_t)m->lay.o.fwd_words * 4, st, k, q_in, qd_in, act, muscle_act, q_out, qd_out, ckpt);
+            return 0;
+        });
         return launched("launch dsim_fwd_kernel");
     });
 }
@@ -658,14 +756,13 @@ int dsim_step_backward(const dsim_model* m, int n_envs, const float* ckpt, const
     return dispatch(m, [&](auto o, auto d, auto nw) {
         constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        if (m->lean)
-            hipLaunchKernelGGL((dsim_bwd_kernel<decltype(o), decltype(d), NW, true>), dim3(n_envs), dim3(DSIM_NL * NW),
+        dsim_with_flags<decltype(d), NW>(m->lean, m->helper_ok(n_envs), [&](auto lean_c, auto help_c) {
+            constexpr bool LEAN = decltype(lean_c)::value, HELP = decltype(help_c)::value;
+            hipLaunchKernelGGL((dsim_bwd_kernel<decltype(o), decltype(d), NW, LEAN, HELP>), dim3(n_envs), dim3(DSIM_NL * NW * (HELP ? 2 : 1)),
                            (size_t)m->lay.o.total_words * 4, st, k, ckpt, act, muscle_act, gq_out, gqd_out, gq_in, gqd_in,
                            gact, gmuscle_act);
-        else
-            hipLaunchKernelGGL((dsim_bwd_kernel<decltype(o), decltype(d), NW, false>), dim3(n_envs), dim3(DSIM_NL * NW),
-                           (size_t)m->lay.o.total_words * 4, st, k, ckpt, act, muscle_act, gq_out, gqd_out, gq_in, gqd_in,
-                           gact, gmuscle_act);
+            return 0;
+        });
         return launched("launch dsim_bwd_kernel");
     });
 }
@@ -705,14 +802,13 @@ int dsim_env_step_forward(const dsim_model* m, const dsim_env_spec* env, int n_e
     return dispatch(m, [&](auto o, auto d, auto nw) {
         constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        if (m->lean)
-            hipLaunchKernelGGL((dsim_env_fwd_kernel<decltype(o), decltype(d), NW, true>), dim3(n_envs), dim3(DSIM_NL * NW),
+        dsim_with_flags<decltype(d), NW>(m->lean, m->helper_ok(n_envs), [&](auto lean_c, auto help_c) {
+            constexpr bool LEAN = decltype(lean_c)::value, HELP = decltype(help_c)::value;
+            hipLaunchKernelGGL((dsim_env_fwd_kernel<decltype(o), decltype(d), NW, LEAN, HELP>), dim3(n_envs), dim3(DSIM_NL * NW * (HELP ? 2 : 1)),
                            (size_t)m->lay.o.fwd_words * 4, st, k, sp, ep, q_in, qd_in, actions, q_out, qd_out, obs, rew,
                            ckpt);
-        else
-            hipLaunchKernelGGL((dsim_env_fwd_kernel<decltype(o), decltype(d), NW, false>), dim3(n_envs), dim3(DSIM_NL * NW),
-                           (size_t)m->lay.o.fwd_words * 4, st, k, sp, ep, q_in, qd_in, actions, q_out, qd_out, obs, rew,
-                           ckpt);
+            return 0;
+        });
         return launched("launch dsim_env_fwd_kernel");
     });
 }
@@ -731,14 +827,13 @@ int dsim_env_step_backward(const dsim_model* m, const dsim_env_spec* env, int n_
     return dispatch(m, [&](auto o, auto d, auto nw) {
         constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        if (m->lean)
-            hipLaunchKernelGGL((dsim_env_bwd_kernel<decltype(o), decltype(d), NW, true>), dim3(n_envs), dim3(DSIM_NL * NW),
+        dsim_with_flags<decltype(d), NW>(m->lean, m->helper_ok(n_envs), [&](auto lean_c, auto help_c) {
+            constexpr bool LEAN = decltype(lean_c)::value, HELP = decltype(help_c)::value;
+            hipLaunchKernelGGL((dsim_env_bwd_kernel<decltype(o), decltype(d), NW, LEAN, HELP>), dim3(n_envs), dim3(DSIM_NL * NW * (HELP ? 2 : 1)),
                            (size_t)m->lay.o.total_words * 4, st, k, sp, ckpt, actions, gq_out, gqd_out, gobs, grew,
                            gobs_before_reset, gq_in, gqd_in, gactions);
-        else
-            hipLaunchKernelGGL((dsim_env_bwd_kernel<decltype(o), decltype(d), NW, false>), dim3(n_envs), dim3(DSIM_NL * NW),
-                           (size_t)m->lay.o.total_words * 4, st, k, sp, ckpt, actions, gq_out, gqd_out, gobs, grew,
-                           gobs_before_reset, gq_in, gqd_in, gactions);
+            return 0;
+        });
         return launched("launch dsim_env_bwd_kernel");
     });
 }

@@ -83,6 +83,16 @@ template <int NW> struct HostExecT {
     float bcast(float v, int src) { return shfl(v, src); }
     void lds_fence() { arrive(); }
     template <class F> void fire(F&& f) { run(f); }
+    // the helper wavefront of the device executor (dsim_hip.hip) does not exist here: both blocks of a split phase run in
+    // the one emulated wave, one after the other
+    static constexpr bool HAS_HELPER = false;
+    template <class F> void run_both(F&& f) { run(f); }
+    template <class FM, class FH> void fork_join(FM&& fm, FH&& fh) {
+        run([&](int lane) {
+            fm(lane);
+            fh(lane);
+        });
+    }
     // host form of the register / v_readlane Gauss-Jordan of the kernels (dsim_hip.hip: dsim_wave_gj): same formulas
     template <int N> void wave_gj(float* H) {
         for (int k = 0; k < N; ++k) {

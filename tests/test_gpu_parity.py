@@ -167,6 +167,42 @@ def test_specialised_kernels_match_generic(env, dev, monkeypatch):
         assert relerr(a[k], b[k]) < 1e-5, k
 
 
+@pytest.mark.parametrize("env", ["ant", "humanoid", "hopper", "cheetah"])
+def test_helper_wave_kernels_match_single_wave(env, dev, monkeypatch):
+    """Models with ground contacts run with a helper wavefront per environment while all environments of a launch are
+    resident (contacts / contacts^T / per-dof cotangents next to the main wave's blocks); beyond that, and under
+    DSIM_HELPER=0, the single-wave kernels run.  Same arithmetic in the same order: bit-identical results, operator level
+    and through the fused environment kernels."""
+    from diffrl_amd import envs as E
+    from diffrl_amd.engine import Engine
+    t = template_from_golden(env)
+    g = golden(env + "_step")
+    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DSIM_HELPER", mode)
+        eng = Engine(t, dev)
+        out[mode] = _run(eng, dev, g["q_in"], g["qd_in"], g["act_in"], g.get("muscle_act_in"), dt, S, mm, g["gq_out"], g["gqd_out"])
+    for k in ("q", "qd", "gq", "gqd", "gact", "ckpt"):
+        assert np.array_equal(out["1"][k], out["0"][k]), k
+    cls = {"ant": E.AntEnv, "humanoid": E.HumanoidEnv, "hopper": E.HopperEnv, "cheetah": E.CheetahEnv}[env]
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DSIM_HELPER", mode)
+        e = cls(num_envs=64, device="cuda:0", no_grad=False, stochastic_init=False)
+        e.initialize_trajectory()
+        torch.manual_seed(3)
+        a = torch.randn((4, 64, e.num_actions), device=dev).tanh().requires_grad_(True)
+        tot = 0.0
+        for s in range(4):
+            obs, rew, done, info = e.step(a[s])
+            tot = tot - rew.sum() + 0.01 * obs.sum()
+        tot.backward()
+        res[mode] = (obs.detach().cpu().numpy(), rew.detach().cpu().numpy(), a.grad.cpu().numpy())
+    for x, y in zip(res["1"], res["0"]):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("env", ["ant", "humanoid", "snu"])
 def test_lean_checkpoint_mode(env, dev):
     """DSIM_CKPT_LEAN (include/dsim.h): rows of (q, qd) only, the adjoint launch recomputes the forward phases -- identical
