@@ -599,7 +599,9 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
     // Nothing is stored before the end of the walk: LDS stores in between would serialise the next position's loads
     // behind them (the compiler cannot prove that they do not alias).
     // role 0: every walker; 1: link lanes only; 2: contact lanes only (the two blocks of the phase when there is a helper wave)
-    auto walk = [&](int lane, int role) {
+    // (always_inline: with two call sites the inliner may hesitate, and an out-of-line call of a lambda that captures the
+    // phase's state by reference would go through scratch memory)
+    auto walk = [&](int lane, int role) __attribute__((always_inline)) {
         constexpr bool with_contacts = DsimContactsInKin<Ctx, Exec::NL>::value;
         const int n_walkers = with_contacts ? c.d.L + c.d.C : c.d.L;
         for (int i = lane; i < n_walkers; i += Exec::NL) {
@@ -1381,7 +1383,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
     });
     // Two blocks that touch disjoint LDS words: (main) the mass-matrix cotangent accumulators and af, (side) the per-dof
     // cotangents of tau -- handed to the helper wavefront where there is one (Exec::fork_join)
-    auto tau_adjoint_per_dof = [&](int lane) {
+    auto tau_adjoint_per_dof = [&](int lane) __attribute__((always_inline)) {
         for (int d = lane; d < nd; d += Exec::NL) {
             int i, type, cs, ds;
             if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {

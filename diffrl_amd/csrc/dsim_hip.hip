@@ -517,6 +517,7 @@ struct dsim_model {
     int helper_max_envs = 0;
     bool helper_ok(int n_envs) const { return n_envs <= helper_max_envs; }
 };
+void dsim_helper_capacity(dsim_model* m);
 #ifndef DSIM_WAVES_WIDE
 #define DSIM_WAVES_WIDE 4   // (-DDSIM_WAVES_WIDE=2 builds the A/B variant)
 #endif
@@ -681,26 +682,47 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
         delete m;
         return hip_fail(e, "dsim_model_create");
     }
-    // helper-wave kernels: how many environments are resident at once (the adjoint kernel has the larger image and the
-    // most registers); DSIM_HELPER=0 / 1 forces the choice (A/B runs)
+    dsim_helper_capacity(m);
+    *out = m;
+    return DSIM_OK;
+}
+
+}  // extern "C"
+
+// helper-wave kernels: how many environments are resident at once (the smallest figure over the model's kernels in the
+// current checkpoint mode); DSIM_HELPER=0 / 1 forces the choice (A/B runs)
+void dsim_helper_capacity(dsim_model* m) {
     dispatch(m, [&](auto o, auto d, auto nw) {
         using O = decltype(o);
         using D = decltype(d);
         constexpr int NW = decltype(nw)::value;
         if constexpr (dsim_has_helper<D, NW>()) {
-            int dev = 0, cus = 0, per_cu = 0;
-            if (hipGetDevice(&dev) == hipSuccess &&
-                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dsim_env_bwd_kernel<O, D, NW, false, true>, 2 * DSIM_NL,
-                                                             (size_t)m->lay.o.total_words * 4) == hipSuccess)
-                m->helper_max_envs = cus * per_cu;
+            int dev = 0, cus = 0, per_cu = 1 << 20;
+            bool ok = hipGetDevice(&dev) == hipSuccess &&
+                      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess;
+            auto cap = [&](auto kernel, int words) {   // resident workgroups per CU of one helper kernel
+                int n = 0;
+                ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 2 * DSIM_NL, (size_t)words * 4) == hipSuccess;
+                if (n < per_cu) per_cu = n;
+            };
+            cap(dsim_env_bwd_kernel<O, D, NW, false, true>, m->lay.o.total_words);
+            cap(dsim_env_fwd_kernel<O, D, NW, false, true>, m->lay.o.fwd_words);
+            cap(dsim_bwd_kernel<O, D, NW, false, true>, m->lay.o.total_words);
+            cap(dsim_fwd_kernel<O, D, NW, false, true>, m->lay.o.fwd_words);
+            if (m->lean) {   // (the mode is chosen right after creation; dsim_model_set_ckpt_mode re-evaluates)
+                cap(dsim_env_bwd_kernel<O, D, NW, true, true>, m->lay.o.total_words);
+                cap(dsim_env_fwd_kernel<O, D, NW, true, true>, m->lay.o.fwd_words);
+                cap(dsim_bwd_kernel<O, D, NW, true, true>, m->lay.o.total_words);
+                cap(dsim_fwd_kernel<O, D, NW, true, true>, m->lay.o.fwd_words);
+            }
+            m->helper_max_envs = ok ? cus * per_cu : 0;
             if (const char* f = getenv("DSIM_HELPER")) m->helper_max_envs = atoi(f) ? (1 << 30) : 0;
         }
         return 0;
     });
-    *out = m;
-    return DSIM_OK;
 }
+
+extern "C" {
 
 int dsim_model_destroy(dsim_model* m) {
     if (!m) return DSIM_OK;
@@ -720,6 +742,7 @@ int dsim_model_set_ckpt_mode(dsim_model* m, int mode) {
     if (!m) return fail(DSIM_ERR_INVALID, "null model");
     if (mode != DSIM_CKPT_FULL && mode != DSIM_CKPT_LEAN) return fail(DSIM_ERR_INVALID, "unknown checkpoint mode");
     m->lean = mode == DSIM_CKPT_LEAN;
+    dsim_helper_capacity(m);
     return DSIM_OK;
 }
 

@@ -1,0 +1,44 @@
+"""CPU-only: the code object inside the built libdsim_hip.so meets the design's resource constraints (read from the kernel
+metadata with the LLVM tools of the ROCm image; no GPU needed).
+
+* no kernel uses scratch memory: a phase state that lands in scratch (a struct select, an out-of-line lambda, a
+  run-time-indexed register array -- all three happened during development) costs 50-200 % of a launch, silently;
+* the helper-wave kernels stay within 256 architectural VGPRs: the helper shares its SIMD with another environment's
+  main wave, which needs two resident waves per SIMD."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+LIB = os.path.join(ROOT, "diffrl_amd", "csrc", "libdsim_hip.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    if not os.path.exists(LIB):
+        pytest.skip("library not built (python __graft_entry__.py)")
+    if not all(os.path.exists(os.path.join(LLVM, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
+        pytest.skip("LLVM binutils of the ROCm image not found")
+    from kernel_meta import kernels as read
+    ks = [k for k in read(LIB) if "dsim_" in k["name"]]
+    assert len(ks) >= 40, "expected the full set of kernel variants in the library"
+    return ks
+
+
+def test_no_kernel_uses_scratch_memory(kernels):
+    bad = [(k["name"][:90], k["private_segment_fixed_size"]) for k in kernels if k.get("private_segment_fixed_size", 0) != 0]
+    assert not bad, bad
+    assert all(k.get("vgpr_spill_count", 0) == 0 for k in kernels)
+
+
+def test_helper_kernels_fit_two_waves_per_simd(kernels):
+    from kernel_meta import short
+    helpers = [k for k in kernels if k.get("max_flat_workgroup_size") == 128]
+    assert helpers, "helper-wave kernels (workgroups of two wavefronts) are part of the library"
+    # full checkpoint mode (the default); the lean adjoint carries the forward phases as well and may exceed it --
+    # dsim_model_create then finds fewer resident workgroups and the launches fall back to the single-wave kernels
+    over = [(short(k["name"]), k["vgpr_count"]) for k in helpers if k["vgpr_count"] + k.get("agpr_count", 0) > 256 and ", lean" not in short(k["name"])]
+    assert not over, over
