@@ -708,6 +708,13 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
         ex.run([&](int lane) { walk(lane, 0); });
 }
 
+// mpart[e][k] = sum of component k over the muscle wrench rows of chunk e (forward: wrenches; adjoint: pose cotangents)
+template <class Ctx> DSIM_FN void dsim_muscle_chunk_sums(const Ctx& c, int lane, int nl) {
+    for (int it = lane; it < 6 * c.d.MK; it += nl) {
+        const int e = it / 6, k = it - 6 * e;
+        WF(mpart)[it] = dsim_range_sum(WF(mus), 6, k, CI(mc_row)[e], CI(mc_cnt)[e], 0.f);
+    }
+}
 // ground contacts (sim.py:1137-1206) and muscle segments (sim.py:1209-1242): per-item wrenches
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Exec& ex) {
     ex.mark(2);
@@ -745,11 +752,13 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Ex
         }
     });
     if (c.d.NS > 0) {
+        // per-body gather of the muscle wrench rows in two steps (dsim_layout.hpp: mc_row): chunk sums, one lane and one LDS
+        // round trip per chunk and component, then per body the sums of its chunks + its contact wrenches
+        ex.run([&](int lane) { dsim_muscle_chunk_sums(c, lane, Exec::NL); });
         ex.run([&](int lane) {
             for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
                 const int i = it / 6, k = it - 6 * i;
-                const int e0 = CI(ml_start)[i];
-                float acc = dsim_range_sum(WF(mus), 6, k, e0, CI(ml_start)[i + 1] - e0, WF(f)[it]);
+                float acc = dsim_range_sum(WF(mpart), 6, k, CI(mb_start)[i], CI(mb_start)[i + 1] - CI(mb_start)[i], WF(f)[it]);
                 acc = dsim_body_contact_sum(c, i, WF(cw), 6, k, acc);   // + the body's own contact wrenches
                 WF(f)[it] = acc;
             }
@@ -1811,20 +1820,22 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             else
                 WF(aatot)[it] = dsim_subtree_sum(c, WF(aa), 6, k, i, n_known);
         }
-        // per-body gather of the muscle pose wrenches (contact cotangents go straight into the subtree sums below)
-        if (c.d.NS > 0)
+        // per-body gather of the muscle pose wrenches, first step: chunk sums (contact cotangents of models without muscles
+        // go straight into the subtree sums below)
+        if (c.d.NS > 0) dsim_muscle_chunk_sums(c, lane, Exec::NL);
+    });
+    if (c.d.NS > 0) {
+        ex.run([&](int lane) {
             for (int it = lane; it < 12 * c.d.L; it += Exec::NL) {
                 const int i = it / 12, r = it - 12 * i;
-                // r < 6: pose wrench of the body = its muscle rows (consecutive, seg_slot) + its contacts; r >= 6: the twist
-                // cotangent of its contacts
+                // r < 6: pose wrench of the body = its muscle rows (chunk sums) + its contacts; r >= 6: the twist cotangent of
+                // its contacts
                 float acc = 0.f;
-                if (r < 6) {
-                    const int e0 = CI(ml_start)[i];
-                    acc = dsim_range_sum(WF(mus), 6, r, e0, CI(ml_start)[i + 1] - e0, 0.f);
-                }
+                if (r < 6) acc = dsim_range_sum(WF(mpart), 6, r, CI(mb_start)[i], CI(mb_start)[i + 1] - CI(mb_start)[i], 0.f);
                 WF(agx)[it] = dsim_body_contact_sum(c, i, WF(acx), 12, r, acc);
             }
-    });
+        });
+    }
     ex.run([&](int lane) {
         constexpr int MASK = dsim_tmask_static<Ctx>();
         for (int i = lane; i < c.d.L; i += Exec::NL) {

@@ -18,6 +18,7 @@
 #define DSIM_TRUNK_MAX 6
 #define DSIM_TRUNK_CH 4
 #define DSIM_LIGHT_CAP 8    // register budget of the light sums: LCAP, CCAP <= this
+#define DSIM_MUSCLE_CHUNK 12
 #define DSIM_TAIL_PAD 384
 struct DsimDims {
     int L, nq, nd, C, M, W, NS, D;  // links, coords, dofs, contacts, muscles, waypoints, active muscle segments, tree levels
@@ -35,6 +36,7 @@ struct DsimDims {
     int tr_ch[DSIM_TRUNK_MAX * DSIM_TRUNK_CH];     // their link indices
     int tr_cb0[DSIM_TRUNK_MAX], tr_ncb[DSIM_TRUNK_MAX];  // the link's own contacts [cb0, cb0 + ncb)
     int tr_d0[DSIM_TRUNK_MAX], tr_nd[DSIM_TRUNK_MAX];    // its own dofs [d0, d0 + nd)
+    int MK;                                        // chunks of the per-body muscle-row gather (DsimOff::mc_row)
 };
 #define DSIM_TM(t) (1 << (t))
 #define DSIM_F_RANGES 1  // subtree(i) == links [i, i+n_i) and its contacts == one contiguous contact range (pre-order numbering)
@@ -56,6 +58,10 @@ struct DsimOff {
     int ml_start, ml_list;      // link -> list of (segment*2 + side)
     int seg_slot;               // [2*NS] (segment, side) -> position in ml_list: wrench rows are kept sorted by body
     int ms_start;               // muscle -> [first, last) active segment
+    // The muscle wrench rows of a body (consecutive, seg_slot) are gathered in two steps: chunks of at most DSIM_MUSCLE_CHUNK
+    // rows are summed by one lane each (one LDS round trip), then the chunk sums of a body -- a body with 86 rows was 11
+    // dependent round trips of one lane.  mc_row / mc_cnt: first row and row count of chunk e; mb_start: body -> its chunks.
+    int mc_row, mc_cnt, mb_start;
     int mlinks;
     // ---- constant block: floats
     int xpj, com, axis, ic6, mass, tke, tkd, lke, lkd, target, lower, upper, arm;
@@ -63,6 +69,7 @@ struct DsimOff {
     int const_words;
     // ---- forward work arrays (floats)
     int q, qd, act, mact, ua, obs, xsc, S, v, a, i10, f, ftot, cw, tau, qdd, ic10, F, hinv, prow, pcol, mus;
+    int mpart;                  // [MK][6] chunk sums of the muscle-row gather
     int epf;                    // episode flags (fused env surface): [0] invalid state seen, [1] episode finished
     int save_words;             // length of the saved block that starts at q (see dsim_build_layout)
     int fwd_words;
@@ -328,6 +335,19 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     for (size_t e = 0; e < ml_list.size(); ++e) seg_slot[ml_list[e]] = (int)e;
     o.seg_slot = put_i(seg_slot.data(), seg_slot.size());
     o.ms_start = put_i(ms_start.data(), M + 1);
+    std::vector<int> mc_row, mc_cnt, mb_start(L + 1, 0);
+    for (int i = 0; i < L; ++i) {
+        mb_start[i] = (int)mc_row.size();
+        for (int r = ml_start[i]; r < ml_start[i + 1]; r += DSIM_MUSCLE_CHUNK) {
+            mc_row.push_back(r);
+            mc_cnt.push_back(ml_start[i + 1] - r < DSIM_MUSCLE_CHUNK ? ml_start[i + 1] - r : DSIM_MUSCLE_CHUNK);
+        }
+    }
+    mb_start[L] = (int)mc_row.size();
+    const int MK = (int)mc_row.size();
+    o.mc_row = put_i(mc_row.data(), MK);
+    o.mc_cnt = put_i(mc_cnt.data(), MK);
+    o.mb_start = put_i(mb_start.data(), L + 1);
     o.mlinks = put_i(m.muscle_links, W);
     o.xpj = put_f(m.joint_X_pj, 7 * L);
     std::vector<float> com(3 * L), ic6(6 * L), mass(L);
@@ -377,6 +397,7 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.f = take(6 * L); o.cw = take(6 * C); o.tau = take(nd);
     o.ic10 = take(10 * L); o.F = take(6 * nd); o.hinv = take(nd * nd); o.prow = take(nd); o.pcol = take(nd);
     o.mus = take(13 * NS);  // 2 NS wrench rows of 6 floats, sorted by body (seg_slot), + (adjoint) NS activation cotangents
+    o.mpart = take(6 * MK);
     o.epf = take(4);
     o.fwd_words = cur;
     o.aq = take(nq); o.aqd = take(nd);
@@ -396,6 +417,7 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.total_words = cur;
 
     out.o = o;
+    dd.MK = MK;
     dd.L = L; dd.nq = nq; dd.nd = nd; dd.C = C; dd.M = M; dd.W = W; dd.NS = NS; dd.D = D;
     dd.flags = ranges ? DSIM_F_RANGES : 0;
     for (int i = 0; i < L; ++i) {
