@@ -530,6 +530,10 @@ template <int MASK, bool FIRST, class Ctx> DSIM_FN void dsim_fk_position(const C
     dsim_fk_compute<MASK, FIRST>(w, dsim_fk_load<MASK>(c, j, cs, ds), type);
 }
 template <int MASK, bool FIRST> DSIM_FN void dsim_fk_compute(DsimFkWalk& w, const DsimFkIn<MASK>& in, int type) {
+    // A position at which only ONE joint type can occur (compile-time mask of the specialised kernels) needs no run-time
+    // type test: every lane that evaluates the position has a joint of that type.  With the test, the compiler turns the
+    // short per-type block into selects on everything it writes (~20 v_cndmask per position and lane).
+    constexpr bool ONE = MASK != 0x1f && (MASK & (MASK - 1)) == 0;
     const v3 ppj = in.ppj, axis = in.axis;
     const q4 rpj = in.rpj;
     const float *qv = in.qv, *qdv = in.qdv;
@@ -543,7 +547,7 @@ template <int MASK, bool FIRST> DSIM_FN void dsim_fk_compute(DsimFkWalk& w, cons
     q4 rc = rj;
     sv6 vj = zerosv();
     if constexpr ((MASK & DSIM_TM(DSIM_JOINT_PRISMATIC)) != 0) {
-        if (type == DSIM_JOINT_PRISMATIC) {
+        if (ONE || type == DSIM_JOINT_PRISMATIC) {
             const v3 u = rotate(rj, axis);
             pc = pj + u * qv[0];
             w.s0 = mksv(zero3(), u);
@@ -551,7 +555,7 @@ template <int MASK, bool FIRST> DSIM_FN void dsim_fk_compute(DsimFkWalk& w, cons
         }
     }
     if constexpr ((MASK & DSIM_TM(DSIM_JOINT_REVOLUTE)) != 0) {
-        if (type == DSIM_JOINT_REVOLUTE) {
+        if (ONE || type == DSIM_JOINT_REVOLUTE) {
             rc = qmul(rj, quat_axis_angle(axis, qv[0]));
             const v3 u = rotate(rj, axis);
             w.s0 = mksv(u, cross(pj, u));
@@ -559,7 +563,7 @@ template <int MASK, bool FIRST> DSIM_FN void dsim_fk_compute(DsimFkWalk& w, cons
         }
     }
     if constexpr ((MASK & DSIM_TM(DSIM_JOINT_BALL)) != 0) {
-        if (type == DSIM_JOINT_BALL) {
+        if (ONE || type == DSIM_JOINT_BALL) {
             rc = qmul(rj, mkq(qv[0], qv[1], qv[2], qv[3]));
             v3 u0, u1, u2;
             rotate_basis(rj, u0, u1, u2);
@@ -572,7 +576,7 @@ template <int MASK, bool FIRST> DSIM_FN void dsim_fk_compute(DsimFkWalk& w, cons
         }
     }
     if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
-        if (type == DSIM_JOINT_FREE) {
+        if (ONE || type == DSIM_JOINT_FREE) {
             pc = rotate(rj, mk3(qv[0], qv[1], qv[2])) + pj;
             rc = qmul(rj, mkq(qv[3], qv[4], qv[5], qv[6]));
             vj = mksv(mk3(qdv[0], qdv[1], qdv[2]), mk3(qdv[3], qdv[4], qdv[5]));  // S = identity (dsim_init_static)
