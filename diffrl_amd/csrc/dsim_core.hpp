@@ -1,10 +1,14 @@
 // dsim_core.hpp -- per-environment forward substep and its hand-derived adjoint, written as
 // SPMD "phases" over the 64 lanes of ONE wavefront (one environment per workgroup, all state in LDS).
 //
-// Every phase is `ex.run([&](int lane){...})`: on the GPU `run` executes the body for
-// lane = threadIdx.x and then synchronises the workgroup (see dsim_hip.hip); a phase never reads
-// LDS words that another lane writes in the same phase, so all cross-lane traffic goes
-// LDS-write -> barrier -> LDS-read.  Nothing is kept in registers across phases.
+// Every phase is `ex.run([&](int lane){...})`: on the GPU `run` executes the body for its lane and then orders the
+// workgroup's LDS traffic (one wavefront: a compiler fence -- the LDS executes a wave's operations in issue order; several
+// wavefronts: a barrier; see dsim_hip.hip).  A phase never reads LDS words that another lane writes in the same phase
+// except behind an explicit `ex.lds_fence()`, so cross-lane traffic goes LDS-write -> boundary -> LDS-read, or through the
+// wavefront's cross-lane primitives (`ex.shfl`, `ex.bcast`).  `ex.fork_join(fm, fh)` is a phase of two blocks that touch
+// disjoint LDS words: a single wavefront runs them one after the other, the helper-wave kernels run fh on a second
+// wavefront.  What a lane keeps in registers across phases it gets from the executor (topology records, accumulators of
+// the mass-matrix cotangent, early-load and prefetch registers).
 // (tests/emu/ re-uses this file with an executor that runs the lanes one after another on the host
 // to unit-test the phase logic without a GPU; that harness is test-only and not part of the library.)
 //
