@@ -219,6 +219,7 @@ struct DsimTopoRegs {
     // trunk ancestor, bit e set <=> link top + e is an ancestor-or-self, first own dof (-1: none)
     int tl_row[DSIM_TR_PASSES], tl_k[DSIM_TR_PASSES], tl_n[DSIM_TR_PASSES], tl_c0[DSIM_TR_PASSES], tl_nc[DSIM_TR_PASSES];
     int ta_top[DSIM_TR_PASSES], ta_tp[DSIM_TR_PASSES], ta_m[DSIM_TR_PASSES], tu_d[DSIM_TR_PASSES];
+    float tw_l[DSIM_TR_PASSES][DSIM_LIGHT_CAP], tw_c[DSIM_TR_PASSES][DSIM_LIGHT_CAP];   // 1 / 0 weights of the light sums' entries (adjoint kernels)
     int adof[16], adof_n;                    // dofs of the ancestors-or-self of link `(63 - lane) / 6` (adjoint of tau)
 };
 template <class Ctx> struct DsimChainRegs {
@@ -299,6 +300,16 @@ template <class Ctx, class Exec> DSIM_FN void dsim_topo_init(const Ctx& c, Exec&
             tp.tl_n[p] = li.nsub;
             tp.tl_c0[p] = li.c0;
             tp.tl_nc[p] = li.nc;
+#pragma unroll
+            for (int e = 0; e < D::LCAP; ++e) {
+                tp.tw_l[p][e] = e < li.nsub ? 1.f : 0.f;
+                DSIM_OPAQUE(tp.tw_l[p][e]);
+            }
+#pragma unroll
+            for (int e = 0; e < D::CCAP; ++e) {
+                tp.tw_c[p][e] = e < li.nc ? 1.f : 0.f;
+                DSIM_OPAQUE(tp.tw_c[p][e]);
+            }
             // ancestors-or-self of i, root first: trunk links, then light ones
             const int e0 = CI(anc_start)[i], e1 = CI(anc_start)[i + 1];
             int top = i, tpl = 0, mask = 0;
@@ -843,7 +854,10 @@ DSIM_FN float dsim_subtree_contact_sum(const Ctx& c, Exec& ex, int lane, int i, 
 //                 previous one through the wavefront's in-order LDS queue (Exec::lds_fence: a compiler fence on the GPU).
 // Replaces, for a 22-link humanoid, flat sums of up to 22 + 35 entries per item in three passes (of which the entries
 // past a cap of 8 ran in run-time loops of dependent loads).  cdata may be null (links only).
-template <class Ctx, class Exec>
+// WEIGHTS: the entries of a light sum are multiplied by per-lane 1 / 0 registers (dsim_range_sum_m's trick: one fused
+// multiply-add per entry instead of compare + select + add); the adjoint kernels have the registers for it (three such sums
+// per substep), the forward kernel of the humanoid (one sum, 233 VGPRs already) keeps the selects.
+template <bool WEIGHTS, class Ctx, class Exec>
 DSIM_FN void dsim_trunk_sum(const Ctx& c, Exec& ex, int lane, const float* ldata, const float* cdata, int cstride, int coff,
                             float* out) {
     using D = decltype(c.d);
@@ -864,11 +878,20 @@ DSIM_FN void dsim_trunk_sum(const Ctx& c, Exec& ex, int lane, const float* ldata
             for (int e = 0; e < D::CCAP; ++e) y[e] = cp[cstride * e];
         }
         float acc = 0.f;
+        if constexpr (WEIGHTS) {
 #pragma unroll
-        for (int e = 0; e < D::LCAP; ++e) acc += (e < n) ? x[e] : 0.f;
-        if (cdata) {
+            for (int e = 0; e < D::LCAP; ++e) acc = __builtin_fmaf(x[e], tp.tw_l[p][e], acc);
+            if (cdata) {
 #pragma unroll
-            for (int e = 0; e < D::CCAP; ++e) acc += (e < nc) ? y[e] : 0.f;
+                for (int e = 0; e < D::CCAP; ++e) acc = __builtin_fmaf(y[e], tp.tw_c[p][e], acc);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < D::LCAP; ++e) acc += (e < n) ? x[e] : 0.f;
+            if (cdata) {
+#pragma unroll
+                for (int e = 0; e < D::CCAP; ++e) acc += (e < nc) ? y[e] : 0.f;
+            }
         }
         if (row >= 0) out[row] = acc;
     }
@@ -895,7 +918,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_tau(const Ctx& c, Exec& e
     // f_tot[i] = sum over subtree(i) of (inverse-dynamics force [+ muscle wrenches, gathered per body]) + contact wrenches
     ex.run([&](int lane) {
         if constexpr (DsimTrunk<Ctx, Exec>::value) {
-            dsim_trunk_sum(c, ex, lane, WF(f), WF(cw), 6, 0, WF(ftot));
+            dsim_trunk_sum<false>(c, ex, lane, WF(f), WF(cw), 6, 0, WF(ftot));
             return;
         }
         for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
@@ -1815,7 +1838,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             const float g = WF(amact)[m];
             WF(amact)[m] = g + dsim_range_sum(WF(mus) + 12 * c.d.NS, 1, 0, s0, s1 - s0, 0.f);
         }
-        if constexpr (DsimTrunk<Ctx, Exec>::value) dsim_trunk_sum(c, ex, lane, WF(aa), nullptr, 0, 0, WF(aatot));
+        if constexpr (DsimTrunk<Ctx, Exec>::value) dsim_trunk_sum<true>(c, ex, lane, WF(aa), nullptr, 0, 0, WF(aatot));
         for (int it = lane; it < (DsimTrunk<Ctx, Exec>::value ? 0 : 6 * c.d.L); it += Exec::NL) {
             const int i = it / 6, k = it - 6 * i;
             int n_known = -1;
@@ -1882,7 +1905,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
     });
     ex.run([&](int lane) {
         if constexpr (DsimTrunk<Ctx, Exec>::value) {
-            dsim_trunk_sum(c, ex, lane, WF(av), WF(acx), 12, 6, WF(avtot));
+            dsim_trunk_sum<true>(c, ex, lane, WF(av), WF(acx), 12, 6, WF(avtot));
             return;
         }
         for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
@@ -1937,7 +1960,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
     });
     ex.run([&](int lane) {
         if constexpr (DsimTrunk<Ctx, Exec>::value) {
-            dsim_trunk_sum(c, ex, lane, WF(aw), WF(acx), 12, 0, WF(azs));
+            dsim_trunk_sum<true>(c, ex, lane, WF(aw), WF(acx), 12, 0, WF(azs));
             return;
         }
         for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
