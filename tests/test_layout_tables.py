@@ -82,3 +82,87 @@ def test_tables_match_a_direct_computation(tree):
         [k for k in range(C) if cbody[k] in sub[i]]) for i in range(L))
     assert bool(dims["flags"] & 1) == (preorder and contiguous)
     assert dims["D"] == max(len(c) for c in anc)
+
+
+@st.composite
+def deep_trees(draw):
+    """pre-order numbered trees of 11..30 links with one free root and hinges below it: what the trunk decomposition is for"""
+    L = draw(st.integers(11, 30))
+    parents = [-1]
+    open_chain = [0]      # pre-order: a new link hangs off a link on the current root-to-leaf path
+    for i in range(1, L):
+        depth = draw(st.integers(max(1, len(open_chain) - 3), len(open_chain)))
+        open_chain = open_chain[:depth]
+        parents.append(open_chain[-1])
+        open_chain.append(i)
+    shapes = [draw(st.sampled_from(["sphere", "capsule"])) for _ in range(L)]
+    return parents, ["free"] + ["rev"] * (L - 1), shapes
+
+
+@settings(max_examples=40, deadline=None)
+@given(deep_trees())
+def test_trunk_decomposition_of_deep_trees(tree):
+    """DsimDims::NT... (dsim_layout.hpp): the trunk is the ancestor-closed set of links with subtrees above the cap, its
+    child / contact / dof records are those of the tree, every other link fits the light caps, light_list lists them."""
+    from emu_lib import layout
+    parents, kinds, shapes = tree
+    t = _build(parents, kinds, shapes)
+    L, C = t.n_links, t.n_contacts
+    off, d = layout(t)
+    img, off2, _ = substep_image(t, t.joint_q0[None], np.zeros((1, t.n_qd), np.float32), np.zeros((1, t.n_qd), np.float32), None,
+                                 1.0 / 960.0)
+    I = img.view(np.int32)
+    sub = [[j for j in range(L) if i in _chain(parents, j)] for i in range(L)]
+    cbody = list(t.contact_body)
+    scb = [[k for k in range(C) if cbody[k] in sub[i]] for i in range(L)]
+    if d["NT"] == 0:
+        return   # the builder found no admissible cap (too many trunk links / children / contacts): flat sums are used
+    nt, cap = d["NT"], d["LCAP"]
+    trunk = d["trunk"][:nt]
+    assert trunk == [i for i in range(L) if len(sub[i]) > cap] and trunk[0] == 0 and 1 <= nt <= 6
+    assert d["NLT"] == L - nt
+    light = [i for i in range(L) if i not in trunk]
+    assert I[off2["light_list"]:off2["light_list"] + len(light)].tolist() == light
+    assert max(len(sub[i]) for i in light) <= cap <= 8
+    assert d["CCAP"] == max([len(scb[i]) for i in light] + [0]) <= 8
+    qds = list(t.joint_qd_start)
+    for u, i in enumerate(trunk):
+        assert parents[i] == (-1 if d["tr_par"][u] < 0 else trunk[d["tr_par"][u]])
+        ch = [j for j in range(L) if parents[j] == i]
+        assert d["tr_nch"][u] == len(ch) <= 4 and d["tr_ch"][4 * u:4 * u + len(ch)] == ch
+        own = [k for k in range(C) if cbody[k] == i]
+        assert d["tr_ncb"][u] == len(own) and (not own or d["tr_cb0"][u] == own[0])
+        assert (d["tr_d0"][u], d["tr_nd"][u]) == (qds[i], qds[i + 1] - qds[i])
+    # trunk + light subtrees tile the tree: a trunk link's subtree = itself + the subtrees of its children
+    for i in trunk:
+        kids = [j for j in range(L) if parents[j] == i]
+        assert sorted([i] + [x for j in kids for x in sub[j]]) == sub[i]
+
+
+def _chain(parents, j):
+    out = []
+    while j >= 0:
+        out.append(j)
+        j = parents[j]
+    return out
+
+
+def test_muscle_chunk_tables_cover_the_body_rows():
+    """mc_row / mc_cnt / mb_start (dsim_layout.hpp): the chunks of a body tile its muscle wrench rows, at most 12 rows each"""
+    from emu_lib import layout
+    from oracle_lib import template_from_golden
+    t = template_from_golden("snu")
+    off, d = layout(t)
+    img, off2, _ = substep_image(t, t.joint_q0[None], np.zeros((1, t.n_qd), np.float32), np.zeros((1, t.n_qd), np.float32),
+                                 np.zeros((1, t.n_muscles), np.float32), 1.0 / 2880.0)
+    I = img.view(np.int32)
+    L, K = t.n_links, d["MK"]
+    assert K > 0
+    ml = I[off2["ml_start"]:off2["ml_start"] + L + 1].tolist()
+    mb = I[off2["mb_start"]:off2["mb_start"] + L + 1].tolist()
+    row, cnt = I[off2["mc_row"]:off2["mc_row"] + K].tolist(), I[off2["mc_cnt"]:off2["mc_cnt"] + K].tolist()
+    assert mb[0] == 0 and mb[L] == K
+    for i in range(L):
+        rows = [r for e in range(mb[i], mb[i + 1]) for r in range(row[e], row[e] + cnt[e])]
+        assert rows == list(range(ml[i], ml[i + 1]))
+        assert all(0 < cnt[e] <= 12 for e in range(mb[i], mb[i + 1]))
