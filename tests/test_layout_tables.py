@@ -86,15 +86,41 @@ def test_tables_match_a_direct_computation(tree):
 
 @st.composite
 def deep_trees(draw):
-    """pre-order numbered trees of 11..30 links with one free root and hinges below it: what the trunk decomposition is for"""
-    L = draw(st.integers(11, 30))
-    parents = [-1]
-    open_chain = [0]      # pre-order: a new link hangs off a link on the current root-to-leaf path
-    for i in range(1, L):
-        depth = draw(st.integers(max(1, len(open_chain) - 3), len(open_chain)))
-        open_chain = open_chain[:depth]
-        parents.append(open_chain[-1])
-        open_chain.append(i)
+    """humanoid-like trees, numbered in pre-order: a trunk chain of 1..4 links below a free root, limbs (chains of 1..6
+    hinged links) attached to trunk links -- what the trunk decomposition is for; L >= 11"""
+    trunk_len = draw(st.integers(1, 4))
+    children = {0: []}
+    nodes = [0]
+    for k in range(1, trunk_len):
+        children[nodes[-1]].append(len(children))
+        children[len(children)] = []
+        nodes.append(len(children) - 1)
+    n_limbs = draw(st.integers(2, 5))
+    for _ in range(n_limbs):
+        at = draw(st.sampled_from(nodes))
+        if len(children[at]) >= 4:
+            continue
+        prev = at
+        for _k in range(draw(st.integers(1, 6))):
+            new = len(children)
+            children[prev].append(new)
+            children[new] = []
+            prev = new
+    # pre-order relabelling
+    order, parent_of = [], {0: -1}
+    stack = [0]
+    while stack:
+        x = stack.pop()
+        order.append(x)
+        for c in reversed(children[x]):
+            parent_of[c] = x
+            stack.append(c)
+    new_id = {x: i for i, x in enumerate(order)}
+    parents = [(-1 if parent_of[x] < 0 else new_id[parent_of[x]]) for x in order]
+    L = len(parents)
+    while L < 11:   # pad with one more limb off the root so that the decomposition applies (L > 10)
+        parents.append(0 if L == len(order) else L - 1)
+        L += 1
     shapes = [draw(st.sampled_from(["sphere", "capsule"])) for _ in range(L)]
     return parents, ["free"] + ["rev"] * (L - 1), shapes
 
@@ -117,6 +143,7 @@ def test_trunk_decomposition_of_deep_trees(tree):
     scb = [[k for k in range(C) if cbody[k] in sub[i]] for i in range(L)]
     if d["NT"] == 0:
         return   # the builder found no admissible cap (too many trunk links / children / contacts): flat sums are used
+    _TRUNK_SEEN.append(1)
     nt, cap = d["NT"], d["LCAP"]
     trunk = d["trunk"][:nt]
     assert trunk == [i for i in range(L) if len(sub[i]) > cap] and trunk[0] == 0 and 1 <= nt <= 6
@@ -137,6 +164,13 @@ def test_trunk_decomposition_of_deep_trees(tree):
     for i in trunk:
         kids = [j for j in range(L) if parents[j] == i]
         assert sorted([i] + [x for j in kids for x in sub[j]]) == sub[i]
+
+
+_TRUNK_SEEN = []
+
+
+def test_trunk_decomposition_was_exercised():
+    assert len(_TRUNK_SEEN) >= 5, "the random deep trees should admit a trunk decomposition most of the time"
 
 
 def _chain(parents, j):
