@@ -1421,8 +1421,8 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
             WF(atau)[i] = dsim_dot_n(WF(hinv) + i * nd, WF(aqdd), nd);  // hinv is symmetric
         }
     });
-    // Two blocks that touch disjoint LDS words: (main) the mass-matrix cotangent accumulators and af, (side) the per-dof
-    // cotangents of tau -- handed to the helper wavefront where there is one (Exec::fork_join)
+    // Three blocks that touch disjoint LDS words: the mass-matrix cotangent accumulators, the per-dof cotangents of tau, and
+    // af -- the last one is handed to the helper wavefront where there is one (Exec::fork_join)
     auto tau_adjoint_per_dof = [&](int lane) __attribute__((always_inline)) {
         for (int d = lane; d < nd; d += Exec::NL) {
             int i, type, cs, ds;
@@ -1457,33 +1457,8 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
             }
         }
     };
-    ex.fork_join([&](int lane) {
-        bool in_regs = false;
-        if constexpr (DsimIsStatic<Ctx>::value) {
-            constexpr int NN = decltype(c.d)::nd * decltype(c.d)::nd, ACC = (NN + Exec::NL - 1) / Exec::NL;
-            if constexpr (ACC <= DSIM_HACC_MAX) {
-                in_regs = true;
-                float* acc = ex.hacc(lane);
-#pragma unroll
-                for (int m = 0; m < ACC; ++m) {
-                    const int it = lane + Exec::NL * m;
-                    if (it < NN) {
-                        const int i = it / decltype(c.d)::nd, j = it - decltype(c.d)::nd * i;
-                        acc[m] -= WF(atau)[i] * WF(qdd)[j];
-                        if (update_mass) WF(aH)[it] = acc[m];
-                    }
-                }
-            }
-        }
-        if (!in_regs) {
-            for (int it = lane; it < nd * nd; it += Exec::NL) {
-                const int i = it / nd, j = it - nd * i;
-                WF(aH)[it] -= WF(atau)[i] * WF(qdd)[j];
-            }
-        }
-        // cotangent of body_f_s[j]: f_tot of every ancestor-or-self i of j contains f[j] and tau_d = -S_d . f_tot[link(d)], so
-        // af[j] = -sum over the dofs d of all ancestors-or-self of j of S_d atau_d (same phase: reads only S and atau;
-        // items are dealt from the top lane down so that they do not pile onto the lanes of the per-dof loop above)
+    // (main) the mass-matrix cotangent accumulators (registers of the main wave) and the per-dof block, (side) af
+    auto af_block = [&](int lane) __attribute__((always_inline)) {
         if constexpr (DsimTrunk<Ctx, Exec>::value) {
             // Trunk decomposition of the ancestor sums: u_j = sum over the own dofs of link j of S_d atau_d; a trunk link's
             // prefix P_t = P_parent + u_t is evaluated by lanes 0..5 straight from S and atau (the trunk is a handful of
@@ -1579,7 +1554,37 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
             for (; e < e1; ++e) acc -= WF(S)[6 * lst[e] + k] * WF(atau)[lst[e]];
             WF(af)[it] = acc;
         }
-    }, tau_adjoint_per_dof);
+    };
+    ex.fork_join([&](int lane) {
+        bool in_regs = false;
+        if constexpr (DsimIsStatic<Ctx>::value) {
+            constexpr int NN = decltype(c.d)::nd * decltype(c.d)::nd, ACC = (NN + Exec::NL - 1) / Exec::NL;
+            if constexpr (ACC <= DSIM_HACC_MAX) {
+                in_regs = true;
+                float* acc = ex.hacc(lane);
+#pragma unroll
+                for (int m = 0; m < ACC; ++m) {
+                    const int it = lane + Exec::NL * m;
+                    if (it < NN) {
+                        const int i = it / decltype(c.d)::nd, j = it - decltype(c.d)::nd * i;
+                        acc[m] -= WF(atau)[i] * WF(qdd)[j];
+                        if (update_mass) WF(aH)[it] = acc[m];
+                    }
+                }
+            }
+        }
+        if (!in_regs) {
+            for (int it = lane; it < nd * nd; it += Exec::NL) {
+                const int i = it / nd, j = it - nd * i;
+                WF(aH)[it] -= WF(atau)[i] * WF(qdd)[j];
+            }
+        }
+        // cotangent of body_f_s[j]: f_tot of every ancestor-or-self i of j contains f[j] and tau_d = -S_d . f_tot[link(d)], so
+        // af[j] = -sum over the dofs d of all ancestors-or-self of j of S_d atau_d (same phase: reads only S and atau;
+        // items are dealt from the top lane down so that they do not pile onto the lanes of the per-dof loop above)
+        tau_adjoint_per_dof(lane);
+    }, af_block);
+
 }
 
 // contacts^T and muscles^T.  The cotangent with respect to the POSE of a body is kept as a world-frame wrench (torque
@@ -1826,11 +1831,17 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             const v3 rg = cross(r.w, grav);
             W.w += cross(I.h, rg);
             W.v += rg * I.m;
-            stsv(WF(aa) + 6 * i, inertia_mul(I, r));
+            if constexpr (!Exec::HAS_HELPER) stsv(WF(aa) + 6 * i, inertia_mul(I, r));
             stsv(WF(av) + 6 * i, a_v);  // contact cotangents are added by the item-parallel gather below
             stsv(WF(aw) + 6 * i, W);
         }
-    }, [&](int lane) { dsim_bwd_external_items(c, ex, lane); });
+    }, [&](int lane) {
+        dsim_bwd_external_items(c, ex, lane);
+        if constexpr (Exec::HAS_HELPER) {   // aa = I af: evens out the two waves (the main block is the longer one)
+            for (int i = lane; i < c.d.L; i += Exec::NL)
+                stsv(WF(aa) + 6 * i, inertia_mul(ld_i10(WF(i10) + 10 * i), ldsv(WF(af) + 6 * i)));
+        }
+    });
     ex.run([&](int lane) {
         for (int m = lane; m < c.d.M; m += Exec::NL) {
             // a muscle's active segments are consecutive rows of `mus`: batched range sum, not a serial chain of loads
