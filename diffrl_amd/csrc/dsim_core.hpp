@@ -420,6 +420,9 @@ template <int I, int N, class F> DSIM_FN void dsim_static_for(F&& f) {
 // joint types that can occur at chain position P (specialised kernels: a compile-time constant, so the branches of
 // types that do not occur there -- and their loads -- are not even compiled)
 template <class D, int P> constexpr int dsim_pos_mask() { return P < DSIM_PMASK_N ? D::pmask[P] : D::tmask; }
+// every joint at chain position P has an identity X_pj rotation (true of all joints of the MJCF / SNU models): the joint
+// frame's orientation IS the parent link's, and q (x) identity is q exactly -- the product is not evaluated
+template <class D, int P> constexpr bool dsim_pos_ident() { return P < DSIM_PMASK_N && ((D::pident >> P) & 1) != 0; }
 // number of joint coordinates / dofs a lane must fetch for a joint whose type is in `mask`
 constexpr int dsim_mask_nq(int mask) {
     return (mask & DSIM_TM(DSIM_JOINT_FREE)) ? 7 : (mask & DSIM_TM(DSIM_JOINT_BALL)) ? 4
@@ -516,12 +519,12 @@ template <class D, int P, int N, class Ctx> DSIM_FN void dsim_fk_load_all(const 
         dsim_fk_load_all<D, P + 1, N>(c, ch, pre.rest);
     }
 }
-template <int MASK, bool FIRST> DSIM_FN void dsim_fk_compute(DsimFkWalk& w, const DsimFkIn<MASK>& in, int type);
+template <int MASK, bool FIRST, bool IDENT = false> DSIM_FN void dsim_fk_compute(DsimFkWalk& w, const DsimFkIn<MASK>& in, int type);
 template <class D, int P, int N> DSIM_FN void dsim_fk_compute_all(DsimFkWalk& w, const int* ch, int n, const DsimFkPre<D, P, N>& pre) {
     if constexpr (P < N) {
         int ty = ch[4 * P + 1];
         DSIM_OPAQUE(ty);
-        if (P < n) dsim_fk_compute<dsim_pos_mask<D, P>(), P == 0>(w, pre.in, ty);
+        if (P < n) dsim_fk_compute<dsim_pos_mask<D, P>(), P == 0, dsim_pos_ident<D, P>()>(w, pre.in, ty);
         dsim_fk_compute_all<D, P + 1, N>(w, ch, n, pre.rest);
     }
 }
@@ -544,7 +547,7 @@ DSIM_FN void dsim_fk_walk_chunks(const Ctx& c, DsimFkWalk& w, const int* ch, int
 template <int MASK, bool FIRST, class Ctx> DSIM_FN void dsim_fk_position(const Ctx& c, DsimFkWalk& w, int j, int type, int cs, int ds) {
     dsim_fk_compute<MASK, FIRST>(w, dsim_fk_load<MASK>(c, j, cs, ds), type);
 }
-template <int MASK, bool FIRST> DSIM_FN void dsim_fk_compute(DsimFkWalk& w, const DsimFkIn<MASK>& in, int type) {
+template <int MASK, bool FIRST, bool IDENT> DSIM_FN void dsim_fk_compute(DsimFkWalk& w, const DsimFkIn<MASK>& in, int type) {
     // A position at which only ONE joint type can occur (compile-time mask of the specialised kernels) needs no run-time
     // type test: every lane that evaluates the position has a joint of that type.  With the test, the compiler turns the
     // short per-type block into selects on everything it writes (~20 v_cndmask per position and lane).
@@ -553,10 +556,11 @@ template <int MASK, bool FIRST> DSIM_FN void dsim_fk_compute(DsimFkWalk& w, cons
     const q4 rpj = in.rpj;
     const float *qv = in.qv, *qdv = in.qdv;
     v3 pj = ppj;
-    q4 rj = rpj;
+    q4 rj = IDENT ? mkq(0.f, 0.f, 0.f, 1.f) : rpj;
     if constexpr (!FIRST) {
         pj = rotate(w.rsp, ppj) + w.psp;
-        rj = qmul(w.rsp, rpj);
+        if constexpr (IDENT) rj = w.rsp;
+        else rj = qmul(w.rsp, rpj);
     }
     v3 pc = pj;
     q4 rc = rj;
@@ -592,8 +596,13 @@ template <int MASK, bool FIRST> DSIM_FN void dsim_fk_compute(DsimFkWalk& w, cons
     }
     if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
         if (ONE || type == DSIM_JOINT_FREE) {
-            pc = rotate(rj, mk3(qv[0], qv[1], qv[2])) + pj;
-            rc = qmul(rj, mkq(qv[3], qv[4], qv[5], qv[6]));
+            if constexpr (FIRST && IDENT) {   // identity joint frame at the root: rotate(1, x) = x and 1 (x) q = q exactly
+                pc = mk3(qv[0], qv[1], qv[2]) + pj;
+                rc = mkq(qv[3], qv[4], qv[5], qv[6]);
+            } else {
+                pc = rotate(rj, mk3(qv[0], qv[1], qv[2])) + pj;
+                rc = qmul(rj, mkq(qv[3], qv[4], qv[5], qv[6]));
+            }
             vj = mksv(mk3(qdv[0], qdv[1], qdv[2]), mk3(qdv[3], qdv[4], qdv[5]));  // S = identity (dsim_init_static)
         }
     }

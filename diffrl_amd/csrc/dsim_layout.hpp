@@ -37,6 +37,7 @@ struct DsimDims {
     int tr_cb0[DSIM_TRUNK_MAX], tr_ncb[DSIM_TRUNK_MAX];  // the link's own contacts [cb0, cb0 + ncb)
     int tr_d0[DSIM_TRUNK_MAX], tr_nd[DSIM_TRUNK_MAX];    // its own dofs [d0, d0 + nd)
     int MK;                                        // chunks of the per-body muscle-row gather (DsimOff::mc_row)
+    int pident;                                    // bit p set: every joint at chain position p has an identity X_pj ROTATION
 };
 #define DSIM_TM(t) (1 << (t))
 #define DSIM_F_RANGES 1  // subtree(i) == links [i, i+n_i) and its contacts == one contiguous contact range (pre-order numbering)
@@ -418,6 +419,14 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
 
     out.o = o;
     dd.MK = MK;
+    for (int p = 0; p < DSIM_PMASK_N; ++p) dd.pident |= 1 << p;
+    for (int i = 0; i < L; ++i) {
+        const float* x = m.joint_X_pj + 7 * i;
+        const bool ident = x[3] == 0.f && x[4] == 0.f && x[5] == 0.f && x[6] == 1.f;
+        const int p = (int)anc[i].size() - 1;
+        if (!ident) dd.pident &= ~(1 << (p < DSIM_PMASK_N ? p : DSIM_PMASK_N - 1));
+        if (!ident && p >= DSIM_PMASK_N) dd.pident = 0;
+    }
     dd.L = L; dd.nq = nq; dd.nd = nd; dd.C = C; dd.M = M; dd.W = W; dd.NS = NS; dd.D = D;
     dd.flags = ranges ? DSIM_F_RANGES : 0;
     for (int i = 0; i < L; ++i) {

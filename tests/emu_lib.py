@@ -68,7 +68,7 @@ def layout(t):
     # trunk decomposition (DsimDims behind pmask, struct order)
     pos = 20
     for name, cnt in [("NT", 0), ("NLT", 0), ("LCAP", 0), ("CCAP", 0), ("trunk", 6), ("tr_par", 6), ("tr_nch", 6), ("tr_ch", 24),
-                      ("tr_cb0", 6), ("tr_ncb", 6), ("tr_d0", 6), ("tr_nd", 6), ("MK", 0)]:
+                      ("tr_cb0", 6), ("tr_ncb", 6), ("tr_d0", 6), ("tr_nd", 6), ("MK", 0), ("pident", 0)]:
         if cnt == 0:
             d[name] = int(dims[pos]); pos += 1
         else:
