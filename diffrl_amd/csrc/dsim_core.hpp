@@ -410,6 +410,19 @@ template <class Ctx, class Exec> DSIM_FN void dsim_topo_init(const Ctx& c, Exec&
     }
 }
 
+// the model's only free joint is its root, whose joint frame has an identity rotation (every floating-base model here)
+template <class Ctx> struct DsimFreeRootIdent {
+    static constexpr bool value = []() {
+        if constexpr (std::is_empty<decltype(Ctx::d)>::value) {
+            using D = decltype(Ctx::d);
+            bool ok = (D::pident & 1) != 0 && D::D <= DSIM_PMASK_N;
+            for (int p = 1; p < DSIM_PMASK_N; ++p) ok = ok && (D::pmask[p] & DSIM_TM(DSIM_JOINT_FREE)) == 0;
+            return ok;
+        } else {
+            return false;
+        }
+    }();
+};
 // compile-time loop with a constexpr index (per-position joint-type masks of the specialised kernels)
 template <int I, int N, class F> DSIM_FN void dsim_static_for(F&& f) {
     if constexpr (I < N) {
@@ -2021,14 +2034,21 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
                     // X_sc = X_sj o (q_p, q_r): translation by R_j dq_p, rotation about p_c
                     const v3 pc = ld3(WF(xsc) + 7 * i);
                     const q4 rc = ldq(WF(xsc) + 7 * i + 3);
-                    const q4 rpj = ldq(CF(xpj) + 7 * i + 3);
-                    q4 rj = rpj;
-                    if (par >= 0) rj = qmul(ldq(WF(xsc) + 7 * par + 3), rpj);
                     const v3 gp = mk3(g0, aq[cs + 1], aq[cs + 2]);
                     const q4 gr = ldq(aq + cs + 3);
                     const v3 tc = Wt.w - cross(pc, Wt.v);
-                    st3(aq + cs, gp + rotate_inv(rj, Wt.v));
-                    stq(aq + cs + 3, gr + qmul(qmul(qconj(rj), mkq(tc.x, tc.y, tc.z, 0.f)), rc) * 2.0f);
+                    if constexpr (DsimFreeRootIdent<Ctx>::value) {
+                        // the only free joint is the root, with an identity joint frame: R_j = 1, and 1^-1 x = x, 1* (x) t = t exactly
+                        (void)par;
+                        st3(aq + cs, gp + Wt.v);
+                        stq(aq + cs + 3, gr + qmul(mkq(tc.x, tc.y, tc.z, 0.f), rc) * 2.0f);
+                    } else {
+                        const q4 rpj = ldq(CF(xpj) + 7 * i + 3);
+                        q4 rj = rpj;
+                        if (par >= 0) rj = qmul(ldq(WF(xsc) + 7 * par + 3), rpj);
+                        st3(aq + cs, gp + rotate_inv(rj, Wt.v));
+                        stq(aq + cs + 3, gr + qmul(qmul(qconj(rj), mkq(tc.x, tc.y, tc.z, 0.f)), rc) * 2.0f);
+                    }
                 }
             }
         }
