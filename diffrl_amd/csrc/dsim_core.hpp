@@ -1106,7 +1106,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_integrate(const Ctx& c, E
                     } else {
                         r = mkq(qv[0], qv[1], qv[2], qv[3]);
                     }
-                    const q4 dr = qmul(mkq(w.x, w.y, w.z, 0.f), r) * 0.5f;
+                    const q4 dr = qmul_v(w, r) * 0.5f;
                     const q4 rt = r + dr * h;
                     const float l = sqrtf(qdot(rt, rt));
                     q4 rn = mkq(0.f, 0.f, 0.f, 1.f);
@@ -1242,7 +1242,7 @@ DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float*
                     } else {
                         r = mkq(qv[0], qv[1], qv[2], qv[3]);
                     }
-                    const q4 dr = qmul(mkq(w.x, w.y, w.z, 0.f), r) * 0.5f;
+                    const q4 dr = qmul_v(w, r) * 0.5f;
                     const q4 rt = r + dr * h;
                     const float l = sqrtf(qdot(rt, rt));
                     q4 rn = mkq(0.f, 0.f, 0.f, 1.f);
@@ -1407,8 +1407,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
                         r = mkq(qv[0], qv[1], qv[2], qv[3]);
                         g_rn = mkq(gqn[0], gqn[1], gqn[2], gqn[3]);
                     }
-                    const q4 W = mkq(w.x, w.y, w.z, 0.f);
-                    const q4 rt = r + qmul(W, r) * (0.5f * h);
+                    const q4 rt = r + qmul_v(w, r) * (0.5f * h);   // W = (w, 0)
                     const float l = sqrtf(qdot(rt, rt));
                     q4 g_rt = mkq(0.f, 0.f, 0.f, 0.f);
                     if (l > 0.0f) {
@@ -1416,7 +1415,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
                         const q4 rn = rt * il;
                         g_rt = (g_rn + rn * (-qdot(rn, g_rn))) * il;
                     }
-                    const q4 g_r = g_rt + qmul_adj_b(W, g_rt) * (0.5f * h);
+                    const q4 g_r = g_rt + qmul_v(mk3(-w.x, -w.y, -w.z), g_rt) * (0.5f * h);   // conj(W) (x) g_rt
                     const q4 g_W = qmul_adj_a(r, g_rt) * (0.5f * h);
                     v3 g_w = qvec(g_W) + mk3(gqdn[0], gqdn[1], gqdn[2]);
                     if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
@@ -2026,7 +2025,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
                     const q4 r = ldq(WF(q) + cs), g = ldq(aq + cs);
                     const v3 t = mk3(sdot(ldsv(WF(S) + 6 * ds), Wt), sdot(ldsv(WF(S) + 6 * ds + 6), Wt),
                                      sdot(ldsv(WF(S) + 6 * ds + 12), Wt));
-                    stq(aq + cs, g + qmul(mkq(t.x, t.y, t.z, 0.f), r) * 2.0f);
+                    stq(aq + cs, g + qmul_v(t, r) * 2.0f);
                 }
             }
             if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
@@ -2041,7 +2040,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
                         // the only free joint is the root, with an identity joint frame: R_j = 1, and 1^-1 x = x, 1* (x) t = t exactly
                         (void)par;
                         st3(aq + cs, gp + Wt.v);
-                        stq(aq + cs + 3, gr + qmul(mkq(tc.x, tc.y, tc.z, 0.f), rc) * 2.0f);
+                        stq(aq + cs + 3, gr + qmul_v(tc, rc) * 2.0f);
                     } else {
                         const q4 rpj = ldq(CF(xpj) + 7 * i + 3);
                         q4 rj = rpj;

@@ -52,6 +52,14 @@ DSIM_FN q4 qmul(q4 a, q4 b) {
               a.w * b.z + b.w * a.z + a.x * b.y - b.x * a.y,
               a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
 }
+// (a, 0) (x) b for a pure-vector left factor (angular velocity, torque): qmul's formulas without the four products with the
+// literal 0 -- which IEEE arithmetic does not let the compiler drop, although 0 * x + y is y for every finite x
+DSIM_FN q4 qmul_v(v3 a, q4 b) {
+    return q4{b.w * a.x + a.y * b.z - b.y * a.z,
+              b.w * a.y + a.z * b.x - b.z * a.x,
+              b.w * a.z + a.x * b.y - b.x * a.y,
+              -(a.x * b.x) - a.y * b.y - a.z * b.z};
+}
 // c = a (x) b is bilinear: adj_a = adj_c (x) conj(b), adj_b = conj(a) (x) adj_c  (== quat.h:232-247)
 DSIM_FN q4 qmul_adj_a(q4 b, q4 r) { return qmul(r, qconj(b)); }
 DSIM_FN q4 qmul_adj_b(q4 a, q4 r) { return qmul(qconj(a), r); }
