@@ -1,11 +1,12 @@
 // dsim_hip.hip -- gfx950 kernels + the C ABI of include/dsim.h.
 //
-// Mapping: ONE environment per workgroup, ONE wavefront (64 lanes) per workgroup.  The articulation
-// template (a few KB) is copied from global memory into LDS once per launch, the environment's state
-// row is loaded with one coalesced read per tensor, all `substeps` substeps run out of LDS, and only
-// (q, qd) [+ the per-substep checkpoint when gradients are wanted] go back to HBM.  N=1024
-// environments therefore put exactly one wave on each of the 1024 SIMDs of an MI355X; larger N
-// stacks waves per SIMD and hides LDS/VALU latency.
+// Mapping: ONE environment per workgroup.  The phase code of an environment runs on ONE wavefront (64 lanes) -- plus, while
+// all environments of a launch are resident at once, a HELPER wavefront that executes only the side blocks of split phases
+// (DevExec<..., HELPER>) -- or on four wavefronts for models whose item lists are several wavefronts long (muscles).  The
+// articulation template (a few KB) is copied from global memory into LDS once per launch, the environment's state row is
+// loaded with one coalesced read per tensor, all `substeps` substeps run out of LDS, and only (q, qd) [+ the per-substep
+// checkpoint when gradients are wanted] go back to HBM.  N=1024 environments put one main wave on each of the 1024 SIMDs
+// of an MI355X; larger N stacks waves per SIMD and hides LDS/VALU latency.
 //
 // Every kernel exists in a GENERIC form (LDS offsets and model sizes are runtime values in SGPRs) and in
 // per-model SPECIALISED forms (dsim_static_layouts.hpp: offsets are instruction immediates, sizes are
