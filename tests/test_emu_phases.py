@@ -101,3 +101,18 @@ def test_quaternion_radial_component_is_the_whole_operator_level_deviation(env):
         diff[:, sl] = 0.0
     assert np.abs(diff).max() < 1e-4 * scale                              # every other coordinate: no projection needed
     print("%s: reference's radial quaternion cotangent, max |.| / max |gq| = %.3f" % (env, rad_ref_norm / scale))
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_first_substep_intermediates_vs_reference(env):
+    """The forward intermediates of the first substep -- X_sc, S, v, a, world inertias, f_tot, qdd -- as the forward pass
+    leaves them in the checkpoint, against the reference's own recording of the same substep (not only the boundary tensors).
+    tests/test_gpu_parity.py runs the same comparison on what the hipcc-compiled kernels wrote."""
+    from ckpt_fields import BOUNDS, compare_with_reference, first_substep
+    t = template_from_golden(env)
+    g = golden(env + "_step")
+    _, _, ck = emu_forward(t, g["q_in"], g["qd_in"], g["act_in"], g.get("muscle_act_in"), float(g["dt"]), int(g["substeps"]),
+                           int(g["mm_freq"]), want_ckpt=True)
+    err = compare_with_reference(t, first_substep(t, ck), g, relerr)
+    for k, e in err.items():
+        assert e < BOUNDS[k], (k, e)

@@ -167,6 +167,21 @@ def test_specialised_kernels_match_generic(env, dev, monkeypatch):
         assert relerr(a[k], b[k]) < 1e-5, k
 
 
+@pytest.mark.parametrize("env", ENVS)
+def test_first_substep_intermediates_vs_reference(env, dev):
+    """Not only boundary tensors: the forward intermediates of the first substep (X_sc, S, v, a, world inertias, f_tot,
+    qdd), read back from the checkpoint the HIP forward kernel wrote, against the reference's recording of that substep --
+    the per-phase quantities as hipcc compiled them (contraction, scheduling), not as the host harness computes them."""
+    from ckpt_fields import BOUNDS, compare_with_reference, first_substep
+    t, eng = _engine(env, dev)
+    g = golden(env + "_step")
+    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
+    r = _run(eng, dev, g["q_in"], g["qd_in"], g["act_in"], g.get("muscle_act_in"), dt, S, mm, g["gq_out"], g["gqd_out"])
+    err = compare_with_reference(t, first_substep(t, r["ckpt"]), g, relerr)
+    for k, e in err.items():
+        assert e < BOUNDS[k], (k, e)
+
+
 @pytest.mark.parametrize("env", ["ant", "humanoid", "hopper", "cheetah"])
 def test_helper_wave_kernels_match_single_wave(env, dev, monkeypatch):
     """Models with ground contacts run with a helper wavefront per environment while all environments of a launch are
