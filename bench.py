@@ -102,15 +102,111 @@ def time_backward_kernel(env, name, n, H, reps, device):
     return t_bwd
 
 
-def measure_other_config(name, n, H, mm, device, steps=2):
-    """fwd+adjoint env-steps/s of another BASELINE.json configuration on this GPU: the same rollout (H x DFlexEnv.step, loss =
-    -sum(rew), one backward), captured as a HIP graph, `steps` timed replays after one warm-up; adjoint / forward kernel
-    times by HIP events.  Informational: the headline `value` is the workload named in config.workload."""
+def pmc_record(name, n, mm):
+    """the committed counter record (profiles/*_pmc.json, tools/profile.sh + tools/make_profile_record.py) that was measured
+    at THESE kernel sources (csrc hash), this environment, N and mass-matrix frequency -- or None.  rocprofv3 cannot run
+    inside this process, so counters are quoted from the tracked files and only when they describe the kernels being timed."""
+    try:
+        h = csrc_hash()
+        for f in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")), reverse=True):
+            pmc = json.load(open(os.path.join(ROOT, "profiles", f)))
+            if (pmc.get("env", "ant") == name and pmc.get("n_envs", 1024) == n and pmc.get("mm_freq", MM_FREQ[name]) == mm
+                    and pmc.get("csrc_hash") == h):
+                pmc["file"] = "profiles/" + f
+                return pmc
+    except Exception:
+        pass
+    return None
+
+
+SIMDS = 1024            # MI355X: 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+FP32_VALU_PEAK = 157.3e12
+
+
+def issue_view(sq, n):
+    """VALU-issue view of one launch from its SQ counters (quad-cycles summed over the launch's wavefronts): one wave64 VALU
+    instruction occupies its SIMD's issue port for one quad-cycle, so busy fraction of the port = SQ_ACTIVE_INST_VALU per
+    occupied SIMD / lifetime of a wave (SQ_WAVE_CYCLES per wave).  None where a counter is missing."""
+    try:
+        waves = sq.get("SQ_WAVES") or None
+        out = {"valu_insts_per_env_step": sq["SQ_INSTS_VALU"] / n, "lds_insts_per_env_step": sq["SQ_INSTS_LDS"] / n}
+        if waves:
+            out["waves_per_env"] = waves / n
+            out["valu_issue_frac"] = (sq["SQ_ACTIVE_INST_VALU"] / min(SIMDS, waves)) / (sq["SQ_WAVE_CYCLES"] / waves)
+        if sq.get("SQ_THREAD_CYCLES_VALU"):
+            out["valu_active_lanes_avg"] = sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"]
+        return out
+    except Exception:
+        return None
+
+
+def roofline_record(env, name, n, H, mm, device, reps):
+    """roofline object of one configuration: times the adjoint and the forward launch with HIP events (same shapes as the
+    rollout), algorithmic bytes per SURVEY.md 8(d), and -- from the committed counter file of these very kernels -- measured HBM
+    traffic, VALU instructions per env-step and the VALU-issue fraction that actually bounds these kernels."""
+    t_bwd = time_backward_kernel(env, name, n, H, reps, device)
+    t_fwd = time_backward_kernel.fwd_s
+    nq, nd = env.num_joint_q, env.num_joint_qd
+    na_in = env.model.muscles_per_articulation if env.model.muscle_count else nd
+    # algorithmic bytes of ONE adjoint launch: re-read (q,qd,act) + read (gq',gqd') + write (gq,gqd,gact); one forward launch:
+    # read (q,qd,act) + write (q',qd')  (the fused kernels also move obs / reward rows; SURVEY's figure is kept)
+    bwd_bytes = 4 * n * ((nq + nd + na_in) + (nq + nd) + (nq + nd + na_in))
+    fwd_bytes = 4 * n * ((nq + nd + na_in) + (nq + nd))
+    achieved = bwd_bytes / t_bwd / 1e9
+    eng = env.model.engine()
+    ckpt_floats = int(eng._lib.dsim_ckpt_floats_mm(eng._h, env.sim_substeps, mm))
+    traffic = 4 * n * ckpt_floats + bwd_bytes
+    traffic_src = "analytic: checkpoint words x N x 4 + boundary tensors (no counter file for these kernel sources)"
+    pmc = pmc_record(name, n, mm)
+    r = {"bound": "valu-issue", "kernel": "dsim_env_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "alg_bytes_per_launch": bwd_bytes, "kernel_ms": t_bwd * 1e3,
+         "fwd_kernel_ms": t_fwd * 1e3, "fwd_alg_bytes_per_launch": fwd_bytes, "csrc_hash": csrc_hash(),
+         "ckpt_bytes_per_env_step": 4 * ckpt_floats, "ckpt_bytes_per_rollout": 4 * ckpt_floats * n * H,
+         "valu_issue_frac": None, "fwd_valu_issue_frac": None, "valu_insts_per_env_step": None,
+         "note": "achieved / frac: ALGORITHMIC bytes of the adjoint launch against the HBM peak, as BASELINE.json asks -- not what "
+                 "binds these kernels (~1,900 flop per algorithmic byte, SURVEY 8d).  bound: the VALU issue port of the SIMD an "
+                 "environment's wavefronts run on; valu_issue_frac = busy fraction of that port (1.0 = an instruction every "
+                 "4 cycles), hbm_measured_frac = counter traffic / kernel time / 8 TB/s (the traffic is the saved forward "
+                 "block the adjoint reads back instead of recomputing, DESIGN.md section 4)"}
+    if pmc:
+        traffic, traffic_src = pmc["traffic_bytes_per_launch"], "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), " + pmc["file"]
+        r["counters"] = pmc["file"]
+        b, f = issue_view(pmc.get("sq_adjoint") or {}, n), issue_view(pmc.get("sq_forward") or {}, n)
+        if b:
+            r["valu_issue_frac"] = b.get("valu_issue_frac")
+            r["adjoint"] = b
+        if f:
+            r["fwd_valu_issue_frac"] = f.get("valu_issue_frac")
+            r["forward"] = f
+        if b and f:
+            r["valu_insts_per_env_step"] = b["valu_insts_per_env_step"] + f["valu_insts_per_env_step"]
+            lanes = [x.get("valu_active_lanes_avg") for x in (b, f)]
+            if all(lanes):
+                # fp32 vector-ALU view: lane-operations actually executed (instructions x active lanes), each counted as one
+                # FMA = 2 flop (an upper bound: moves, compares and selects are VALU instructions too), against the packed-
+                # fp32 vector peak
+                ops = n * (b["valu_insts_per_env_step"] * lanes[0] + f["valu_insts_per_env_step"] * lanes[1])
+                r["fp32_valu_frac_est"] = 2.0 * ops / (t_bwd + t_fwd) / FP32_VALU_PEAK
+        wf = (pmc.get("forward_kernel") or {}).get("traffic_bytes_per_launch")
+        if wf:
+            r["fwd_hbm_measured_frac"] = wf / t_fwd / (HBM_PEAK_GBS * 1e9)
+    r["traffic"], r["traffic_source"] = traffic, traffic_src
+    r["hbm_measured_frac"] = traffic / t_bwd / (HBM_PEAK_GBS * 1e9)
+    return r
+
+
+def measure_other_config(name, n, H, mm, device, steps=10, generic=False):
+    """fwd+adjoint env-steps/s of another BASELINE.json configuration on this GPU, measured like the headline: the same
+    rollout (H x DFlexEnv.step, loss = -sum(rew), one backward) captured as a HIP graph, `steps` timed replays after two
+    warm-up replays, and its own roofline object (kernel times by HIP events, counters from the matching profiles/ file)."""
     saved = MM_FREQ[name]
     MM_FREQ[name] = mm
+    if generic:
+        os.environ["DSIM_FORCE_GENERIC"] = "1"   # read by dsim_model_create (diffrl_amd/csrc/dsim_hip.hip: match_variant)
     try:
         from diffrl_amd.graph import GraphedRollout
         env = make_env(name, n, str(device))
+        assert (env.model.engine().variant == 0) == bool(generic)
         gen = torch.Generator().manual_seed(1)
         actions = torch.tanh(2.0 * torch.rand((H, n, env.num_actions), generator=gen) - 1.0).to(device)
         acts = actions.detach().clone().requires_grad_(True)
@@ -122,7 +218,8 @@ def measure_other_config(name, n, H, mm, device, steps=2):
         env.clear_grad()
         env.reset()
         roll = GraphedRollout(env, body, leaves=[acts], carry_state=False)
-        roll.replay()
+        for _ in range(2):
+            roll.replay()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -130,16 +227,17 @@ def measure_other_config(name, n, H, mm, device, steps=2):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         assert torch.isfinite(acts.grad).all()
-        t_bwd = time_backward_kernel(env, name, n, H, 10, device)
-        eng = env.model.engine()
+        rf = roofline_record(env, name, n, H, mm, device, 20)
         return {"workload": "%s %d envs x H=%d, MM_caching_frequency %d" % (name, n, H, mm), "value": steps * n * H / el,
-                "unit": "env-steps/s", "ms_per_rollout": el / steps * 1e3, "kernel_ms": t_bwd * 1e3,
-                "fwd_kernel_ms": time_backward_kernel.fwd_s * 1e3,
-                "ckpt_bytes_per_env_step": 4 * int(eng._lib.dsim_ckpt_floats_mm(eng._h, env.sim_substeps, mm))}
+                "unit": "env-steps/s", "steps": steps, "ms_per_rollout": el / steps * 1e3, "kernel_ms": rf["kernel_ms"],
+                "fwd_kernel_ms": rf["fwd_kernel_ms"], "ckpt_bytes_per_env_step": rf["ckpt_bytes_per_env_step"],
+                "kernels": "generic (run-time layout)" if generic else "specialised (compile-time layout)", "roofline": rf}
     except Exception as ex:
         return {"workload": "%s %d envs x H=%d" % (name, n, H), "value": None, "error": str(ex)[:200]}
     finally:
         MM_FREQ[name] = saved
+        if generic:
+            os.environ.pop("DSIM_FORCE_GENERIC", None)
 
 
 def cpu_baseline(name, budget_s=12.0):
@@ -179,6 +277,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short measurements of the other BASELINE.json configurations (Humanoid 1024 x 32, SNUHumanoid "
                          "512 x 32, Ant with MM_caching_frequency 1) that the default single-GPU Ant run appends as `other_configs`")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the informational legs (Python-driven eager loop, forward-only no-grad loop): under rocprofv3 every "
+                         "launch of a kernel is then a launch of the timed rollout or of the kernel timing (tools/profile.sh)")
     ap.add_argument("--eager", action="store_true", help="time the Python-driven step loop instead of the graph replay")
     ap.add_argument("--strict", action="store_true", help="exit non-zero if the graph capture fell back to the eager loop")
     ap.add_argument("--launcher", action="store_true",
@@ -329,7 +430,7 @@ def main(argv=None):
     total_env_steps = a.steps * world * n * H
     value = total_env_steps / el
     eager_value = None
-    if roll is not None and rank == 0:
+    if roll is not None and rank == 0 and not a.no_extras:
         # the same rollouts driven step by step from Python (what a caller that does not capture gets)
         env2 = make_env(a.env, n, str(device))
         for _ in range(2):
@@ -343,30 +444,8 @@ def main(argv=None):
         del env2
 
     if rank == 0:
-        t_bwd = time_backward_kernel(env, a.env, n, H, 50, device)
-        # algorithmic bytes of ONE adjoint launch: re-read (q,qd,act) + read (gq',gqd') + write (gq,gqd,gact)
-        # (the fused kernel additionally reads the obs/reward cotangents; not counted, SURVEY's figure is kept)
-        nq, nd = env.num_joint_q, env.num_joint_qd
-        na_in = env.model.muscles_per_articulation if env.model.muscle_count else nd
-        bwd_bytes = 4 * n * ((nq + nd + na_in) + (nq + nd) + (nq + nd + na_in))
-        achieved = bwd_bytes / t_bwd / 1e9
-        # HBM bytes of one adjoint launch.  Measured: the committed PMC passes (rocprofv3 cannot run inside this process),
-        # valid only for the kernel sources they were taken at (csrc hash) and for that env / N.  Otherwise the analytic
-        # figure: the adjoint reads its whole checkpoint (dsim_ckpt_floats_mm floats per environment) plus the boundary tensors.
+        rf = roofline_record(env, a.env, n, H, mm, device, 50)
         eng = env.model.engine()
-        ckpt_floats = int(eng._lib.dsim_ckpt_floats_mm(eng._h, env.sim_substeps, mm))
-        traffic_analytic = 4 * n * ckpt_floats + bwd_bytes
-        traffic, traffic_src = traffic_analytic, "analytic: checkpoint words x N x 4 + boundary tensors"
-        try:
-            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
-            for f in reversed(pmcs):
-                pmc = json.load(open(os.path.join(ROOT, "profiles", f)))
-                if (pmc.get("env", "ant") == a.env and pmc.get("n_envs", 1024) == n and pmc.get("mm_freq", MM_FREQ[a.env]) == mm
-                        and pmc.get("csrc_hash") == csrc_hash()):
-                    traffic, traffic_src = pmc["traffic_bytes_per_launch"], "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/" + f
-                    break
-        except Exception:
-            pass
         out = {
             "metric": "fwd+adjoint env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "rccl_ranks": rccl_ranks,
@@ -378,30 +457,22 @@ def main(argv=None):
                        "mm_freq": mm, "sharding": "envs by index, no collective", "submission": submission,
                        "submission_fallback": fallback},
             "eager_env_steps_per_s": eager_value,
-            "roofline": {"bound": "hbm", "kernel": "dsim_env_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "csrc_hash": csrc_hash(), "ckpt_bytes_per_env_step": 4 * ckpt_floats,
-                         "ckpt_bytes_per_rollout": 4 * ckpt_floats * n * H,
-                         "kernel_ms": t_bwd * 1e3, "fwd_kernel_ms": time_backward_kernel.fwd_s * 1e3,
-                         "alg_bytes_per_launch": bwd_bytes,
-                         "note": "fused kernel is VALU/latency-bound by construction (SURVEY 8d); traffic >> algorithmic bytes on purpose: "
-                                 "the saved forward block the adjoint reads back instead of recomputing, see DESIGN.md section 4"},
-            # fp32 vector-ALU view of the same launch pair (SURVEY 8d asks for it next to the HBM fraction): ~1.2 MFLOP per
-            # Ant env-step fwd+adjoint (SURVEY's op-count estimate) against the 157.3 TFLOP/s fp32 vector peak
-            "fp32_valu_frac_est": (1.2e6 * n / (t_bwd + time_backward_kernel.fwd_s)) / 157.3e12 if a.env == "ant" else None,
+            "roofline": rf,
+            "fp32_valu_frac_est": rf.get("fp32_valu_frac_est"),
         }
         # forward-only serving path (dflex.config.no_grad: no checkpoint traffic), SURVEY.md 8(f).4 -- informational
-        with torch.no_grad():
-            spec = env._spec()
-            q, qd = env.state.joint_q.detach().clone(), env.state.joint_qd.detach().clone()
-            for _ in range(5):
-                eng.env_forward(spec, q, qd, actions[0], env.sim_dt, env.sim_substeps, mm, False)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for t in range(100):
-                q, qd, _, _, _ = eng.env_forward(spec, q, qd, actions[t % H], env.sim_dt, env.sim_substeps, mm, False)
-            torch.cuda.synchronize()
-            out["no_grad_forward_env_steps_per_s"] = 100 * n / (time.perf_counter() - t0)
+        if not a.no_extras:
+            with torch.no_grad():
+                spec = env._spec()
+                q, qd = env.state.joint_q.detach().clone(), env.state.joint_qd.detach().clone()
+                for _ in range(5):
+                    eng.env_forward(spec, q, qd, actions[0], env.sim_dt, env.sim_substeps, mm, False)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for t in range(100):
+                    q, qd, _, _, _ = eng.env_forward(spec, q, qd, actions[t % H], env.sim_dt, env.sim_substeps, mm, False)
+                torch.cuda.synchronize()
+                out["no_grad_forward_env_steps_per_s"] = 100 * n / (time.perf_counter() - t0)
         if not a.no_other_configs and world == 1 and a.env == "ant" and not a.eager:
             # BASELINE.json configs[2], configs[3] and the MM_caching_frequency = 1 variant of configs[1] (SURVEY.md 8(d):
             # "also report 1"), each a few seconds: driver-visible numbers next to the headline
@@ -410,7 +481,10 @@ def main(argv=None):
             torch.cuda.empty_cache()
             out["other_configs"] = [measure_other_config("humanoid", 1024, H, MM_FREQ["humanoid"], device),
                                     measure_other_config("snu", 512, H, MM_FREQ["snu"], device),
-                                    measure_other_config("ant", n, H, 1, device)]
+                                    measure_other_config("ant", n, H, 1, device),
+                                    # the headline workload on the GENERIC kernels (run-time layout: what a user model that
+                                    # matches no specialised kernel set gets; tools/gen_static_layouts.py adds a set)
+                                    measure_other_config("ant", n, H, MM_FREQ["ant"], device, generic=True)]
         if not a.no_cpu_baseline and world == 1:   # reported at N = 1 only (the host cores are the same for every N)
             out["cpu_baseline"] = cpu_baseline(a.env)
         print(json.dumps(out))

@@ -55,6 +55,7 @@ class Episode(C.Structure):
 
 ENV_LOCOMOTION, ENV_CARTPOLE, ENV_PLANAR = 1, 2, 3
 CKPT_FULL, CKPT_LEAN = 0, 1
+OK, ERR_INVALID, ERR_HIP, ERR_LIMIT = 0, -1, -2, -3   # include/dsim.h: DSIM_OK, DSIM_ERR_*
 REW_ANT, REW_HUMANOID, REW_SNU, REW_CARTPOLE, REW_HOPPER, REW_CHEETAH = 0, 1, 2, 3, 4, 5
 
 
@@ -110,7 +111,7 @@ class DsimError(RuntimeError):
 
 
 _lib = None
-EXPECTED_ABI = 103   # dsim_version() of the library this binding was written against (argument lists of include/dsim.h)
+EXPECTED_ABI = 104   # dsim_version() of the library this binding was written against (argument lists of include/dsim.h)
 
 
 def lib():
@@ -133,6 +134,8 @@ def lib():
     L.dsim_model_destroy.argtypes = [vp]
     L.dsim_model_variant.argtypes = [vp]
     L.dsim_model_variant.restype = C.c_int
+    L.dsim_model_device.argtypes = [vp]
+    L.dsim_model_device.restype = C.c_int
     L.dsim_ckpt_floats.argtypes = [vp, C.c_int]
     L.dsim_ckpt_floats.restype = C.c_int64
     L.dsim_ckpt_floats_mm.argtypes = [vp, C.c_int, C.c_int]
@@ -160,7 +163,7 @@ def check(rc):
         raise DsimError("dsim error %d: %s" % (rc, lib().dsim_last_error().decode()))
 
 
-EXPORTS = ("dsim_last_error", "dsim_version", "dsim_model_create", "dsim_model_destroy", "dsim_model_variant",
+EXPORTS = ("dsim_last_error", "dsim_version", "dsim_model_create", "dsim_model_destroy", "dsim_model_variant", "dsim_model_device",
            "dsim_ckpt_floats", "dsim_ckpt_floats_mm", "dsim_model_set_ckpt_mode",
            "dsim_step_forward", "dsim_step_backward", "dsim_env_step_forward", "dsim_env_step_backward",
            "dsim_env_observe")

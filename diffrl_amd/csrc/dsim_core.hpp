@@ -200,6 +200,10 @@ template <class Ctx, class Exec> DSIM_FN void dsim_init_static(const Ctx& c, Exe
 // LDS tables once per launch (dsim_topo_init) instead of as an index -> record -> data chain of three dependent LDS round
 // trips per position in every substep.
 #define DSIM_CHAIN_MAX 10
+#define DSIM_SCAN_ROUNDS_MAX 4   // log-depth kinematics: trees of up to 16 levels
+#ifndef DSIM_SCAN_MIN_DEPTH
+#define DSIM_SCAN_MIN_DEPTH 5    // ... used from this many levels on (-DDSIM_SCAN_MIN_DEPTH=99 builds the A/B variant without it)
+#endif
 #define DSIM_TR_PASSES 2   // passes of the light items of a trunk-decomposed model over one wavefront
 // Per-lane topology records kept in REGISTERS by the specialised kernels (the executor owns one per lane).  A lane plays
 // the same roles in every substep -- link `lane`, dof `lane`, contact `lane` (forward) or `63 - lane` (adjoint) -- and the
@@ -221,6 +225,7 @@ struct DsimTopoRegs {
     int ta_top[DSIM_TR_PASSES], ta_tp[DSIM_TR_PASSES], ta_m[DSIM_TR_PASSES], tu_d[DSIM_TR_PASSES];
     float tw_l[DSIM_TR_PASSES][DSIM_LIGHT_CAP], tw_c[DSIM_TR_PASSES][DSIM_LIGHT_CAP];   // 1 / 0 weights of the light sums' entries (adjoint kernels)
     int adof[16], adof_n;                    // dofs of the ancestors-or-self of link `(63 - lane) / 6` (adjoint of tau)
+    int jmp[DSIM_SCAN_ROUNDS_MAX];           // ancestor of link `lane` at distance 2^r (-1: none): log-depth kinematics (DsimScanFk)
 };
 template <class Ctx> struct DsimChainRegs {
     static constexpr bool value = []() {
@@ -276,12 +281,34 @@ template <class Ctx, int NL> struct DsimContactRegs {  // contact `lane` / `63 -
         else return false;
     }();
 };
+// Log-depth forward kinematics (dsim_fwd_kinematics_scan) instead of the per-lane chain walk: specialised kernels with one
+// wavefront per environment, trees of DSIM_SCAN_MIN_DEPTH levels or more.  A walk costs every lane (and, SIMD-wise, the
+// whole wave) `levels` chain positions of ~130 instructions; composing the links' LOCAL transforms along the ancestor chains
+// by pointer jumping costs ceil(log2(levels)) rounds of ~45 (Humanoid: 10 positions -> 4 rounds), and the twists and bias
+// accelerations are prefix sums over the same chains.  Contacts then read the finished poses / twists of their bodies.
+template <class Ctx, int NL> struct DsimScanFk {
+    static constexpr bool value = []() {
+        if constexpr (std::is_empty<decltype(Ctx::d)>::value) {
+            using D = decltype(Ctx::d);
+            return NL == DSIM_NL && D::L <= NL && D::nd <= NL && D::C <= NL && D::D >= DSIM_SCAN_MIN_DEPTH &&
+                   D::D <= (1 << DSIM_SCAN_ROUNDS_MAX);
+        } else {
+            return false;
+        }
+    }();
+};
+constexpr int dsim_scan_rounds(int levels) {
+    int r = 0;
+    while ((1 << r) < levels) ++r;
+    return r;
+}
 // Contacts evaluated INSIDE the kinematics phase: lane L + k walks the ancestor chain of contact k's body next to the link
 // lanes (same instruction stream, so the walk costs nothing extra) and evaluates its contact from the pose and twist it
 // holds in registers -- no phase boundary, no reload of X_sc / v.  Needs the chain records and L + C lanes.
 template <class Ctx, int NL> struct DsimContactsInKin {
     static constexpr bool value = []() {
-        if constexpr (DsimChainRegs<Ctx>::value) return decltype(Ctx::d)::C > 0 && decltype(Ctx::d)::L + decltype(Ctx::d)::C <= NL;
+        if constexpr (DsimScanFk<Ctx, NL>::value) return false;   // they read the finished poses instead
+        else if constexpr (DsimChainRegs<Ctx>::value) return decltype(Ctx::d)::C > 0 && decltype(Ctx::d)::L + decltype(Ctx::d)::C <= NL;
         else return false;
     }();
 };
@@ -330,7 +357,16 @@ template <class Ctx, class Exec> DSIM_FN void dsim_topo_init(const Ctx& c, Exec&
             tp.tu_d[p] = (CI(qdstart)[i + 1] > CI(qdstart)[i]) ? CI(qdstart)[i] : -1;
         }
     }
-    if constexpr (DsimChainRegs<Ctx>::value) {
+    if constexpr (DsimScanFk<Ctx, Exec::NL>::value) {
+        DsimTopoRegs& tp = ex.topo(lane);
+        const int i = lane < c.d.L ? lane : 0;
+        const int e0 = CI(anc_start)[i], e1 = CI(anc_start)[i + 1];   // ancestors-or-self, root first
+#pragma unroll
+        for (int r = 0; r < DSIM_SCAN_ROUNDS_MAX; ++r) {
+            const int dist = 1 << r;
+            tp.jmp[r] = (lane < c.d.L && e1 - e0 > dist) ? CI(anc_list)[e1 - 1 - dist] : -1;
+        }
+    } else if constexpr (DsimChainRegs<Ctx>::value) {
         constexpr int DEPTH = decltype(c.d)::D;
         int* ch = ex.topo(lane).chain;
         int i = lane < c.d.L ? lane : 0;
@@ -631,8 +667,207 @@ template <int MASK, bool FIRST, bool IDENT> DSIM_FN void dsim_fk_compute(DsimFkW
     w.rsp = rc;
 }
 
+// ground contacts of this lane from the finished pose and twist of their bodies in LDS (sim.py:1137-1206)
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_contacts(const Ctx& c, Exec& ex, int lane) {
+    for (int k = lane; k < c.d.C; k += Exec::NL) {
+        int b;
+        if constexpr (DsimContactRegs<Ctx, Exec::NL>::value) b = ex.topo(lane).cbody_f;
+        else b = CI(cbody)[k];
+        const v3 xp = ld3(WF(xsc) + 7 * b);
+        const q4 xq = ldq(WF(xsc) + 7 * b + 3);
+        const sv6 vb = ldsv(WF(v) + 6 * b);
+        stsv(WF(cw) + 6 * k, dsim_contact_wrench(dsim_contact_load(c, k), xp, xq, vb));
+    }
+}
+
+// Log-depth forward kinematics (DsimScanFk).  One lane per link, every lane executes every step (lanes past the last link
+// compute on link 0's inputs and store nothing): the rounds exchange their operands between lanes with ds_bpermute (Exec::shfl),
+// which needs uniform control flow, and the results go to LDS once -- poses, twists and bias accelerations as they become final:
+//   local    T_i = X_pj o X_jc(q_i), the transform from the parent's frame to the link's (sim.py:1269-1319)
+//   poses    R rounds of pointer jumping: T_i <- T_j o T_i with j the ancestor at distance 2^r; after ceil(log2(levels)) rounds
+//            T_i = X_sc[i] (sim.py:1638-1678 composes the same transforms root to leaf, one link after the other)
+//   S, v_j   motion subspace and joint twist from the link's own pose: a revolute / ball joint does not translate, so the joint
+//            frame's origin is the link's (p_sj = p_sc), and a rotation about the axis leaves the axis where it was
+//            (R_sc axis = R_sj axis); sim.py:1323-1387
+//   v        prefix sums of v_j over the ancestor chains (R rounds), then the bias term c_i = v_i x v_j,i per link and
+//   a        prefix sums of c (sim.py:1716-1763: v = v_parent + v_j, a = a_parent + v x v_j)
+// Same terms as the chain walk, associated differently (products of transforms pairwise instead of left to right, sums
+// likewise): not bit-identical to it; tests hold both to the reference's recording of the first substep (1e-5).
+// Between poses + twists and the rest, Exec::mid() lets the helper wavefront start on the contacts (fork_join_mid).
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_scan(const Ctx& c, Exec& ex) {
+    using D = decltype(c.d);
+    constexpr int L = D::L, R = dsim_scan_rounds(D::D), MASK = D::tmask;
+    constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
+    constexpr bool IDENT = (D::pident & ((1 << D::D) - 1)) == ((1 << D::D) - 1);   // every X_pj rotation is the identity
+    constexpr bool HAS_P = (MASK & DSIM_TM(DSIM_JOINT_PRISMATIC)) != 0, HAS_R = (MASK & DSIM_TM(DSIM_JOINT_REVOLUTE)) != 0,
+                   HAS_B = (MASK & DSIM_TM(DSIM_JOINT_BALL)) != 0, HAS_F = (MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0;
+    ex.fork_join_mid([&](int lane) {
+        const DsimTopoRegs& tp = ex.topo(lane);
+        const bool on = lane < L;
+        const int i = on ? lane : 0;
+        int type = tp.own_type;
+        DSIM_OPAQUE(type);
+        const int cs = tp.own_cs, ds = tp.own_ds;
+        // ---- every input of the phase in one round trip: joint constants and coordinates, body constants
+        const v3 ppj = ld3(CF(xpj) + 7 * i), axis = ld3(CF(axis) + 3 * i);
+        const q4 rpj = ldq(CF(xpj) + 7 * i + 3);
+        float qv[NQ > 0 ? NQ : 1], qdv[NDF > 0 ? NDF : 1];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) qv[k] = WF(q)[cs + k];
+#pragma unroll
+        for (int k = 0; k < NDF; ++k) qdv[k] = WF(qd)[ds + k];
+        const v3 com = ld3(CF(com) + 3 * i);
+        const float* icp = CF(ic6) + 6 * i;
+        const float ic0 = icp[0], ic1 = icp[1], ic2 = icp[2], ic3 = icp[3], ic4 = icp[4], ic5 = icp[5];
+        const float m = CF(mass)[i];
+        const v3 grav = ld3(CF(grav));
+        // ---- local transform
+        v3 p = ppj;
+        q4 r = rpj;
+        if constexpr (HAS_P) {
+            if (type == DSIM_JOINT_PRISMATIC) p = ppj + (IDENT ? axis * qv[0] : rotate(rpj, axis * qv[0]));
+        }
+        if constexpr (HAS_R) {
+            if (type == DSIM_JOINT_REVOLUTE) {
+                const q4 qa = quat_axis_angle(axis, qv[0]);
+                r = IDENT ? qa : qmul(rpj, qa);
+            }
+        }
+        if constexpr (HAS_B) {
+            if (type == DSIM_JOINT_BALL) {
+                const q4 qb = mkq(qv[0], qv[1], qv[2], qv[3]);
+                r = IDENT ? qb : qmul(rpj, qb);
+            }
+        }
+        if constexpr (HAS_F) {
+            if (type == DSIM_JOINT_FREE) {
+                const v3 pf = mk3(qv[0], qv[1], qv[2]);
+                const q4 qf = mkq(qv[3], qv[4], qv[5], qv[6]);
+                p = ppj + (IDENT ? pf : rotate(rpj, pf));
+                r = IDENT ? qf : qmul(rpj, qf);
+            }
+        }
+        // ---- poses: pointer jumping along the ancestor chains.  T_j travels from lane j by ds_bpermute (Exec::shfl): no LDS
+        // store, no store -> load ordering -- a round is seven cross-lane reads and one composition
+        dsim_static_for<0, R>([&](auto rr) {
+            int j = tp.jmp[decltype(rr)::value];
+            DSIM_OPAQUE(j);
+            const int src = j < 0 ? lane : j;
+            const v3 pa = mk3(ex.shfl(p.x, src), ex.shfl(p.y, src), ex.shfl(p.z, src));
+            const q4 ra = mkq(ex.shfl(r.x, src), ex.shfl(r.y, src), ex.shfl(r.z, src), ex.shfl(r.w, src));
+            if (j >= 0) {
+                p = rotate(ra, p) + pa;
+                r = qmul(ra, r);
+            }
+        });
+        if (on) {
+            st3(WF(xsc) + 7 * i, p);
+            stq(WF(xsc) + 7 * i + 3, r);
+        }
+        ex.stamp();
+        // ---- motion subspace and joint twist from the link's own pose
+        sv6 s0 = zerosv(), s1 = zerosv(), s2 = zerosv(), vj = zerosv();
+        if constexpr (HAS_B) {
+            // a ball joint's subspace is the joint frame's basis: R_sj = R_parent (x) R_pj
+            const int par = tp.own_parent, psrc = par < 0 ? lane : par;
+            const q4 rpar = mkq(ex.shfl(r.x, psrc), ex.shfl(r.y, psrc), ex.shfl(r.z, psrc), ex.shfl(r.w, psrc));
+            if (type == DSIM_JOINT_BALL) {
+                q4 rj = rpj;
+                if (par >= 0) rj = IDENT ? rpar : qmul(rpar, rpj);
+                v3 u0, u1, u2;
+                rotate_basis(rj, u0, u1, u2);
+                s0 = mksv(u0, cross(p, u0));
+                s1 = mksv(u1, cross(p, u1));
+                s2 = mksv(u2, cross(p, u2));
+                vj = s0 * qdv[0];
+                vj += s1 * qdv[1];
+                vj += s2 * qdv[2];
+            }
+        }
+        if constexpr (HAS_P) {
+            if (type == DSIM_JOINT_PRISMATIC) {
+                s0 = mksv(zero3(), rotate(r, axis));
+                vj = s0 * qdv[0];
+            }
+        }
+        if constexpr (HAS_R) {
+            if (type == DSIM_JOINT_REVOLUTE) {
+                const v3 u = rotate(r, axis);
+                s0 = mksv(u, cross(p, u));
+                vj = s0 * qdv[0];
+            }
+        }
+        if constexpr (HAS_F) {
+            if (type == DSIM_JOINT_FREE)   // S = identity (dsim_init_static)
+                vj = mksv(mk3(qdv[0], qdv[1], qdv[2]), mk3(qdv[3], qdv[4], qdv[5]));
+        }
+        // ---- twists: prefix sums of v_j along the chains
+        sv6 v = vj;
+        dsim_static_for<0, R>([&](auto rr) {
+            int j = tp.jmp[decltype(rr)::value];
+            DSIM_OPAQUE(j);
+            const int src = j < 0 ? lane : j;
+            const sv6 va = mksv(mk3(ex.shfl(v.w.x, src), ex.shfl(v.w.y, src), ex.shfl(v.w.z, src)),
+                                mk3(ex.shfl(v.v.x, src), ex.shfl(v.v.y, src), ex.shfl(v.v.z, src)));
+            if (j >= 0) v += va;
+        });
+        if (on) stsv(WF(v) + 6 * i, v);
+        ex.stamp();
+        ex.mid();   // X_sc and v of every link are final: the contacts may start
+        // ---- bias accelerations: c_i = v_i x v_j,i (exactly zero at the root: a vector crossed with itself), prefix sums in a
+        sv6 a = zerosv();
+        if (tp.own_level > 0) a = scross(v, vj);
+        dsim_static_for<0, R>([&](auto rr) {
+            int j = tp.jmp[decltype(rr)::value];
+            DSIM_OPAQUE(j);
+            const int src = j < 0 ? lane : j;
+            const sv6 aa = mksv(mk3(ex.shfl(a.w.x, src), ex.shfl(a.w.y, src), ex.shfl(a.w.z, src)),
+                                mk3(ex.shfl(a.v.x, src), ex.shfl(a.v.y, src), ex.shfl(a.v.z, src)));
+            if (j >= 0) a += aa;
+        });
+        if (on) stsv(WF(a) + 6 * i, a);
+        ex.stamp();
+        // ---- COM, world inertia about the origin (Theta = R Ic R^T, A = Theta + m(c.c 1 - c c^T), h = m c) and body force
+        const v3 cm = rotate(r, com) + p;
+        v3 rx, ry, rz;
+        rotate_basis(r, rx, ry, rz);
+        const v3 b0 = rx * ic0 + ry * ic1 + rz * ic2;
+        const v3 b1 = rx * ic1 + ry * ic3 + rz * ic4;
+        const v3 b2 = rx * ic2 + ry * ic4 + rz * ic5;
+        inertia10 I;
+        I.m = m;
+        I.h = cm * m;
+        const float cc = dot(cm, cm);
+        I.axx = b0.x * rx.x + b1.x * ry.x + b2.x * rz.x + m * (cc - cm.x * cm.x);
+        I.axy = b0.x * rx.y + b1.x * ry.y + b2.x * rz.y - m * cm.x * cm.y;
+        I.axz = b0.x * rx.z + b1.x * ry.z + b2.x * rz.z - m * cm.x * cm.z;
+        I.ayy = b0.y * rx.y + b1.y * ry.y + b2.y * rz.y + m * (cc - cm.y * cm.y);
+        I.ayz = b0.y * rx.z + b1.y * ry.z + b2.y * rz.z - m * cm.y * cm.z;
+        I.azz = b0.z * rx.z + b1.z * ry.z + b2.z * rz.z + m * (cc - cm.z * cm.z);
+        const sv6 fb = inertia_mul(I, a) + scross_dual(v, inertia_mul(I, v));
+        const v3 mg = grav * m;
+        const sv6 fg = mksv(cross(cm, mg), mg);
+        if (on) {
+            st_i10(WF(i10) + 10 * i, I);
+            stsv(WF(f) + 6 * i, fb - fg);
+            float* S = WF(S) + 6 * ds;
+            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
+                stsv(S, s0);
+            } else if (type == DSIM_JOINT_BALL) {
+                stsv(S, s0);
+                stsv(S + 6, s1);
+                stsv(S + 12, s2);
+            }
+        }
+    }, [&](int lane) { dsim_fwd_contacts(c, ex, lane); });
+}
+
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, Exec& ex) {
     ex.mark(1);
+    if constexpr (DsimScanFk<Ctx, Exec::NL>::value) {
+        dsim_fwd_kinematics_scan(c, ex);
+        return;
+    }
     // "Flat" forward kinematics: every link's lane walks its own ancestor chain from the root and recomputes the
     // joint transforms / twists on the way, instead of one barrier-separated phase per tree level (redundant
     // arithmetic, no per-level phase boundaries; same operations in the same order along each chain as the
@@ -759,20 +994,10 @@ template <class Ctx> DSIM_FN void dsim_muscle_chunk_sums(const Ctx& c, int lane,
 // ground contacts (sim.py:1137-1206) and muscle segments (sim.py:1209-1242): per-item wrenches
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Exec& ex) {
     ex.mark(2);
-    constexpr bool in_kin = DsimContactsInKin<Ctx, Exec::NL>::value;  // contacts were done by the kinematics phase
+    constexpr bool in_kin = DsimContactsInKin<Ctx, Exec::NL>::value || DsimScanFk<Ctx, Exec::NL>::value;  // contacts were done by the kinematics phase
     if ((c.d.C == 0 || in_kin) && c.d.NS == 0) return;
     ex.run([&](int lane) {
-        if constexpr (!in_kin) {
-            for (int k = lane; k < c.d.C; k += Exec::NL) {
-                int b;
-                if constexpr (DsimContactRegs<Ctx, Exec::NL>::value) b = ex.topo(lane).cbody_f;
-                else b = CI(cbody)[k];
-                const v3 xp = ld3(WF(xsc) + 7 * b);
-                const q4 xq = ldq(WF(xsc) + 7 * b + 3);
-                const sv6 vb = ldsv(WF(v) + 6 * b);
-                stsv(WF(cw) + 6 * k, dsim_contact_wrench(dsim_contact_load(c, k), xp, xq, vb));
-            }
-        }
+        if constexpr (!in_kin) dsim_fwd_contacts(c, ex, lane);
         for (int s = lane; s < c.d.NS; s += Exec::NL) {
             const int w = CI(seg_wp)[s];
             const int l0 = CI(mlinks)[w], l1 = CI(mlinks)[w + 1];
@@ -879,6 +1104,11 @@ DSIM_FN float dsim_subtree_contact_sum(const Ctx& c, Exec& ex, int lane, int i, 
 // WEIGHTS: the entries of a light sum are multiplied by per-lane 1 / 0 registers (dsim_range_sum_m's trick: one fused
 // multiply-add per entry instead of compare + select + add); the adjoint kernels have the registers for it (three such sums
 // per substep), the forward kernel of the humanoid (one sum, 233 VGPRs already) keeps the selects.
+template <class D> constexpr int dsim_trunk_pos(int link) {   // position of `link` in the trunk list, -1: a light link
+    for (int u = 0; u < D::NT; ++u)
+        if (D::trunk[u] == link) return u;
+    return -1;
+}
 template <bool WEIGHTS, class Ctx, class Exec>
 DSIM_FN void dsim_trunk_sum(const Ctx& c, Exec& ex, int lane, const float* ldata, const float* cdata, int cstride, int coff,
                             float* out) {
@@ -918,20 +1148,32 @@ DSIM_FN void dsim_trunk_sum(const Ctx& c, Exec& ex, int lane, const float* ldata
         if (row >= 0) out[row] = acc;
     }
     ex.lds_fence();
-    dsim_static_for<0, D::NT>([&](auto uu) {
-        constexpr int u = D::NT - 1 - decltype(uu)::value, t = D::trunk[u];
-        if (lane < 6) {
+    // trunk links, deepest first, component `lane` on lanes 0..5.  The sum of a trunk child is carried in a REGISTER (ts), so
+    // the chain root <- ... <- deepest trunk link is register arithmetic and everything it reads from LDS -- own rows, own
+    // contacts, finished sums of the light children -- is independent of it: one LDS round trip for the whole trunk instead
+    // of one per trunk link (the humanoid's four: ~250 cycles each, in four sums per env-substep).  Same terms, same order.
+    if (lane < 6) {
+        float ts[D::NT];
+        dsim_static_for<0, D::NT>([&](auto uu) {
+            constexpr int u = D::NT - 1 - decltype(uu)::value, t = D::trunk[u];
             float acc = ldata[6 * t + lane];
             if (cdata) {
 #pragma unroll
                 for (int e = 0; e < D::tr_ncb[u]; ++e) acc += cdata[cstride * (D::tr_cb0[u] + e) + coff + lane];
             }
-#pragma unroll
-            for (int e = 0; e < D::tr_nch[u]; ++e) acc += out[6 * D::tr_ch[DSIM_TRUNK_CH * u + e] + lane];
+            dsim_static_for<0, DSIM_TRUNK_CH>([&](auto ee) {
+                constexpr int e = decltype(ee)::value;
+                if constexpr (e < D::tr_nch[u]) {
+                    constexpr int ch = D::tr_ch[DSIM_TRUNK_CH * u + e], pos = dsim_trunk_pos<D>(ch);
+                    if constexpr (pos >= 0) acc += ts[pos];
+                    else acc += out[6 * ch + lane];
+                }
+            });
+            ts[u] = acc;
             out[6 * t + lane] = acc;
-        }
-        ex.lds_fence();
-    });
+        });
+    }
+    ex.lds_fence();
 }
 
 // joint-space forces (sim.py:1421-1502, 1792-1842)
@@ -1123,6 +1365,36 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_integrate(const Ctx& c, E
     });
 }
 
+// checkpoint row of a substep: the saved block in LDS -> this environment's row in global memory, 16 bytes per lane and
+// instruction.  Specialised kernels: the row length is a compile-time constant, so the copy is unrolled -- ALL the LDS reads
+// are issued first, then the stores (the run-time loop it replaces waited for every read before its store: five LDS
+// latencies in a row for the humanoid's 259 16-byte words).
+typedef float __attribute__((vector_size(16), may_alias)) dsim_vec4;   // a native vector: stays in registers (an array of the
+                                                                         // may_alias STRUCT dsim_f4 went to scratch memory)
+template <class Ctx, int NL> DSIM_FN void dsim_ckpt_store_row(const Ctx& c, int lane, float* g_row) {
+    if constexpr (DsimIsStatic<Ctx>::value) {
+        using O = decltype(c.o);
+        constexpr int W4 = (Ctx::LEAN ? O::xsc - O::q : O::save_words) / 4, IT = (W4 + NL - 1) / NL;
+        const dsim_vec4* src = reinterpret_cast<const dsim_vec4*>(WF(q));
+        dsim_vec4* dst = reinterpret_cast<dsim_vec4*>(g_row);
+        dsim_vec4 x[IT];
+#pragma unroll
+        for (int r = 0; r < IT; ++r) {
+            const int k = lane + NL * r;
+            if (k < W4) x[r] = src[k];
+        }
+#pragma unroll
+        for (int r = 0; r < IT; ++r) {
+            const int k = lane + NL * r;
+            if (k < W4) dst[k] = x[r];
+        }
+    } else {
+        const dsim_f4* src = reinterpret_cast<const dsim_f4*>(WF(q));
+        dsim_f4* dst = reinterpret_cast<dsim_f4*>(g_row);
+        for (int k = lane; k < dsim_row(c) / 4; k += NL) dst[k] = src[k];
+    }
+}
+
 // ---- forward dynamics of a substep in ONE phase (small models, one wavefront per environment) -----------------------------
 // f_tot (subtree sums) -> tau -> qdd = H^-1 tau -> checkpoint copy -> integrate used to be four phases whose only
 // connection is a handful of values that change lanes: the 6 components of f_tot[link(d)] go from the (link, component)
@@ -1180,6 +1452,7 @@ DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float*
             ft = dsim_subtree_contact_sum(c, ex, lane, lane / 6, WF(f), lane - 6 * (lane / 6), WF(cw), 6, lane - 6 * (lane / 6));
             WF(ftot)[lane] = ft;   // the adjoint reads it from the checkpoint
         }
+        ex.stamp();
         // ---- f_tot[link(d)] -> dof lane d
         sv6 F;
         F.w.x = ex.shfl(ft, 6 * di + 0); F.w.y = ex.shfl(ft, 6 * di + 1); F.w.z = ex.shfl(ft, 6 * di + 2);
@@ -1202,6 +1475,7 @@ DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float*
             WF(tau)[lane] = t;
             WF(qdd)[lane] = acc;
         }
+        ex.stamp();
         // ---- qdd of a link's dofs -> the link's lane
         float av[NDF > 0 ? NDF : 1];
 #pragma unroll
@@ -1209,13 +1483,12 @@ DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float*
         // ---- checkpoint row (needs f_tot and qdd of all lanes in LDS, and q / qd before integrate overwrites them)
         if (g_row) {
             ex.lds_fence();
-            const dsim_f4* src = reinterpret_cast<const dsim_f4*>(WF(q));
-            dsim_f4* dst = reinterpret_cast<dsim_f4*>(g_row);
-            for (int k = lane; k < dsim_row(c) / 4; k += Exec::NL) dst[k] = src[k];
+            dsim_ckpt_store_row<Ctx, Exec::NL>(c, lane, g_row);
             if (update_mass && g_hinv)
                 for (int k = lane; k < nd * nd; k += Exec::NL) g_hinv[k] = WF(hinv)[k];
             ex.lds_fence();
         }
+        ex.stamp();
         // ---- link role: semi-implicit Euler (sim.py:1505-1636), in place on q, qd
         if (is_link) {
             float *q = WF(q), *qd = WF(qd);
@@ -1291,9 +1564,7 @@ DSIM_FN void dsim_fwd_substep(const Ctx& c, Exec& ex, bool update_mass, float* g
         // reads back: no wait -- they drain while the step goes on (16 bytes per lane and instruction: the saved block
         // and a checkpoint row are 16-byte aligned multiples of 4 words).
         ex.fire([&](int lane) {
-            const dsim_f4* src = reinterpret_cast<const dsim_f4*>(WF(q));
-            dsim_f4* dst = reinterpret_cast<dsim_f4*>(g_row);
-            for (int k = lane; k < dsim_row(c) / 4; k += Exec::NL) dst[k] = src[k];
+            dsim_ckpt_store_row<Ctx, Exec::NL>(c, lane, g_row);
             if (update_mass && g_hinv)
                 for (int k = lane; k < c.d.nd * c.d.nd; k += Exec::NL) g_hinv[k] = WF(hinv)[k];
         });

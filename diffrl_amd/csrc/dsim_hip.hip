@@ -121,7 +121,27 @@ template <int NW, int CW> struct DsimImage {
 // can only execute one after the other.  Unlike NW > 1 (every wave runs every phase on its share of the items) the
 // helper skips all ordinary phases, so it adds almost nothing to the issue load of the SIMD it shares with another
 // environment's main wave; a workgroup barrier of two waves costs ~30 cycles (measured), two per fork_join.
+#ifdef DSIM_STAMPS
+// developer builds only (tools/stamps.py): cycle stamps of workgroup 0's main wave at every phase boundary of the PRODUCT
+// executor (helper wave and all), read back with dsim_debug_stamps.  clock64 is an SMEM read: it drains the wave's LDS queue.
+__device__ long long g_dsim_stamps[2 * 16384];
+#endif
 template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
+#ifdef DSIM_STAMPS
+    int stamp_i_ = 0, stamp_tag_ = 0;
+    __device__ __forceinline__ void stamp() {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && stamp_i_ < 16384) {
+            g_dsim_stamps[stamp_i_] = clock64();
+            g_dsim_stamps[16384 + stamp_i_] = stamp_tag_;
+        }
+        ++stamp_i_;
+        ++stamp_tag_;
+    }
+    __device__ __forceinline__ void mark(int t) { stamp_tag_ = t * 100; }
+#else
+    __device__ __forceinline__ void stamp() {}
+    __device__ __forceinline__ void mark(int) {}
+#endif
     static_assert(!HELPER || NW == 1, "the helper wavefront belongs to the one-wave mapping");
     static constexpr bool HAS_HELPER = HELPER;
     const bool helper_ = HELPER && threadIdx.x >= DSIM_NL;
@@ -151,6 +171,7 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
     __device__ __forceinline__ void sync() {
         if constexpr (NW == 1) dsim_wave_sync();
         else __syncthreads();
+        stamp();
     }
     template <class F> __device__ __forceinline__ void run(F&& f) {
         if (!helper_) f(lane_());
@@ -169,11 +190,36 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
             if (helper_) fh(lane_());
             else fm(lane_());
             group_barrier();
+            stamp();
         } else {
             fm((int)threadIdx.x);
             fh((int)threadIdx.x);
             sync();
         }
+    }
+    // The same with a hand-over INSIDE the main block: fm calls mid() exactly once, at the point from which fh may read what
+    // fm has written so far (the kinematics publish poses and twists, then go on with inertias and body forces while the
+    // helper evaluates the contacts).  The helper waits at mid()'s barrier instead of at a barrier before the phase; what fm
+    // keeps in registers across mid() stays there.  Without a helper: fm, then fh.
+    template <class FM, class FH> __device__ __forceinline__ void fork_join_mid(FM&& fm, FH&& fh) {
+        if constexpr (HELPER) {
+            if (helper_) {
+                group_barrier();
+                fh(lane_());
+            } else {
+                fm(lane_());
+            }
+            group_barrier();
+            stamp();
+        } else {
+            fm((int)threadIdx.x);
+            fh((int)threadIdx.x);
+            sync();
+        }
+    }
+    __device__ __forceinline__ void mid() {
+        if constexpr (HELPER) group_barrier();
+        else dsim_wave_sync();
     }
     // phase that only writes global memory nobody in this launch reads back: no vmcnt wait.  One wave: no barrier either
     // (its LDS reads precede, in program order, whatever the next phase stores); several waves: the LDS words it reads
@@ -182,7 +228,6 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
         if (!helper_) f(lane_());
         if constexpr (NW > 1) __syncthreads();
     }
-    __device__ __forceinline__ void mark(int) {}
     // begin(): the model constants arrive in LDS and the work area is cleared (see DsimImage).  The step functions call it
     // AFTER they have requested their own inputs from global memory (dsim_core.hpp: early loads), so that the launch
     // pays ONE memory latency for all of them instead of one per prologue phase.
@@ -413,6 +458,9 @@ template <int NW> struct TimingExec {
             fh(lane);
         });
     }
+    template <class FM, class FH> __device__ __forceinline__ void fork_join_mid(FM&& fm, FH&& fh) { fork_join(fm, fh); }
+    __device__ __forceinline__ void mid() { __syncthreads(); }
+    __device__ __forceinline__ void stamp() {}
     DsimImage<NW, 0> img_;
     __device__ __forceinline__ void begin_request() {}
     __device__ __forceinline__ void begin() { img_.land(); __syncthreads(); }
@@ -511,6 +559,7 @@ struct dsim_model {
     int variant = V_GENERIC;
     int waves = 1;   // wavefronts per environment: 1 or DSIM_WAVES_WIDE
     int lean = 0;    // checkpoint mode (dsim_model_set_ckpt_mode)
+    int device = 0;  // HIP device the constants live on (the current device of dsim_model_create); every call checks it
     int row_words() const { return lean ? lay.o.xsc - lay.o.q : lay.o.save_words; }
     // Helper-wave kernels (DevExec<..., HELPER>) are used while every environment of the launch is resident at once: the
     // helper takes a wave slot of its SIMD, so beyond that point (several rounds of workgroups) it would halve the
@@ -575,8 +624,22 @@ KCommonT<O, D> make_k(const dsim_model* m, O o, D d, int n_envs, float dt, int s
     return k;
 }
 
+// a model belongs to the device it was created on: its constant block lives there and the kernel attributes / occupancy
+// figures were set up for it.  One process may drive several GPUs (one model per GPU); a call must run with its model's
+// device current, and the stream and pointers it is given must belong to that device.
+int check_device(const dsim_model* m) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+    if (dev != m->device)
+        return fail(DSIM_ERR_INVALID, "model was created on HIP device " + std::to_string(m->device) + " but the current device is " +
+                                          std::to_string(dev) + " (hipSetDevice / torch.cuda.device before the call)");
+    return DSIM_OK;
+}
+
 int check_common(const dsim_model* m, int n_envs, float dt, int substeps, int mm_freq) {
     if (!m) return fail(DSIM_ERR_INVALID, "null model");
+    if (int rc = check_device(m)) return rc;
     if (n_envs <= 0) return fail(DSIM_ERR_INVALID, "n_envs must be positive");
     if (substeps <= 0 || mm_freq <= 0) return fail(DSIM_ERR_INVALID, "substeps and mm_freq must be positive");
     if (!(dt > 0.f)) return fail(DSIM_ERR_INVALID, "dt must be positive");
@@ -628,7 +691,7 @@ int make_spec(const dsim_model* m, const dsim_env_spec* e, DsimEnvSpec& sp) {
 extern "C" {
 
 const char* dsim_last_error(void) { return g_err.c_str(); }
-int dsim_version(void) { return 103; }
+int dsim_version(void) { return 104; }
 
 int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
     if (!desc || !out) return fail(DSIM_ERR_INVALID, "null argument");
@@ -646,7 +709,8 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
     }
     m->variant = match_variant(m->lay);
     m->waves = pick_waves(m->lay, m->variant);
-    hipError_t e = hipMalloc(&m->d_cblob, sizeof(uint32_t) * m->lay.cblob.size());
+    hipError_t e = hipGetDevice(&m->device);
+    if (e == hipSuccess) e = hipMalloc(&m->d_cblob, sizeof(uint32_t) * m->lay.cblob.size());
     if (e == hipSuccess)
         e = hipMemcpy(m->d_cblob, m->lay.cblob.data(), sizeof(uint32_t) * m->lay.cblob.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess && (bytes > 64 * 1024 || fbytes > 64 * 1024)) {
@@ -698,9 +762,8 @@ void dsim_helper_capacity(dsim_model* m) {
         using D = decltype(d);
         constexpr int NW = decltype(nw)::value;
         if constexpr (dsim_has_helper<D, NW>()) {
-            int dev = 0, cus = 0, per_cu = 1 << 20;
-            bool ok = hipGetDevice(&dev) == hipSuccess &&
-                      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess;
+            int cus = 0, per_cu = 1 << 20;   // (callers have the model's device current: dsim_model_create, check_device)
+            bool ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device) == hipSuccess;
             auto cap = [&](auto kernel, int words) {   // resident workgroups per CU of one helper kernel
                 int n = 0;
                 ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 2 * DSIM_NL, (size_t)words * 4) == hipSuccess;
@@ -742,6 +805,7 @@ int64_t dsim_ckpt_floats(const dsim_model* m, int substeps) { return dsim_ckpt_f
 int dsim_model_set_ckpt_mode(dsim_model* m, int mode) {
     if (!m) return fail(DSIM_ERR_INVALID, "null model");
     if (mode != DSIM_CKPT_FULL && mode != DSIM_CKPT_LEAN) return fail(DSIM_ERR_INVALID, "unknown checkpoint mode");
+    if (int rc = check_device(m)) return rc;   // the occupancy query below is per device
     m->lean = mode == DSIM_CKPT_LEAN;
     dsim_helper_capacity(m);
     return DSIM_OK;
@@ -882,7 +946,14 @@ int dsim_env_observe(const dsim_model* m, const dsim_env_spec* env, int n_envs, 
 
 /* 0 = generic kernels, >0 = index of the specialised variant in use (diagnostics / tests) */
 int dsim_model_variant(const dsim_model* m) { return m ? m->variant : -1; }
+int dsim_model_device(const dsim_model* m) { return m ? m->device : -1; }
 
+#ifdef DSIM_STAMPS
+int dsim_debug_stamps(long long* out, int n) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dsim_stamps), sizeof(long long) * (size_t)(n < 2 * 16384 ? n : 2 * 16384));
+    return e == hipSuccess ? DSIM_OK : hip_fail(e, "dsim_debug_stamps");
+}
+#endif
 #ifdef DSIM_ENABLE_PHASE_TIMER
 int dsim_debug_phase_timer(const dsim_model* m, const dsim_env_spec* env, int n_envs, int backward, const float* q_in,
                            const float* qd_in, const float* actions, float dt, int substeps, int mm_freq, float* q_out,

@@ -26,6 +26,8 @@ class Engine:
         if self.device.type != "cuda":
             raise capi.DsimError("diffrl_amd runs on MI355X only (device=%s); there is no CPU path" % device)
         self._lib = capi.lib()
+        if self.device.index is None:   # "cuda" means the current device; tensors report an explicit index
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self._desc, self._keep = capi.make_desc(template)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -35,7 +37,9 @@ class Engine:
         self.ckpt_mode = (ckpt_mode or os.environ.get("DIFFRL_AMD_CKPT", "full")).lower()
         if self.ckpt_mode not in ("full", "lean"):
             raise capi.DsimError("ckpt_mode must be 'full' or 'lean'")
-        capi.check(self._lib.dsim_model_set_ckpt_mode(h, capi.CKPT_LEAN if self.ckpt_mode == "lean" else capi.CKPT_FULL))
+        with torch.cuda.device(self.device):   # (re-evaluates the occupancy of the helper-wave kernels on the model's device)
+            capi.check(self._lib.dsim_model_set_ckpt_mode(h, capi.CKPT_LEAN if self.ckpt_mode == "lean" else capi.CKPT_FULL))
+        assert int(self._lib.dsim_model_device(h)) == self.device.index
         self.variant = int(self._lib.dsim_model_variant(h))  # 0 = generic kernels, > 0 = specialised for this model
         self.n_q, self.n_qd, self.n_muscles = template.n_q, template.n_qd, template.n_muscles
 
@@ -81,7 +85,16 @@ class Engine:
                                                    mm_freq, _ptr(q_out), _ptr(qd_out), _ptr(ckpt), st))
         return q_out, qd_out, ckpt
 
+    def _check_ckpt(self, ckpt, substeps, mm_freq):
+        """a checkpoint must be consumed with the geometry (substeps, mass-matrix frequency, checkpoint mode) it was written
+        with: the row stride differs otherwise and the adjoint launch would read other rows' words"""
+        words = int(self._lib.dsim_ckpt_floats_mm(self._h, substeps, mm_freq))
+        if ckpt.dim() != 2 or ckpt.shape[1] != words or ckpt.device != self.device or ckpt.dtype != torch.float32:
+            raise capi.DsimError("checkpoint of shape %s does not match this model / step geometry (%d floats per environment "
+                                 "in '%s' mode on %s)" % (tuple(ckpt.shape), words, self.ckpt_mode, self.device))
+
     def backward(self, ckpt, act, mact, dt, substeps, mm_freq, gq_out, gqd_out):
+        self._check_ckpt(ckpt, substeps, mm_freq)
         n = ckpt.shape[0]
         gq_out = gq_out.contiguous()
         gqd_out = gqd_out.contiguous()
@@ -124,6 +137,7 @@ class Engine:
 
     def env_backward(self, spec, ckpt, actions, dt, substeps, mm_freq, gq_out, gqd_out, gobs, grew, gobs_before=None):
         """any cotangent may be None (= zeros: no fill kernels are launched for unused outputs)"""
+        self._check_ckpt(ckpt, substeps, mm_freq)
         n = ckpt.shape[0]
         gq = torch.empty(n * self.n_q, dtype=torch.float32, device=self.device)
         gqd = torch.empty(n * self.n_qd, dtype=torch.float32, device=self.device)

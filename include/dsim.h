@@ -88,9 +88,13 @@ typedef struct dsim_model dsim_model; /* opaque, owns device copies of the templ
 const char* dsim_last_error(void);
 int dsim_version(void);
 
-/* Uploads the template to the current HIP device. */
+/* Uploads the template to the CURRENT HIP device; the model belongs to that device from then on.  One process may hold
+ * models on several GPUs ("one stream (or process) per GPU"): every call that takes a model must be
+ * made with the model's device current (hipSetDevice / torch.cuda.device), with a stream and pointers of that device, and
+ * returns DSIM_ERR_INVALID otherwise -- a launch on another device would read a constant block that is not there. */
 int dsim_model_create(const dsim_model_desc* desc, dsim_model** out);
 int dsim_model_destroy(dsim_model* m);
+int dsim_model_device(const dsim_model* m);   /* HIP device index the model was created on */
 /* 0: generic kernels (runtime layout); > 0: a per-model specialised kernel set is in use (layout matched a
  * compile-time table exactly).  Same results either way. */
 int dsim_model_variant(const dsim_model* m);

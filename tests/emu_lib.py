@@ -76,6 +76,18 @@ def layout(t):
     return dict(zip(names, off[:n].tolist())), d
 
 
+SCAN_MIN_DEPTH = 5   # dsim_core.hpp: DSIM_SCAN_MIN_DEPTH
+
+
+def reorders(t):
+    """True if the one-wave SPECIALISED kernels of this model associate sums / products differently from the generic
+    kernels (same terms, different order): trunk decomposition of the subtree sums (dsim_trunk_sum) and / or the log-depth
+    kinematics of deep trees (dsim_fwd_kinematics_scan).  Such pairs agree to a tolerance, all others bit for bit."""
+    d = layout(t)[1]
+    scan = d["D"] >= SCAN_MIN_DEPTH and d["L"] <= 64 and d["nd"] <= 64 and d["C"] <= 64 and d["NS"] <= 64
+    return d["NT"] > 0 or scan
+
+
 def substep_image(t, q, qd, act, mact, h):
     """One substep (mass refresh, no integrate) for one env; returns dict name -> LDS slice getter."""
     desc, keep = make_desc(t)

@@ -34,11 +34,11 @@ def test_specialised_paths_match_generic(env, static_mode):
         f = emu_env_forward(t, spec, q, qd, a, dt, S, mm)   # asserts rc == 0: a specialised variant exists for every env
         b = emu_env_backward(t, spec, f[4], a, dt, S, mm, cot[0], cot[1], gobs, grew)
         out[mode] = (f[:4], b)
-    from emu_lib import layout
-    trunk = layout(t)[1]["NT"] > 0
+    from emu_lib import reorders
     for x, y in zip(out[1][0] + out[1][1], out[0][0] + out[0][1]):
-        if trunk:
-            # trunk decomposition of the subtree / ancestor sums (dsim_trunk_sum): the same terms in a different order
+        if reorders(t):
+            # trunk decomposition of the subtree / ancestor sums (dsim_trunk_sum), log-depth kinematics
+            # (dsim_fwd_kinematics_scan): the same terms in a different order
             assert np.abs(x - y).max() <= 2e-5 * max(np.abs(y).max(), 1e-6)
         else:
             # same operations in the same order; the bounded sums only add exact zeros for the unused slots
@@ -87,10 +87,10 @@ def test_four_waves_per_environment_match_one(env, static):
     finally:
         emu().dsim_emu_set_waves(1)
         emu().dsim_emu_use_static(0)
-    from emu_lib import layout
-    trunk = static and layout(t)[1]["NT"] > 0   # the one-wave specialised kernels of a deep tree sum in trunk order
+    from emu_lib import reorders
+    reord = static and reorders(t)   # the one-wave specialised kernels of a deep tree: trunk order, log-depth kinematics
     for x, y in zip(out[4][0] + out[4][1], out[1][0] + out[1][1]):
-        if trunk:
+        if reord:
             assert np.abs(x - y).max() <= 2e-5 * max(np.abs(y).max(), 1e-6)
         else:
             np.testing.assert_allclose(x, y, rtol=0, atol=0)

@@ -146,7 +146,21 @@ def test_fused_episode_gradients_match_the_torch_path():
         assert torch.allclose(o1, o2, rtol=1e-4, atol=1e-5) and torch.allclose(r1, r2, rtol=1e-4, atol=1e-5)
         assert torch.allclose(b1, b2, rtol=1e-4, atol=1e-5)
     assert sum(int(d.sum()) for _, _, d, _, _ in res[0][0]) >= n
-    assert relerr(res[0][1].cpu().numpy(), res[1][1].cpu().numpy()) < 2e-3
+    err, tol = relerr(res[0][1].cpu().numpy(), res[1][1].cpu().numpy()), 1e-3
+    if err >= tol:
+        # 1e-3 unless the REFERENCE-order gradient of this very rollout is more sensitive than that --
+        # the scalar oracle (reference operation order, same episode rules and loss) from a start state moved by 1e-7
+        from oracle_env import episode_rollout_grad
+        from oracle_lib import template_from_golden
+        prog0 = np.zeros(n, np.int64)
+        prog0[: n // 2] = 2
+        A, W = acts0.cpu().numpy(), w.cpu().numpy()
+        g0, _ = episode_rollout_grad("ant", template_from_golden("ant"), prog0, A, W, 5)
+        scale = (1.0 + 1e-7 * np.random.default_rng(0).normal(size=(n, 15))).astype(np.float32)
+        g1, _ = episode_rollout_grad("ant", template_from_golden("ant"), prog0, A, W, 5, q0_scale=scale)
+        tol = max(tol, 3.0 * relerr(g1, g0))
+        print("fused vs torch path: %.2e, reference-order sensitivity %.2e" % (err, tol / 3.0))
+    assert err < tol
     assert torch.allclose(res[0][2], res[1][2], rtol=1e-4, atol=1e-5)
 
 

@@ -34,13 +34,21 @@ write_b = counters("write", "dsim_env_bwd_kernel").get("WRITE_SIZE")
 fetch_f = counters("fetch", "dsim_env_fwd_kernel").get("FETCH_SIZE")
 write_f = counters("write", "dsim_env_fwd_kernel").get("WRITE_SIZE")
 sq = counters("sq ", "dsim_env_bwd_kernel")
+sqf = counters("sq ", "dsim_env_fwd_kernel")
+try:   # wave count and lane-cycles of the VALU (their own pass)
+    for dst, k in ((sq, "dsim_env_bwd_kernel"), (sqf, "dsim_env_fwd_kernel")):
+        for name_, val in counters("sq3", k).items():
+            if name_ != "SQ_INSTS_VALU":
+                dst[name_] = val
+except ValueError:
+    pass
 header = [
     "# rocprofv3 summary, %s, MI355X, ROCm 7.2, tools/profile.sh %s %s %d%s" % (name, tag, env, n, ("  -- " + note) if note else ""),
     "# command profiled: %s   (kernel sources: csrc hash %s)" % (cmd, h),
     "# passes: (1) --kernel-trace --stats  (2) --pmc FETCH_SIZE  (3) --pmc WRITE_SIZE  (4,5) --pmc SQ_* / GRBM_*  (each its own run)",
     "# FETCH_SIZE / WRITE_SIZE in KiB per launch; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes (MI355X_MICROARCH.md, HBM",
-    "# section): bytes read = FETCH_SIZE x 2 x 1024 (checked against the known checkpoint size of the adjoint launch); the forward",
-    "# kernel's WRITE_SIZE average mixes checkpointing launches with the no-grad launches of the bench's forward-only leg.",
+    "# section): bytes read = FETCH_SIZE x 2 x 1024 (checked against the known checkpoint size of the adjoint launch); every",
+    "# forward launch of the profiled command writes a checkpoint (bench.py --no-extras: no forward-only leg).",
     "# SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* in quad-cycles summed over the wavefronts of a launch.",
 ]
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
@@ -48,7 +56,8 @@ open(os.path.join(ROOT, "profiles", "%s_%s_rocprofv3_summary.txt" % (name, env))
 rec = {"env": env, "n_envs": n, "mm_freq": MM[env], "kernel": "dsim_env_bwd_kernel", "csrc_hash": h,
        "fetch_size_kib_per_launch": fetch_b, "write_size_kib_per_launch": write_b,
        "traffic_bytes_per_launch": int(fetch_b * 2 * 1024 + write_b * 1024) if fetch_b is not None and write_b is not None else None,
-       "forward_kernel": {"fetch_size_kib_per_launch": fetch_f, "write_size_kib_per_launch_mixed": write_f},
-       "sq_adjoint": sq, "source": "profiles/%s_%s_rocprofv3_summary.txt" % (name, env)}
+       "forward_kernel": {"fetch_size_kib_per_launch": fetch_f, "write_size_kib_per_launch": write_f,
+                          "traffic_bytes_per_launch": int(fetch_f * 2 * 1024 + write_f * 1024) if fetch_f is not None and write_f is not None else None},
+       "sq_adjoint": sq, "sq_forward": sqf, "source": "profiles/%s_%s_rocprofv3_summary.txt" % (name, env)}
 json.dump(rec, open(os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (name, env)), "w"), indent=1)
 print(json.dumps(rec)[:400])

@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/prof_${TAG}_$ENVN
 RAW=/tmp/prof_raw_$ENVN
 mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --env $ENVN --envs-per-gpu $ENVS"
+CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-extras --env $ENVN --envs-per-gpu $ENVS"
 echo "$CMD" > $OUT/command.txt
 python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(bench.csrc_hash())" > $OUT/csrc_hash.txt 2>/dev/null
 run() { timeout 240 rocprofv3 --output-format csv "$@" < /dev/null; }
@@ -17,6 +17,7 @@ run --kernel-trace --stats -d $RAW/trace -o t -- $CMD > $OUT/trace.log 2>&1
 run --pmc FETCH_SIZE --kernel-trace -d $RAW/fetch -o f -- $CMD > $OUT/fetch.log 2>&1
 run --pmc WRITE_SIZE --kernel-trace -d $RAW/write -o w -- $CMD > $OUT/write.log 2>&1
 run --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace -d $RAW/sq -o s -- $CMD > $OUT/sq.log 2>&1
+run --pmc SQ_WAVES SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU --kernel-trace -d $RAW/sq3 -o s3 -- $CMD > $OUT/sq3.log 2>&1
 run --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --kernel-trace -d $RAW/sq2 -o s2 -- $CMD > $OUT/sq2.log 2>&1
 find $RAW -type f -printf "%p %s\n" > $OUT/files.txt
 timeout 120 python - > $OUT/summary.txt 2>&1 < /dev/null <<PY
@@ -32,7 +33,7 @@ print("== rocprofv3 --kernel-trace --stats : kernel_stats (top 15 by total time)
 if st: print(",".join(st[0].keys()))
 for r in st[:15]:
     print(",".join(str(v)[:70] for v in r.values()))
-for sub in ("fetch","write","sq","sq2"):
+for sub in ("fetch","write","sq","sq2","sq3"):
     rows=load(sub+"/**/*counter_collection.csv")
     agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
     for r in rows:
