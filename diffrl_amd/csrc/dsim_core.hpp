@@ -667,6 +667,42 @@ template <int MASK, bool FIRST, bool IDENT> DSIM_FN void dsim_fk_compute(DsimFkW
     w.rsp = rc;
 }
 
+// checkpoint row of a substep: the saved block in LDS -> this environment's row in global memory, 16 bytes per lane and
+// instruction.  Specialised kernels: the row length is a compile-time constant, so the copy is unrolled -- ALL the LDS reads
+// are issued first, then the stores (the run-time loop it replaces waited for every read before its store: five LDS
+// latencies in a row for the humanoid's 259 16-byte words).
+typedef float __attribute__((vector_size(16), may_alias)) dsim_vec4;   // a native vector: stays in registers (an array of the
+                                                                         // may_alias STRUCT dsim_f4 went to scratch memory)
+// PART 0: the whole row; 1: its head (q, qd -- the words the integrator overwrites); 2: the rest (X_sc ... qdd).  The
+// helper-wave kernels copy the head while the kinematics run (q, qd are stable until the integrator) and the rest beside the
+// integrator (dsim_fwd_dynamics_wave), so that no copy is left on the main wave's path.
+template <class Ctx, int NL, int PART = 0> DSIM_FN void dsim_ckpt_store_row(const Ctx& c, int lane, float* g_row) {
+    if constexpr (DsimIsStatic<Ctx>::value) {
+        using O = decltype(c.o);
+        constexpr int ALL4 = (Ctx::LEAN ? O::xsc - O::q : O::save_words) / 4, HEAD4 = (O::xsc - O::q) / 4;
+        constexpr int B4 = PART == 2 ? HEAD4 : 0, E4 = PART == 1 ? HEAD4 : ALL4, IT = (E4 - B4 + NL - 1) / NL;
+        const dsim_vec4* src = reinterpret_cast<const dsim_vec4*>(WF(q)) + B4;
+        dsim_vec4* dst = reinterpret_cast<dsim_vec4*>(g_row) + B4;
+        dsim_vec4 x[IT > 0 ? IT : 1];
+#pragma unroll
+        for (int r = 0; r < IT; ++r) {
+            const int k = lane + NL * r;
+            if (k < E4 - B4) x[r] = src[k];
+        }
+#pragma unroll
+        for (int r = 0; r < IT; ++r) {
+            const int k = lane + NL * r;
+            if (k < E4 - B4) dst[k] = x[r];
+        }
+    } else {
+        const int head4 = (c.o.xsc - c.o.q) / 4, all4 = dsim_row(c) / 4;
+        const int b4 = PART == 2 ? head4 : 0, e4 = PART == 1 ? head4 : all4;
+        const dsim_f4* src = reinterpret_cast<const dsim_f4*>(WF(q));
+        dsim_f4* dst = reinterpret_cast<dsim_f4*>(g_row);
+        for (int k = b4 + lane; k < e4; k += NL) dst[k] = src[k];
+    }
+}
+
 // ground contacts of this lane from the finished pose and twist of their bodies in LDS (sim.py:1137-1206)
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_contacts(const Ctx& c, Exec& ex, int lane) {
     for (int k = lane; k < c.d.C; k += Exec::NL) {
@@ -694,7 +730,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_contacts(const Ctx& c, Ex
 // Same terms as the chain walk, associated differently (products of transforms pairwise instead of left to right, sums
 // likewise): not bit-identical to it; tests hold both to the reference's recording of the first substep (1e-5).
 // Between poses + twists and the rest, Exec::mid() lets the helper wavefront start on the contacts (fork_join_mid).
-template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_scan(const Ctx& c, Exec& ex) {
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_scan(const Ctx& c, Exec& ex, float* g_row) {
     using D = decltype(c.d);
     constexpr int L = D::L, R = dsim_scan_rounds(D::D), MASK = D::tmask;
     constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
@@ -859,13 +895,18 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_scan(const Ctx
                 stsv(S + 12, s2);
             }
         }
-    }, [&](int lane) { dsim_fwd_contacts(c, ex, lane); });
+    }, [&](int lane) {
+        dsim_fwd_contacts(c, ex, lane);
+        if (g_row) dsim_ckpt_store_row<Ctx, Exec::NL, 1>(c, lane, g_row);   // head of the checkpoint row: (q, qd) entering the substep
+    });
 }
 
-template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, Exec& ex) {
+// g_row (one-phase dynamics only, DsimWaveDyn): the substep's checkpoint row -- its head (q, qd) is copied here, by the helper
+// wavefront where there is one, the rest beside the integrator (dsim_fwd_dynamics_wave)
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, Exec& ex, float* g_row = nullptr) {
     ex.mark(1);
     if constexpr (DsimScanFk<Ctx, Exec::NL>::value) {
-        dsim_fwd_kinematics_scan(c, ex);
+        dsim_fwd_kinematics_scan(c, ex, g_row);
         return;
     }
     // "Flat" forward kinematics: every link's lane walks its own ancestor chain from the root and recomputes the
@@ -937,6 +978,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
                     continue;
                 }
             }
+            ex.stamp();
             // COM, world inertia and body force of link i from the values still in registers
             const v3 pc = w.psp;
             const q4 rc = w.rsp;
@@ -978,10 +1020,13 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
             }
         }
     };
+    auto head = [&](int lane) __attribute__((always_inline)) {
+        if (g_row) dsim_ckpt_store_row<Ctx, Exec::NL, 1>(c, lane, g_row);
+    };
     if constexpr (Exec::HAS_HELPER && DsimContactsInKin<Ctx, Exec::NL>::value)
-        ex.fork_join([&](int lane) { walk(lane, 1); }, [&](int lane) { walk(lane, 2); });
+        ex.fork_join([&](int lane) { walk(lane, 1); }, [&](int lane) { walk(lane, 2); head(lane); });
     else
-        ex.run([&](int lane) { walk(lane, 0); });
+        ex.run([&](int lane) { walk(lane, 0); head(lane); });
 }
 
 // mpart[e][k] = sum of component k over the muscle wrench rows of chunk e (forward: wrenches; adjoint: pose cotangents)
@@ -1176,13 +1221,12 @@ DSIM_FN void dsim_trunk_sum(const Ctx& c, Exec& ex, int lane, const float* ldata
     ex.lds_fence();
 }
 
-// joint-space forces (sim.py:1421-1502, 1792-1842)
-template <class Ctx, class Exec> DSIM_FN void dsim_fwd_tau(const Ctx& c, Exec& ex) {
+// f_tot[i] = sum over subtree(i) of (inverse-dynamics force [+ muscle wrenches, gathered per body]) + contact wrenches
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_ftot(const Ctx& c, Exec& ex) {
     ex.mark(3);
-    // f_tot[i] = sum over subtree(i) of (inverse-dynamics force [+ muscle wrenches, gathered per body]) + contact wrenches
     ex.run([&](int lane) {
         if constexpr (DsimTrunk<Ctx, Exec>::value) {
-            dsim_trunk_sum<false>(c, ex, lane, WF(f), WF(cw), 6, 0, WF(ftot));
+            dsim_trunk_sum<true>(c, ex, lane, WF(f), WF(cw), 6, 0, WF(ftot));
             return;
         }
         for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
@@ -1190,6 +1234,10 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_tau(const Ctx& c, Exec& e
             WF(ftot)[it] = dsim_subtree_contact_sum(c, ex, lane, i, WF(f), k, WF(cw), 6, k);
         }
     });
+}
+// joint-space forces (sim.py:1421-1502, 1792-1842)
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_tau(const Ctx& c, Exec& ex) {
+    dsim_fwd_ftot(c, ex);
     ex.run([&](int lane) {
         for (int d = lane; d < c.d.nd; d += Exec::NL) {
             int i, type, cs, ds;
@@ -1365,36 +1413,6 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_integrate(const Ctx& c, E
     });
 }
 
-// checkpoint row of a substep: the saved block in LDS -> this environment's row in global memory, 16 bytes per lane and
-// instruction.  Specialised kernels: the row length is a compile-time constant, so the copy is unrolled -- ALL the LDS reads
-// are issued first, then the stores (the run-time loop it replaces waited for every read before its store: five LDS
-// latencies in a row for the humanoid's 259 16-byte words).
-typedef float __attribute__((vector_size(16), may_alias)) dsim_vec4;   // a native vector: stays in registers (an array of the
-                                                                         // may_alias STRUCT dsim_f4 went to scratch memory)
-template <class Ctx, int NL> DSIM_FN void dsim_ckpt_store_row(const Ctx& c, int lane, float* g_row) {
-    if constexpr (DsimIsStatic<Ctx>::value) {
-        using O = decltype(c.o);
-        constexpr int W4 = (Ctx::LEAN ? O::xsc - O::q : O::save_words) / 4, IT = (W4 + NL - 1) / NL;
-        const dsim_vec4* src = reinterpret_cast<const dsim_vec4*>(WF(q));
-        dsim_vec4* dst = reinterpret_cast<dsim_vec4*>(g_row);
-        dsim_vec4 x[IT];
-#pragma unroll
-        for (int r = 0; r < IT; ++r) {
-            const int k = lane + NL * r;
-            if (k < W4) x[r] = src[k];
-        }
-#pragma unroll
-        for (int r = 0; r < IT; ++r) {
-            const int k = lane + NL * r;
-            if (k < W4) dst[k] = x[r];
-        }
-    } else {
-        const dsim_f4* src = reinterpret_cast<const dsim_f4*>(WF(q));
-        dsim_f4* dst = reinterpret_cast<dsim_f4*>(g_row);
-        for (int k = lane; k < dsim_row(c) / 4; k += NL) dst[k] = src[k];
-    }
-}
-
 // ---- forward dynamics of a substep in ONE phase (small models, one wavefront per environment) -----------------------------
 // f_tot (subtree sums) -> tau -> qdd = H^-1 tau -> checkpoint copy -> integrate used to be four phases whose only
 // connection is a handful of values that change lanes: the 6 components of f_tot[link(d)] go from the (link, component)
@@ -1406,10 +1424,16 @@ template <class Ctx, class Exec> struct DsimWaveDyn {
     static constexpr bool value = []() {
         if constexpr (std::is_empty<decltype(Ctx::d)>::value && Exec::WAVE_OPS) {
             using D = decltype(Ctx::d);
-            return 6 * D::L <= Exec::NL && D::nd <= 32 && D::NS == 0 && (D::flags & DSIM_F_RANGES) != 0;
+            return D::L <= Exec::NL && D::nd <= 32 && D::NS == 0 && (D::flags & DSIM_F_RANGES) != 0;
         } else {
             return false;
         }
+    }();
+    // ... with the subtree sums inside the phase too, on (link, component) lanes (6 L lanes); models with more links sum in a
+    // phase of their own (dsim_fwd_ftot: trunk decomposition) and the dof lanes read f_tot of their links from LDS
+    static constexpr bool sums_inside = []() {
+        if constexpr (std::is_empty<decltype(Ctx::d)>::value) return 6 * decltype(Ctx::d)::L <= Exec::NL;
+        else return false;
     }();
 };
 template <class Ctx, class Exec>
@@ -1417,7 +1441,7 @@ DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float*
     ex.mark(3);
     using D = decltype(c.d);
     constexpr int nd = D::nd, L = D::L;
-    ex.run([&](int lane) {
+    ex.fork_mid_detached([&](int lane) {
         constexpr int MASK = dsim_tmask_static<Ctx>();
         constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
         const float h = c.h;
@@ -1446,17 +1470,21 @@ DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float*
         for (int k = 0; k < NQ; ++k) qv[k] = WF(q)[lcs + k];
 #pragma unroll
         for (int k = 0; k < NDF; ++k) qdv[k] = WF(qd)[lds_ + k];
-        // ---- (link, component) role: f_tot = subtree sums of the body forces and contact wrenches
-        float ft = 0.f;
-        if (lane < 6 * L) {
-            ft = dsim_subtree_contact_sum(c, ex, lane, lane / 6, WF(f), lane - 6 * (lane / 6), WF(cw), 6, lane - 6 * (lane / 6));
-            WF(ftot)[lane] = ft;   // the adjoint reads it from the checkpoint
-        }
-        ex.stamp();
-        // ---- f_tot[link(d)] -> dof lane d
         sv6 F;
-        F.w.x = ex.shfl(ft, 6 * di + 0); F.w.y = ex.shfl(ft, 6 * di + 1); F.w.z = ex.shfl(ft, 6 * di + 2);
-        F.v.x = ex.shfl(ft, 6 * di + 3); F.v.y = ex.shfl(ft, 6 * di + 4); F.v.z = ex.shfl(ft, 6 * di + 5);
+        if constexpr (DsimWaveDyn<Ctx, Exec>::sums_inside) {
+            // ---- (link, component) role: f_tot = subtree sums of the body forces and contact wrenches
+            float ft = 0.f;
+            if (lane < 6 * L) {
+                ft = dsim_subtree_contact_sum(c, ex, lane, lane / 6, WF(f), lane - 6 * (lane / 6), WF(cw), 6, lane - 6 * (lane / 6));
+                WF(ftot)[lane] = ft;   // the adjoint reads it from the checkpoint
+            }
+            ex.stamp();
+            // ---- f_tot[link(d)] -> dof lane d
+            F.w.x = ex.shfl(ft, 6 * di + 0); F.w.y = ex.shfl(ft, 6 * di + 1); F.w.z = ex.shfl(ft, 6 * di + 2);
+            F.v.x = ex.shfl(ft, 6 * di + 3); F.v.y = ex.shfl(ft, 6 * di + 4); F.v.z = ex.shfl(ft, 6 * di + 5);
+        } else {
+            F = ldsv(WF(ftot) + 6 * di);   // summed by the phase before (dsim_fwd_ftot)
+        }
         // ---- dof role: tau (sim.py:1421-1502)
         float t = 0.0f - sdot(Sd, F);
         if (hinge) {
@@ -1480,14 +1508,9 @@ DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float*
         float av[NDF > 0 ? NDF : 1];
 #pragma unroll
         for (int k = 0; k < NDF; ++k) av[k] = ex.shfl(acc, lds_ + k);
-        // ---- checkpoint row (needs f_tot and qdd of all lanes in LDS, and q / qd before integrate overwrites them)
-        if (g_row) {
-            ex.lds_fence();
-            dsim_ckpt_store_row<Ctx, Exec::NL>(c, lane, g_row);
-            if (update_mass && g_hinv)
-                for (int k = lane; k < nd * nd; k += Exec::NL) g_hinv[k] = WF(hinv)[k];
-            ex.lds_fence();
-        }
+        // ---- f_tot and qdd of all lanes are in LDS: the rest of the checkpoint row may be copied (side block below; its head --
+        // q, qd, which the integrator is about to overwrite -- went out during the kinematics)
+        ex.mid();
         ex.stamp();
         // ---- link role: semi-implicit Euler (sim.py:1505-1636), in place on q, qd
         if (is_link) {
@@ -1529,6 +1552,21 @@ DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float*
                 }
             }
         }
+    }, [&](int lane) {
+        // side block (helper wavefront where there is one): the rest of the checkpoint row and, on a refresh, the inverse.  Nothing
+        // it reads is written again before the next substep's kinematics, which start behind a barrier both waves take.
+        if (g_row) {
+            dsim_ckpt_store_row<Ctx, Exec::NL, 2>(c, lane, g_row);
+            if (update_mass && g_hinv) {
+                constexpr int IT = (nd * nd + Exec::NL - 1) / Exec::NL;
+                float x[IT];
+#pragma unroll
+                for (int r = 0; r < IT; ++r) x[r] = WF(hinv)[(lane + Exec::NL * r) < nd * nd ? lane + Exec::NL * r : 0];
+#pragma unroll
+                for (int r = 0; r < IT; ++r)
+                    if (lane + Exec::NL * r < nd * nd) g_hinv[lane + Exec::NL * r] = x[r];
+            }
+        }
     });
 }
 
@@ -1549,10 +1587,11 @@ template <class Ctx> DSIM_FN float* dsim_ckpt_tail(const Ctx& c, float* g_ckpt, 
 // one substep on the LDS-resident state; g_row / g_hinv: where to stream the saved block / the fresh inverse (or null)
 template <class Ctx, class Exec>
 DSIM_FN void dsim_fwd_substep(const Ctx& c, Exec& ex, bool update_mass, float* g_row = nullptr, float* g_hinv = nullptr) {
-    dsim_fwd_kinematics(c, ex);
+    dsim_fwd_kinematics(c, ex, DsimWaveDyn<Ctx, Exec>::value ? g_row : nullptr);
     dsim_fwd_external(c, ex);
     if constexpr (DsimWaveDyn<Ctx, Exec>::value) {
         if (update_mass) dsim_fwd_mass(c, ex);   // H depends on the kinematics only
+        if constexpr (!DsimWaveDyn<Ctx, Exec>::sums_inside) dsim_fwd_ftot(c, ex);
         dsim_fwd_dynamics_wave(c, ex, g_row, g_hinv, update_mass);
         return;
     }

@@ -129,10 +129,13 @@ __device__ long long g_dsim_stamps[2 * 16384];
 template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
 #ifdef DSIM_STAMPS
     int stamp_i_ = 0, stamp_tag_ = 0;
+    // main wave: entries [0, 8192), helper wave: [8192, 16384) (its tags + 50)
     __device__ __forceinline__ void stamp() {
-        if (blockIdx.x == 0 && threadIdx.x == 0 && stamp_i_ < 16384) {
-            g_dsim_stamps[stamp_i_] = clock64();
-            g_dsim_stamps[16384 + stamp_i_] = stamp_tag_;
+        const bool main_lane = threadIdx.x == 0, help_lane = HELPER && threadIdx.x == DSIM_NL;
+        if (blockIdx.x == 0 && (main_lane || help_lane) && stamp_i_ < 8192) {
+            const int k = stamp_i_ + (help_lane ? 8192 : 0);
+            g_dsim_stamps[k] = clock64();
+            g_dsim_stamps[16384 + k] = stamp_tag_ + (help_lane ? 50 : 0);
         }
         ++stamp_i_;
         ++stamp_tag_;
@@ -189,6 +192,7 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
             group_barrier();
             if (helper_) fh(lane_());
             else fm(lane_());
+            stamp();          // (this wave's block is done; the next stamp is behind the barrier: the difference is waiting)
             group_barrier();
             stamp();
         } else {
@@ -203,12 +207,14 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
     // keeps in registers across mid() stays there.  Without a helper: fm, then fh.
     template <class FM, class FH> __device__ __forceinline__ void fork_join_mid(FM&& fm, FH&& fh) {
         if constexpr (HELPER) {
+            group_barrier();   // the helper is done with whatever it was left to do beside the previous phase (fork_mid_detached)
             if (helper_) {
                 group_barrier();
                 fh(lane_());
             } else {
                 fm(lane_());
             }
+            stamp();
             group_barrier();
             stamp();
         } else {
@@ -220,6 +226,25 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
     __device__ __forceinline__ void mid() {
         if constexpr (HELPER) group_barrier();
         else dsim_wave_sync();
+    }
+    // ... and without the barrier at the end: fh is a DETACHED side block -- nothing it reads is written, and nothing it writes is
+    // read, before the next barrier that both waves take (the checkpoint copy beside the integrator: the next substep's
+    // kinematics start with one).  The main wave goes on at once.
+    template <class FM, class FH> __device__ __forceinline__ void fork_mid_detached(FM&& fm, FH&& fh) {
+        if constexpr (HELPER) {
+            if (helper_) {
+                group_barrier();
+                fh(lane_());
+            } else {
+                fm(lane_());
+            }
+            asm volatile("" ::: "memory");
+            stamp();
+        } else {
+            fm((int)threadIdx.x);
+            fh((int)threadIdx.x);
+            sync();
+        }
     }
     // phase that only writes global memory nobody in this launch reads back: no vmcnt wait.  One wave: no barrier either
     // (its LDS reads precede, in program order, whatever the next phase stores); several waves: the LDS words it reads
@@ -459,6 +484,7 @@ template <int NW> struct TimingExec {
         });
     }
     template <class FM, class FH> __device__ __forceinline__ void fork_join_mid(FM&& fm, FH&& fh) { fork_join(fm, fh); }
+    template <class FM, class FH> __device__ __forceinline__ void fork_mid_detached(FM&& fm, FH&& fh) { fork_join(fm, fh); }
     __device__ __forceinline__ void mid() { __syncthreads(); }
     __device__ __forceinline__ void stamp() {}
     DsimImage<NW, 0> img_;

@@ -95,6 +95,7 @@ template <int NW> struct HostExecT {
     }
     // fm hands over to fh at its mid() call (device: the helper's barrier): every lane passes mid() before any lane gets to fh
     template <class FM, class FH> void fork_join_mid(FM&& fm, FH&& fh) { fork_join(fm, fh); }
+    template <class FM, class FH> void fork_mid_detached(FM&& fm, FH&& fh) { fork_join(fm, fh); }
     void mid() { arrive(); }
     void stamp() {}
     // host form of the register / v_readlane Gauss-Jordan of the kernels (dsim_hip.hip: dsim_wave_gj): same formulas

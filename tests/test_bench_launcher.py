@@ -59,7 +59,16 @@ def test_bench_through_the_launcher_rccl_group_of_one():
     j = _json_line(out)
     assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1 and j["steps"] == 2
     # the other BASELINE.json configurations ride along in the default single-GPU line
-    oc = {o["workload"].split()[0] + ("_mm1" if o["workload"].endswith("frequency 1") else ""): o for o in j["other_configs"]}
-    assert set(oc) == {"humanoid", "snu", "ant_mm1"} and all(o["value"] and o["value"] > 1e5 for o in oc.values()), oc
+    def key(o):
+        k = o["workload"].split()[0]
+        return k + ("_mm1" if o["workload"].endswith("frequency 1") else "") + ("_generic" if o["kernels"].startswith("generic") else "")
+    oc = {key(o): o for o in j["other_configs"]}
+    assert set(oc) == {"humanoid", "snu", "ant_mm1", "ant_generic"}, oc
+    for o in oc.values():   # each measured like the headline (>= 10 timed replays) and with its own roofline object
+        assert o["value"] and o["value"] > 1e5 and o["steps"] >= 10, o
+        r = o["roofline"]
+        assert r["bound"] == "valu-issue" and r["traffic"] > r["alg_bytes_per_launch"] and 0 < r["hbm_measured_frac"] < 1, r
+    assert oc["ant_generic"]["value"] < j["value"]
     assert j["config"]["submission_fallback"] is False
     assert j["value"] > 1e5 and j["roofline"]["traffic"] > j["roofline"]["alg_bytes_per_launch"]
+    assert j["roofline"]["bound"] == "valu-issue" and "valu_issue_frac" in j["roofline"] and "hbm_measured_frac" in j["roofline"]

@@ -53,16 +53,19 @@ for backward in (0, 1):
         torch.cuda.synchronize()
     buf = np.zeros(2 * CAP, np.int64)
     capi.check(L.dsim_debug_stamps(buf.ctypes.data_as(C.c_void_p), 2 * CAP))
-    clk, tag = buf[:CAP], buf[CAP:]
-    n = int((clk != 0).sum())
-    d = np.diff(clk[:n])
-    tags = tag[1:n]
-    print("==", env, "N", N, "adjoint" if backward else "forward", "stamps", n, "total cycles (stamp clock)", int(clk[n - 1] - clk[0]))
-    agg = collections.OrderedDict()
-    for tg, x in zip(tags.tolist(), d.tolist()):
-        agg.setdefault(tg, []).append(x)
-    tot = collections.Counter()
-    for tg, xs in agg.items():
-        tot[names.get(tg // 100, "?")] += sum(xs)
-        print("  %-12s stamp %2d: n=%3d mean %7.0f  min %6d max %6d" % (names.get(tg // 100, "?"), tg % 100, len(xs), sum(xs) / len(xs), min(xs), max(xs)))
-    print("  totals:", dict(tot))
+    for wave, lo in (("main wave", 0), ("helper wave", 8192)):
+        clk, tag = buf[lo:lo + 8192], buf[CAP + lo:CAP + lo + 8192]
+        n = int((clk != 0).sum())
+        if n < 2:
+            continue
+        d = np.diff(clk[:n])
+        tags = tag[1:n]
+        print("==", env, "N", N, "adjoint" if backward else "forward", wave, "stamps", n, "total cycles (stamp clock)", int(clk[n - 1] - clk[0]))
+        agg = collections.OrderedDict()
+        for tg, x in zip(tags.tolist(), d.tolist()):
+            agg.setdefault(tg, []).append(x)
+        tot = collections.Counter()
+        for tg, xs in agg.items():
+            tot[names.get(tg // 100, "?")] += sum(xs)
+            print("  %-12s stamp %2d: n=%3d mean %7.0f  min %6d max %6d" % (names.get(tg // 100, "?"), tg % 100, len(xs), sum(xs) / len(xs), min(xs), max(xs)))
+        print("  totals:", dict(tot))
