@@ -225,7 +225,7 @@ struct DsimTopoRegs {
     int ta_top[DSIM_TR_PASSES], ta_tp[DSIM_TR_PASSES], ta_m[DSIM_TR_PASSES], tu_d[DSIM_TR_PASSES];
     float tw_l[DSIM_TR_PASSES][DSIM_LIGHT_CAP], tw_c[DSIM_TR_PASSES][DSIM_LIGHT_CAP];   // 1 / 0 weights of the light sums' entries (adjoint kernels)
     int adof[16], adof_n;                    // dofs of the ancestors-or-self of link `(63 - lane) / 6` (adjoint of tau)
-    int jmp[DSIM_SCAN_ROUNDS_MAX];           // ancestor of link `lane` at distance 2^r (-1: none): log-depth kinematics (DsimScanFk)
+    int jmp[DSIM_SCAN_ROUNDS_MAX];           // lane of the ancestor of link `lane` at distance 2^r (none: the last lane): DsimScanFk
 };
 template <class Ctx> struct DsimChainRegs {
     static constexpr bool value = []() {
@@ -290,7 +290,7 @@ template <class Ctx, int NL> struct DsimScanFk {
     static constexpr bool value = []() {
         if constexpr (std::is_empty<decltype(Ctx::d)>::value) {
             using D = decltype(Ctx::d);
-            return NL == DSIM_NL && D::L <= NL && D::nd <= NL && D::C <= NL && D::D >= DSIM_SCAN_MIN_DEPTH &&
+            return NL == DSIM_NL && D::L < NL && D::nd <= NL && D::C <= NL && D::D >= DSIM_SCAN_MIN_DEPTH &&
                    D::D <= (1 << DSIM_SCAN_ROUNDS_MAX);
         } else {
             return false;
@@ -364,7 +364,8 @@ template <class Ctx, class Exec> DSIM_FN void dsim_topo_init(const Ctx& c, Exec&
 #pragma unroll
         for (int r = 0; r < DSIM_SCAN_ROUNDS_MAX; ++r) {
             const int dist = 1 << r;
-            tp.jmp[r] = (lane < c.d.L && e1 - e0 > dist) ? CI(anc_list)[e1 - 1 - dist] : -1;
+            // no such ancestor: the wave's last lane, which carries the neutral element (identity transform, zero twist)
+            tp.jmp[r] = (lane < c.d.L && e1 - e0 > dist) ? CI(anc_list)[e1 - 1 - dist] : Exec::NL - 1;
         }
     } else if constexpr (DsimChainRegs<Ctx>::value) {
         constexpr int DEPTH = decltype(c.d)::D;
@@ -785,16 +786,18 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_scan(const Ctx
         }
         // ---- poses: pointer jumping along the ancestor chains.  T_j travels from lane j by ds_bpermute (Exec::shfl): no LDS
         // store, no store -> load ordering -- a round is seven cross-lane reads and one composition
+        // (a lane without an ancestor at that distance reads the wave's last lane, which holds the identity: rotate(1, x) + 0 = x
+        // and 1 (x) q = q exactly, so every lane composes unconditionally -- no selects)
+        if (lane >= L) {
+            p = zero3();
+            r = mkq(0.f, 0.f, 0.f, 1.f);
+        }
         dsim_static_for<0, R>([&](auto rr) {
-            int j = tp.jmp[decltype(rr)::value];
-            DSIM_OPAQUE(j);
-            const int src = j < 0 ? lane : j;
+            const int src = tp.jmp[decltype(rr)::value];
             const v3 pa = mk3(ex.shfl(p.x, src), ex.shfl(p.y, src), ex.shfl(p.z, src));
             const q4 ra = mkq(ex.shfl(r.x, src), ex.shfl(r.y, src), ex.shfl(r.z, src), ex.shfl(r.w, src));
-            if (j >= 0) {
-                p = rotate(ra, p) + pa;
-                r = qmul(ra, r);
-            }
+            p = rotate(ra, p) + pa;
+            r = qmul(ra, r);
         });
         if (on) {
             st3(WF(xsc) + 7 * i, p);
@@ -839,27 +842,22 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_scan(const Ctx
         }
         // ---- twists: prefix sums of v_j along the chains
         sv6 v = vj;
+        if (lane >= L) v = zerosv();   // (the neutral element of the sums, see the poses)
         dsim_static_for<0, R>([&](auto rr) {
-            int j = tp.jmp[decltype(rr)::value];
-            DSIM_OPAQUE(j);
-            const int src = j < 0 ? lane : j;
-            const sv6 va = mksv(mk3(ex.shfl(v.w.x, src), ex.shfl(v.w.y, src), ex.shfl(v.w.z, src)),
-                                mk3(ex.shfl(v.v.x, src), ex.shfl(v.v.y, src), ex.shfl(v.v.z, src)));
-            if (j >= 0) v += va;
+            const int src = tp.jmp[decltype(rr)::value];
+            v += mksv(mk3(ex.shfl(v.w.x, src), ex.shfl(v.w.y, src), ex.shfl(v.w.z, src)),
+                      mk3(ex.shfl(v.v.x, src), ex.shfl(v.v.y, src), ex.shfl(v.v.z, src)));
         });
         if (on) stsv(WF(v) + 6 * i, v);
         ex.stamp();
         ex.mid();   // X_sc and v of every link are final: the contacts may start
         // ---- bias accelerations: c_i = v_i x v_j,i (exactly zero at the root: a vector crossed with itself), prefix sums in a
         sv6 a = zerosv();
-        if (tp.own_level > 0) a = scross(v, vj);
+        if (tp.own_level > 0 && on) a = scross(v, vj);
         dsim_static_for<0, R>([&](auto rr) {
-            int j = tp.jmp[decltype(rr)::value];
-            DSIM_OPAQUE(j);
-            const int src = j < 0 ? lane : j;
-            const sv6 aa = mksv(mk3(ex.shfl(a.w.x, src), ex.shfl(a.w.y, src), ex.shfl(a.w.z, src)),
-                                mk3(ex.shfl(a.v.x, src), ex.shfl(a.v.y, src), ex.shfl(a.v.z, src)));
-            if (j >= 0) a += aa;
+            const int src = tp.jmp[decltype(rr)::value];
+            a += mksv(mk3(ex.shfl(a.w.x, src), ex.shfl(a.w.y, src), ex.shfl(a.w.z, src)),
+                      mk3(ex.shfl(a.v.x, src), ex.shfl(a.v.y, src), ex.shfl(a.v.z, src)));
         });
         if (on) stsv(WF(a) + 6 * i, a);
         ex.stamp();

@@ -137,7 +137,21 @@ int dsim_step_forward(const dsim_model* m, int n_envs,
  * (gact / gmuscle_act may be NULL to skip).  Follows the reference's adjoint conventions
  * (SURVEY.md App. B): Cholesky treated as constant, dH = -(LL^T)^-1 g_qdd * qdd^T accumulated over
  * the substeps that reuse a factor (matnn.h:310-336), min/max/clamp/step/normalize rules of
- * adjoint.h:129-190 and vec3.h:204-222. */
+ * adjoint.h:129-190 and vec3.h:204-222.
+ *
+ * ONE STATED DEVIATION from what the reference's SimulateFunc.backward (sim.py:2127-2154) returns: for every quaternion
+ * block of joint_q (free joint: q[cs+3 .. cs+6], ball joint: q[cs .. cs+3]) gq_in has NO component along the quaternion
+ * itself.  The reference differentiates its rotation formulas literally (quat.h:232-288 adj_mul / adj_rotate,
+ * spatial.h:740-798), also in the direction in which |quat| changes, where those formulas are not rotations; that "radial"
+ * component depends on how mathematically identical formulas happen to be written, is annihilated by the integrator's
+ * quaternion normalisation (sim.py:1552, 1616) in every upstream propagation -- gradients of rollouts w.r.t. actions are
+ * unaffected and match the reference as they stand -- and is exactly zero here, where a pose cotangent is a world-frame wrench
+ * (DESIGN.md section 3).  So: gq_in == reference's gq_in minus, per quaternion block, (u . g_ref) u with u = quat / |quat|;
+ * every other output (all non-quaternion coordinates of gq_in, gqd_in, gact, gmuscle_act) equals the reference's to the fp32
+ * tolerance.  Size of the dropped part on the reference recordings: 32 % / 16 % / 8 % of max |gq_in| (Ant / Humanoid /
+ * SNUHumanoid).  A caller that needs the reference's literal value at this boundary -- none of algorithms/*.py does -- cannot
+ * get it from this library.  tests/test_gpu_parity.py::test_unprojected_gq_differs_from_the_reference_by_its_radial_part_only
+ * asserts the three statements above on the HIP kernels' raw output. */
 int dsim_step_backward(const dsim_model* m, int n_envs,
                        const float* ckpt, const float* act, const float* muscle_act,
                        float dt, int substeps, int mm_freq,

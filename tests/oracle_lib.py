@@ -123,3 +123,29 @@ def step_grad_tolerance(t, q, qd, act, mact, dt, substeps, mm_freq, gq_out, gqd_
             a, b = (project_tangent(t, q, pr[k]), project_tangent(t, q, ref[k])) if k == "gq" else (pr[k], ref[k])
             tol[k] = max(1e-3, 3.0 * relerr(a, b))
     return tol
+
+
+def radial_split(t, q, ours, ref):
+    """UN-projected comparison of a joint_q cotangent with the reference's at the operator boundary (include/dsim.h,
+    dsim_step_backward).  Returns (max |radial part of ours|, max |ours - ref + radial part of ref| over the quaternion blocks,
+    max |ours - ref| over every other coordinate, max |radial part of ref|), all relative to max |ref|: the first three must
+    vanish -- the whole un-projected difference IS the reference's radial part -- the fourth is its reported size."""
+    ours, ref, q = np.array(ours, np.float64), np.array(ref, np.float64), np.asarray(q, np.float64)
+    scale = np.abs(ref).max()
+    diff = ours - ref
+    own_rad = resid = rad_ref = 0.0
+    blocks = 0
+    for i in range(t.n_links):
+        ty, cs = int(t.joint_type[i]), int(t.joint_q_start[i])
+        sl = slice(cs + 3, cs + 7) if ty == 4 else (slice(cs, cs + 4) if ty == 2 else None)
+        if sl is None:
+            continue
+        blocks += 1
+        u = q[:, sl] / np.linalg.norm(q[:, sl], axis=1, keepdims=True)
+        ref_rad = (u * ref[:, sl]).sum(1)
+        own_rad = max(own_rad, np.abs((u * ours[:, sl]).sum(1)).max())
+        resid = max(resid, np.abs(diff[:, sl] + u * ref_rad[:, None]).max())
+        rad_ref = max(rad_ref, np.abs(ref_rad).max())
+        diff[:, sl] = 0.0
+    assert blocks
+    return own_rad / scale, resid / scale, np.abs(diff).max() / scale, rad_ref / scale

@@ -58,6 +58,25 @@ def test_step_vs_reference_golden(env, dev):
         assert relerr(r["gmact"], g["gmuscle_act_in"]) < 1e-3
 
 
+@pytest.mark.parametrize("env", ["ant", "humanoid", "snu"])
+def test_unprojected_gq_differs_from_the_reference_by_its_radial_part_only(env, dev):
+    """include/dsim.h (dsim_step_backward) states ONE deviation from the reference's adjoint at the operator boundary: the
+    cotangent of a quaternion coordinate block has no component along the quaternion itself.  Asserted here on what the HIP
+    adjoint kernel returns, WITHOUT any projection: (i) that component is zero, (ii) the difference to the reference's
+    recording is exactly the reference's own radial component, (iii) every other coordinate agrees as it stands; the size of
+    the reference's radial part is printed (32 % / 16 % / 8 % of max |gq| on these recordings)."""
+    from oracle_lib import radial_split
+    t, eng = _engine(env, dev)
+    g = golden(env + "_step")
+    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
+    r = _run(eng, dev, g["q_in"], g["qd_in"], g["act_in"], g.get("muscle_act_in"), dt, S, mm, g["gq_out"], g["gqd_out"])
+    own_rad, resid, other, rad_ref = radial_split(t, g["q_in"], r["gq"], g["gq_in"])
+    print("%s: radial part of this adjoint %.1e, residual of (ours - ref + ref's radial part) %.1e, other coordinates %.1e; "
+          "reference's radial part %.3f of max |gq|" % (env, own_rad, resid, other, rad_ref))
+    assert own_rad < 1e-4 and resid < 1e-3 and other < 1e-3
+    assert rad_ref > 0.01      # (the recordings do exercise it)
+
+
 @pytest.mark.parametrize("env,n", [("cartpole", 256), ("ant", 192), ("humanoid", 24), ("snu", 16)])
 def test_step_vs_oracle_batch(env, n, dev):
     """seeded perturbations of the golden states; sizes the scalar oracle finishes in seconds"""
