@@ -1434,6 +1434,23 @@ template <class Ctx, class Exec> struct DsimWaveDyn {
         else return false;
     }();
 };
+// The integrator's 1 / |r + dr h| of the free root's quaternion update rides in the saved block (DsimOff::qil, a padding word
+// behind qdd): integrate^T multiplies by it instead of redoing the square root and the division on its one busy lane (~35
+// dependent instructions at the head of every adjoint substep).  Full checkpoint mode, models whose only quaternion joint is
+// the free root (Ant, Humanoid); everything else recomputes as before.
+template <class Ctx, class Exec> struct DsimSavedIl {
+    static constexpr bool value = []() {
+        if constexpr (DsimWaveDyn<Ctx, Exec>::value && !Ctx::LEAN) {
+            using D = decltype(Ctx::d);
+            bool ok = decltype(Ctx::o)::qil >= 0 && (D::tmask & DSIM_TM(DSIM_JOINT_BALL)) == 0 && (D::pmask[0] & DSIM_TM(DSIM_JOINT_FREE)) != 0 &&
+                      D::D <= DSIM_PMASK_N;
+            for (int p = 1; p < DSIM_PMASK_N; ++p) ok = ok && (D::pmask[p] & DSIM_TM(DSIM_JOINT_FREE)) == 0;
+            return ok;
+        } else {
+            return false;
+        }
+    }();
+};
 template <class Ctx, class Exec>
 DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float* g_hinv, bool update_mass) {
     ex.mark(3);
@@ -1506,41 +1523,58 @@ DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float*
         float av[NDF > 0 ? NDF : 1];
 #pragma unroll
         for (int k = 0; k < NDF; ++k) av[k] = ex.shfl(acc, lds_ + k);
-        // ---- f_tot and qdd of all lanes are in LDS: the rest of the checkpoint row may be copied (side block below; its head --
-        // q, qd, which the integrator is about to overwrite -- went out during the kinematics)
-        ex.mid();
-        ex.stamp();
-        // ---- link role: semi-implicit Euler (sim.py:1505-1636), in place on q, qd
-        if (is_link) {
-            float *q = WF(q), *qd = WF(qd);
-            if (ltype == DSIM_JOINT_PRISMATIC || ltype == DSIM_JOINT_REVOLUTE) {
-                const float qdn = qdv[0] + av[0] * h;
-                qd[lds_] = qdn;
-                q[lcs] = qv[0] + qdn * h;
-            }
-            if constexpr ((MASK & (DSIM_TM(DSIM_JOINT_BALL) | DSIM_TM(DSIM_JOINT_FREE))) != 0) {
-                if (ltype == DSIM_JOINT_BALL || ltype == DSIM_JOINT_FREE) {
-                    const bool fr = ltype == DSIM_JOINT_FREE;
-                    const v3 w = mk3(qdv[0], qdv[1], qdv[2]) + mk3(av[0], av[1], av[2]) * h;
-                    q4 r;
-                    v3 pn = zero3(), vn = zero3();
-                    if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
-                        if (fr) {
-                            vn = mk3(qdv[3], qdv[4], qdv[5]) + mk3(av[3], av[4], av[5]) * h;
-                            const v3 p = mk3(qv[0], qv[1], qv[2]);
-                            pn = p + (vn + cross(w, p)) * h;
-                            r = mkq(qv[3], qv[4], qv[5], qv[6]);
-                        } else {
-                            r = mkq(qv[0], qv[1], qv[2], qv[3]);
-                        }
+        // ---- link role: semi-implicit Euler (sim.py:1505-1636).  The arithmetic comes first -- the inverse norm of the root's
+        // quaternion update belongs to the saved block (DsimSavedIl) -- then the hand-over of the checkpoint copy, then the stores
+        float qdn = 0.f, qn = 0.f;
+        v3 w = zero3(), pn = zero3(), vn = zero3();
+        q4 rn = mkq(0.f, 0.f, 0.f, 1.f);
+        const bool hinge_l = ltype == DSIM_JOINT_PRISMATIC || ltype == DSIM_JOINT_REVOLUTE;
+        const bool quat_l = ltype == DSIM_JOINT_BALL || ltype == DSIM_JOINT_FREE, fr = ltype == DSIM_JOINT_FREE;
+        if (hinge_l) {
+            qdn = qdv[0] + av[0] * h;
+            qn = qv[0] + qdn * h;
+        }
+        if constexpr ((MASK & (DSIM_TM(DSIM_JOINT_BALL) | DSIM_TM(DSIM_JOINT_FREE))) != 0) {
+            if (quat_l) {
+                w = mk3(qdv[0], qdv[1], qdv[2]) + mk3(av[0], av[1], av[2]) * h;
+                q4 r;
+                if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
+                    if (fr) {
+                        vn = mk3(qdv[3], qdv[4], qdv[5]) + mk3(av[3], av[4], av[5]) * h;
+                        const v3 p = mk3(qv[0], qv[1], qv[2]);
+                        pn = p + (vn + cross(w, p)) * h;
+                        r = mkq(qv[3], qv[4], qv[5], qv[6]);
                     } else {
                         r = mkq(qv[0], qv[1], qv[2], qv[3]);
                     }
-                    const q4 dr = qmul_v(w, r) * 0.5f;
-                    const q4 rt = r + dr * h;
-                    const float l = sqrtf(qdot(rt, rt));
-                    q4 rn = mkq(0.f, 0.f, 0.f, 1.f);
-                    if (l > 0.0f) rn = rt * (1.0f / l);
+                } else {
+                    r = mkq(qv[0], qv[1], qv[2], qv[3]);
+                }
+                const q4 dr = qmul_v(w, r) * 0.5f;
+                const q4 rt = r + dr * h;
+                const float l = sqrtf(qdot(rt, rt));
+                float il = 0.f;
+                if (l > 0.0f) {
+                    il = 1.0f / l;
+                    rn = rt * il;
+                }
+                if constexpr (DsimSavedIl<Ctx, Exec>::value) {
+                    if (is_link && fr) WF(qil)[0] = il;
+                }
+            }
+        }
+        // ---- f_tot and qdd (and the word above) of all lanes are in LDS: the rest of the checkpoint row may be copied (side block
+        // below; its head -- q, qd, which the stores below overwrite -- went out during the kinematics)
+        ex.mid();
+        ex.stamp();
+        if (is_link) {
+            float *q = WF(q), *qd = WF(qd);
+            if (hinge_l) {
+                qd[lds_] = qdn;
+                q[lcs] = qn;
+            }
+            if constexpr ((MASK & (DSIM_TM(DSIM_JOINT_BALL) | DSIM_TM(DSIM_JOINT_FREE))) != 0) {
+                if (quat_l) {
                     if (fr) {
                         st3(q + lcs, pn);
                         st3(qd + lds_ + 3, vn);
@@ -1715,11 +1749,16 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
                         r = mkq(qv[0], qv[1], qv[2], qv[3]);
                         g_rn = mkq(gqn[0], gqn[1], gqn[2], gqn[3]);
                     }
-                    const q4 rt = r + qmul_v(w, r) * (0.5f * h);   // W = (w, 0)
-                    const float l = sqrtf(qdot(rt, rt));
+                    const q4 rt = r + qmul_v(w, r) * 0.5f * h;   // W = (w, 0); the integrator's own expression, rounding included
                     q4 g_rt = mkq(0.f, 0.f, 0.f, 0.f);
-                    if (l > 0.0f) {
-                        const float il = 1.0f / l;
+                    float il = 0.f;
+                    if constexpr (DsimSavedIl<Ctx, Exec>::value) {
+                        il = WF(qil)[0];   // from the forward launch, through the checkpoint: no square root, no division here
+                    } else {
+                        const float l = sqrtf(qdot(rt, rt));
+                        if (l > 0.0f) il = 1.0f / l;
+                    }
+                    if (il > 0.0f) {
                         const q4 rn = rt * il;
                         g_rt = (g_rn + rn * (-qdot(rn, g_rn))) * il;
                     }
@@ -2853,6 +2892,10 @@ DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& s
             if (bad) WF(epf)[0] = 1.f;  // every writer stores the same value
         });
     }
+    // `done` is assigned inside a main-wave phase: the helper wavefront (Exec::HAS_HELPER) keeps done == false and skips the
+    // restart block below, which is correct ONLY because that block contains no workgroup barrier (plain run / fire phases).
+    // A fork_join there would give the two waves different barrier counts and hang the GPU: derive `done` from values both
+    // waves have (the flags in epf behind a run_both) before adding one.
     bool done = false;
     ex.run([&](int lane) {
         const float* o = WF(obs);

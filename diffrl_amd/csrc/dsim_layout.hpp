@@ -72,6 +72,8 @@ struct DsimOff {
     int q, qd, act, mact, ua, obs, xsc, S, v, a, i10, f, ftot, cw, tau, qdd, ic10, F, hinv, prow, pcol, mus;
     int mpart;                  // [MK][6] chunk sums of the muscle-row gather
     int epf;                    // episode flags (fused env surface): [0] invalid state seen, [1] episode finished
+    int qil;                    // one spare word of qdd's 16-byte padding INSIDE the saved block (-1: none): 1 / |r + dr h| of the
+                                // free root's quaternion update, left there by the integrator for integrate^T (dsim_core.hpp: DsimSavedIl)
     int save_words;             // length of the saved block that starts at q (see dsim_build_layout)
     int fwd_words;
     // ---- adjoint work arrays (floats)
@@ -392,6 +394,7 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.xsc = take(7 * L); o.S = take(6 * nd);
     o.v = take(6 * L); o.a = take(6 * L); o.i10 = take(10 * L);
     o.ftot = take(6 * L); o.qdd = take(nd);
+    o.qil = (((nd + 3) & ~3) - nd) >= 1 ? o.qdd + nd : -1;
     o.save_words = cur - o.q;
     o.act = take(nd); o.mact = take(M);
     o.ua = take(M > nd ? M : nd); o.obs = take(16 + nq + nd + (M > nd ? M : nd));

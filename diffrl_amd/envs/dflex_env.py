@@ -33,12 +33,15 @@ def find_asset(name):
 
 
 class Box:
-    """Minimal stand-in for gym.spaces.Box (rl_games only reads low / high / shape)."""
+    """Minimal stand-in for gym.spaces.Box with gym's constructor (rl_games reads low / high / shape / dtype and builds
+    Box(low=0, high=1, shape=(k,)) spaces of its own, rl_games/common/experience.py:335)."""
 
-    def __init__(self, low, high):
-        self.low, self.high = np.asarray(low, np.float32), np.asarray(high, np.float32)
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        self.dtype = np.dtype(dtype)   # (a numpy dtype object, as in gym: rl_games keys a dict with it)
+        if shape is not None:
+            low, high = np.full(shape, low, self.dtype), np.full(shape, high, self.dtype)
+        self.low, self.high = np.asarray(low, self.dtype), np.asarray(high, self.dtype)
         self.shape = self.low.shape
-        self.dtype = np.float32
 
 
 class DFlexEnv:
@@ -160,9 +163,21 @@ class DFlexEnv:
         stochastic resets -- the noise amplitudes the kernel perturbs it with (a fresh counter-based draw per restart:
         no pool to exhaust, no host work per step, nothing to redraw under a captured graph)."""
         from ..engine import EpisodeIO
+        # what the cached start states / noise amplitudes were built from: a later change of stochastic_init or of the
+        # environment's start pose (start_pos, start_rotation, start_joint_q, ...) must not be silently ignored by the fused
+        # step while the torch reset() path honours it
+        # (identity + in-place version counter of the tensors: no device work, no host sync -- this runs on every step)
+        def stamp(v):
+            return (id(v), v._version) if torch.is_tensor(v) else v
+        key = (bool(getattr(self, "stochastic_init", False)),) + tuple(
+            stamp(getattr(self, a, None)) for a in ("start_pos", "start_rotation", "start_joint_q", "start_joint_target", "start_height"))
+        if getattr(self, "_pool", None) is not None and getattr(self, "_pool_key", None) != key:
+            self._pool = None
         if getattr(self, "_pool", None) is None:
+            self._pool_key = key
             self._pool = self._deterministic_start_state()
-            self._reset_count = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+            if getattr(self, "_reset_count", None) is None:
+                self._reset_count = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
             self._noise = None
             if bool(getattr(self, "stochastic_init", False)):
                 n = self.reset_noise()
@@ -177,7 +192,13 @@ class DFlexEnv:
         return EpisodeIO(self.progress_buf, self._pool[0], self._pool[1], self._reset_count, self.episode_length,
                          self.height_terminate, self.check_invalid, want_obs_before=not self.no_grad,
                          noise_q=nq, noise_qd=nqd, noise_angle=ang,
-                         seed=(int(self.seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF)
+                         seed=self._philox_key())
+
+    def _philox_key(self):
+        """key of the in-kernel restart noise: the environment's seed mixed with the rank of the process, so that the shards of
+        a multi-GPU job (same seed, local environment indices 0..n-1 on every rank) do not draw identical restart noise"""
+        rank = int(os.environ.get("RANK", "0") or 0)
+        return (int(self.seed) * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
 
     def _step_fused(self, actions, spec):
         actions = actions.view((self.num_envs, self.num_actions))

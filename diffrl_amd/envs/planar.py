@@ -59,6 +59,14 @@ class PlanarEnv(DFlexEnv):
         self.actions = self.actions.clone()
         self.actions[env_ids, :] = 0.0
 
+    def _deterministic_start_state(self):
+        q, qd = super()._deterministic_start_state()
+        if self.stochastic_init:
+            # a stochastic reset_state() REPLACES the root angle by its noise term (envs/hopper.py:195, cheetah.py:183), it
+            # does not add it to start_rotation: the start state the in-kernel noise is added to has a zero root angle
+            q[..., 2] = 0.0
+        return q, qd
+
     def reset_noise(self):
         nq = np.empty(self.num_joint_q, np.float32)
         nq[0:2] = self.pos_noise * 2.0

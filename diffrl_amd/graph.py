@@ -42,10 +42,16 @@ class GraphedRollout:
             self._act = env.actions.detach().clone()
             self._progress = env.progress_buf.clone()
         self._frames_per_replay = None
+        self._count0 = None
         # Finished environments restart inside the captured step kernels: the start state is perturbed with counter-based
         # random numbers keyed by the per-environment restart counter, which lives in device memory and advances with every
         # replay -- nothing has to be drawn on the host (the reference's reset_state() indexed writes are not capturable).
         env._episode_io()
+        if not carry_state:
+            # the in-kernel restart noise is keyed by the per-environment restart counter, which every replay advances: a
+            # replay that restarts from the construction state must restart the counters too, or replays with
+            # stochastic_init would draw different start states ("deterministic benchmark")
+            self._count0 = env._reset_count.clone()
         # warm-up on a side stream (lazy initialisation, allocator pools), as torch.cuda.graph requires
         side = torch.cuda.Stream(device=env.device)
         side.wait_stream(torch.cuda.current_stream(env.device))
@@ -73,6 +79,8 @@ class GraphedRollout:
         env.state = st
         env.actions = self._act.clone()
         env.progress_buf = self._progress.clone()
+        if self._count0 is not None:
+            env._reset_count.copy_(self._count0)
         loss = self.body(env)
         if self.backward:
             loss.backward()

@@ -149,7 +149,7 @@ int dsim_step_forward(const dsim_model* m, int n_envs,
  * (DESIGN.md section 3).  So: gq_in == reference's gq_in minus, per quaternion block, (u . g_ref) u with u = quat / |quat|;
  * every other output (all non-quaternion coordinates of gq_in, gqd_in, gact, gmuscle_act) equals the reference's to the fp32
  * tolerance.  Size of the dropped part on the reference recordings: 32 % / 16 % / 8 % of max |gq_in| (Ant / Humanoid /
- * SNUHumanoid).  A caller that needs the reference's literal value at this boundary -- none of algorithms/*.py does -- cannot
+ * SNUHumanoid).  A caller that needs the reference's literal value at this boundary -- none of the reference's algorithms does -- cannot
  * get it from this library.  tests/test_gpu_parity.py::test_unprojected_gq_differs_from_the_reference_by_its_radial_part_only
  * asserts the three statements above on the HIP kernels' raw output. */
 int dsim_step_backward(const dsim_model* m, int n_envs,
