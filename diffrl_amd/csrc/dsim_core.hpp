@@ -302,12 +302,26 @@ constexpr int dsim_scan_rounds(int levels) {
     while ((1 << r) < levels) ++r;
     return r;
 }
+// Shallow trees keep the chain walk (DsimChainRegs), but their contact lanes do not walk chains of their own any more (round 2:
+// lane L + k re-walked the chain of contact k's body -- on the helper wavefront a second copy of the whole walk, a third of the
+// forward kernel's instructions): the link lanes publish poses and twists as soon as the walk is done, hand over (Exec::mid)
+// and go on with inertias and body forces while the contacts are evaluated from the published values.  Same code in both launch
+// modes (helper wavefront or not): bit-identical results.
+template <class Ctx, int NL> struct DsimContactsAfterWalk {
+    static constexpr bool value = []() {
+        if constexpr (DsimScanFk<Ctx, NL>::value) return false;
+        else if constexpr (DsimChainRegs<Ctx>::value) {
+            using D = decltype(Ctx::d);
+            return NL == DSIM_NL && D::C > 0 && D::C <= NL && D::L <= NL && D::nd <= NL && D::NS == 0;
+        } else return false;
+    }();
+};
 // Contacts evaluated INSIDE the kinematics phase: lane L + k walks the ancestor chain of contact k's body next to the link
 // lanes (same instruction stream, so the walk costs nothing extra) and evaluates its contact from the pose and twist it
 // holds in registers -- no phase boundary, no reload of X_sc / v.  Needs the chain records and L + C lanes.
 template <class Ctx, int NL> struct DsimContactsInKin {
     static constexpr bool value = []() {
-        if constexpr (DsimScanFk<Ctx, NL>::value) return false;   // they read the finished poses instead
+        if constexpr (DsimScanFk<Ctx, NL>::value || DsimContactsAfterWalk<Ctx, NL>::value) return false;   // they read the finished poses instead
         else if constexpr (DsimChainRegs<Ctx>::value) return decltype(Ctx::d)::C > 0 && decltype(Ctx::d)::L + decltype(Ctx::d)::C <= NL;
         else return false;
     }();
@@ -899,12 +913,98 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_scan(const Ctx
     });
 }
 
+// Chain walk of a shallow tree with the contacts behind it (DsimContactsAfterWalk).  Every lane runs the whole block (lanes past
+// the last link have an empty chain and store nothing), so that the hand-over is a point all lanes pass.
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_walk_mid(const Ctx& c, Exec& ex, float* g_row) {
+    using D = decltype(c.d);
+    ex.fork_join_mid([&](int lane) {
+        const bool on = lane < D::L;
+        const int i = on ? lane : 0;
+        DsimFkWalk w;
+        w.psp = zero3();
+        w.rsp = mkq(0.f, 0.f, 0.f, 1.f);
+        w.v = zerosv();
+        w.a = zerosv();
+        w.s0 = w.s1 = w.s2 = zerosv();
+        // body constants of the link, requested together with the chain inputs
+        const v3 com = ld3(CF(com) + 3 * i);
+        const float* icp = CF(ic6) + 6 * i;
+        const float ic0 = icp[0], ic1 = icp[1], ic2 = icp[2], ic3 = icp[3], ic4 = icp[4], ic5 = icp[5];
+        const float m = CF(mass)[i];
+        const v3 grav = ld3(CF(grav));
+        const int* ch = ex.topo(lane).chain;
+        int n = ch[4 * DSIM_CHAIN_MAX];
+        DSIM_OPAQUE(n);
+        if constexpr (D::D <= 4) {
+            DsimFkPre<D, 0, D::D> pre;
+            dsim_fk_load_all<D, 0, D::D>(c, ch, pre);
+            dsim_fk_compute_all<D, 0, D::D>(w, ch, n, pre);
+        } else {
+            DsimFkPre<D, 0, 3> pre;
+            dsim_fk_load_all<D, 0, 3>(c, ch, pre);
+            dsim_fk_walk_chunks<D, 0>(c, w, ch, n, pre);
+        }
+        int own_type = ex.topo(lane).own_type;
+        const int own_ds = ex.topo(lane).own_ds;
+        DSIM_OPAQUE(own_type);
+        const v3 pc = w.psp;
+        const q4 rc = w.rsp;
+        if (on) {
+            st3(WF(xsc) + 7 * i, pc);
+            stq(WF(xsc) + 7 * i + 3, rc);
+            stsv(WF(v) + 6 * i, w.v);
+        }
+        ex.stamp();
+        ex.mid();   // poses and twists of every link are in LDS: the contacts may start
+        // COM, world inertia about the origin (Theta = R Ic R^T, A = Theta + m(c.c 1 - c c^T), h = m c) and body force
+        const v3 cm = rotate(rc, com) + pc;
+        v3 rx, ry, rz;
+        rotate_basis(rc, rx, ry, rz);
+        const v3 b0 = rx * ic0 + ry * ic1 + rz * ic2;
+        const v3 b1 = rx * ic1 + ry * ic3 + rz * ic4;
+        const v3 b2 = rx * ic2 + ry * ic4 + rz * ic5;
+        inertia10 I;
+        I.m = m;
+        I.h = cm * m;
+        const float cc = dot(cm, cm);
+        I.axx = b0.x * rx.x + b1.x * ry.x + b2.x * rz.x + m * (cc - cm.x * cm.x);
+        I.axy = b0.x * rx.y + b1.x * ry.y + b2.x * rz.y - m * cm.x * cm.y;
+        I.axz = b0.x * rx.z + b1.x * ry.z + b2.x * rz.z - m * cm.x * cm.z;
+        I.ayy = b0.y * rx.y + b1.y * ry.y + b2.y * rz.y + m * (cc - cm.y * cm.y);
+        I.ayz = b0.y * rx.z + b1.y * ry.z + b2.y * rz.z - m * cm.y * cm.z;
+        I.azz = b0.z * rx.z + b1.z * ry.z + b2.z * rz.z + m * (cc - cm.z * cm.z);
+        const sv6 fb = inertia_mul(I, w.a) + scross_dual(w.v, inertia_mul(I, w.v));
+        const v3 mg = grav * m;
+        const sv6 fg = mksv(cross(cm, mg), mg);
+        if (on) {
+            stsv(WF(a) + 6 * i, w.a);
+            st_i10(WF(i10) + 10 * i, I);
+            stsv(WF(f) + 6 * i, fb - fg);
+            float* S = WF(S) + 6 * own_ds;
+            if (own_type == DSIM_JOINT_PRISMATIC || own_type == DSIM_JOINT_REVOLUTE) {
+                stsv(S, w.s0);
+            } else if (own_type == DSIM_JOINT_BALL) {
+                stsv(S, w.s0);
+                stsv(S + 6, w.s1);
+                stsv(S + 12, w.s2);
+            }
+        }
+    }, [&](int lane) {
+        dsim_fwd_contacts(c, ex, lane);
+        if (g_row) dsim_ckpt_store_row<Ctx, Exec::NL, 1>(c, lane, g_row);   // head of the checkpoint row: (q, qd) entering the substep
+    });
+}
+
 // g_row (one-phase dynamics only, DsimWaveDyn): the substep's checkpoint row -- its head (q, qd) is copied here, by the helper
 // wavefront where there is one, the rest beside the integrator (dsim_fwd_dynamics_wave)
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, Exec& ex, float* g_row = nullptr) {
     ex.mark(1);
     if constexpr (DsimScanFk<Ctx, Exec::NL>::value) {
         dsim_fwd_kinematics_scan(c, ex, g_row);
+        return;
+    }
+    if constexpr (DsimContactsAfterWalk<Ctx, Exec::NL>::value) {
+        dsim_fwd_kinematics_walk_mid(c, ex, g_row);
         return;
     }
     // "Flat" forward kinematics: every link's lane walks its own ancestor chain from the root and recomputes the
@@ -1037,7 +1137,8 @@ template <class Ctx> DSIM_FN void dsim_muscle_chunk_sums(const Ctx& c, int lane,
 // ground contacts (sim.py:1137-1206) and muscle segments (sim.py:1209-1242): per-item wrenches
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Exec& ex) {
     ex.mark(2);
-    constexpr bool in_kin = DsimContactsInKin<Ctx, Exec::NL>::value || DsimScanFk<Ctx, Exec::NL>::value;  // contacts were done by the kinematics phase
+    constexpr bool in_kin = DsimContactsInKin<Ctx, Exec::NL>::value || DsimScanFk<Ctx, Exec::NL>::value ||
+                            DsimContactsAfterWalk<Ctx, Exec::NL>::value;  // contacts were done by the kinematics phase
     if ((c.d.C == 0 || in_kin) && c.d.NS == 0) return;
     ex.run([&](int lane) {
         if constexpr (!in_kin) dsim_fwd_contacts(c, ex, lane);
