@@ -140,7 +140,7 @@ def issue_view(sq, n):
         return None
 
 
-def roofline_record(env, name, n, H, mm, device, reps):
+def roofline_record(env, name, n, H, mm, device, reps, counters=True):
     """roofline object of one configuration: times the adjoint and the forward launch with HIP events (same shapes as the
     rollout), algorithmic bytes per SURVEY.md 8(d), and -- from the committed counter file of these very kernels -- measured HBM
     traffic, VALU instructions per env-step and the VALU-issue fraction that actually bounds these kernels."""
@@ -157,7 +157,7 @@ def roofline_record(env, name, n, H, mm, device, reps):
     ckpt_floats = int(eng._lib.dsim_ckpt_floats_mm(eng._h, env.sim_substeps, mm))
     traffic = 4 * n * ckpt_floats + bwd_bytes
     traffic_src = "analytic: checkpoint words x N x 4 + boundary tensors (no counter file for these kernel sources)"
-    pmc = pmc_record(name, n, mm)
+    pmc = pmc_record(name, n, mm) if counters else None   # (the committed counter files describe the SPECIALISED kernels)
     r = {"bound": "valu-issue", "kernel": "dsim_env_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": achieved / HBM_PEAK_GBS, "alg_bytes_per_launch": bwd_bytes, "kernel_ms": t_bwd * 1e3,
          "fwd_kernel_ms": t_fwd * 1e3, "fwd_alg_bytes_per_launch": fwd_bytes, "csrc_hash": csrc_hash(),
@@ -227,7 +227,7 @@ def measure_other_config(name, n, H, mm, device, steps=10, generic=False):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         assert torch.isfinite(acts.grad).all()
-        rf = roofline_record(env, name, n, H, mm, device, 20)
+        rf = roofline_record(env, name, n, H, mm, device, 20, counters=not generic)
         return {"workload": "%s %d envs x H=%d, MM_caching_frequency %d" % (name, n, H, mm), "value": steps * n * H / el,
                 "unit": "env-steps/s", "steps": steps, "ms_per_rollout": el / steps * 1e3, "kernel_ms": rf["kernel_ms"],
                 "fwd_kernel_ms": rf["fwd_kernel_ms"], "ckpt_bytes_per_env_step": rf["ckpt_bytes_per_env_step"],
