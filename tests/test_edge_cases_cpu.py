@@ -223,3 +223,29 @@ def test_random_trees_with_muscles(seed, floating):
                gact=relerr(r["gact"], o["gact"]), gmact=relerr(r["gmact"], o["gmact"]))
     tol = step_grad_tolerance(t, q, qd, act, mact, dt, S, mm, gq, gqd, err, ref=o)   # 1e-3, or probed
     assert np.abs(o["gmact"]).max() > 0 and all(err[k] < tol[k] for k in err), (err, tol)
+
+
+def test_half_angle_polynomials_at_and_beyond_their_range():
+    """dsim_math.hpp::half_angle_sincos replaces sinf / cosf of a joint half-angle by degree-11 / 12 polynomials for
+    |angle / 2| <= pi / 2 and falls back to the library routines beyond.  Isolated here: a revolute chain whose joint angles sit
+    at the ends of the hot range, just inside and just outside the switch (|q| = pi -/+ 1e-3), at +-pi exactly and far outside
+    (several turns), first-substep link poses X_sc and the end state against the scalar oracle, which calls sinf / cosf as the
+    reference does (quat.h:44-52).  Bound: 1e-6 relative on the poses -- below the 1e-5 budget of a substep by a decade."""
+    from ckpt_fields import first_substep
+    from oracle_lib import oracle_forward
+    t = _chain(3, with_shapes=True, floating=False)
+    angles = np.array([0.0, 1.0, -1.0, np.pi - 1e-3, -(np.pi - 1e-3), np.pi, -np.pi, np.pi + 1e-3, -(np.pi + 1e-3), 2.5 * np.pi,
+                       -7.3, 3.0, -3.1], np.float32)
+    n = len(angles)
+    q = np.zeros((n, t.n_q), np.float32)
+    q[:, 0] = angles
+    q[:, 1] = angles[::-1]
+    q[:, 2] = 0.5 * angles
+    qd = np.zeros((n, t.n_qd), np.float32)
+    act = np.zeros((n, t.n_qd), np.float32)
+    dt, S, mm = 1.0 / 960.0, 1, 1
+    qo, qdo, ck = emu_forward(t, q, qd, act, None, dt, S, mm, want_ckpt=True)
+    o_q, o_qd, dbg = oracle_forward(t, q, qd, act, None, dt, S, mm, debug=True)
+    X = first_substep(t, ck)["X_sc"]
+    assert relerr(X, dbg["X_sc"]) < 1e-6
+    assert relerr(qo, o_q) < 1e-6

@@ -130,3 +130,27 @@ def test_clip_range_gradients():
     g = a.grad
     assert float(g[:, 2].abs().max()) == 0.0 and float(g[:, 3].abs().max()) == 0.0
     assert float(g[:, [0, 1, 4, 5, 6, 7]].abs().min()) > 0.0
+
+
+def test_half_angle_polynomials_at_and_beyond_their_range_on_the_gpu():
+    """the GPU side of tests/test_edge_cases_cpu.py::test_half_angle_polynomials_at_and_beyond_their_range: revolute angles at
+    the ends of the polynomial range of dsim_math.hpp::half_angle_sincos, at the switch to sinf / cosf and beyond, first-substep
+    link poses (read back from the checkpoint the HIP kernel wrote) and end state against the scalar oracle"""
+    from ckpt_fields import first_substep
+    from diffrl_amd.engine import Engine
+    from oracle_lib import oracle_forward
+    t = _chain(3, True, False)
+    eng = Engine(t, DEV)
+    angles = np.array([0.0, 1.0, -1.0, np.pi - 1e-3, -(np.pi - 1e-3), np.pi, -np.pi, np.pi + 1e-3, -(np.pi + 1e-3), 2.5 * np.pi,
+                       -7.3, 3.0, -3.1], np.float32)
+    n = len(angles)
+    q = np.zeros((n, t.n_q), np.float32)
+    q[:, 0], q[:, 1], q[:, 2] = angles, angles[::-1], 0.5 * angles
+    qd, act = np.zeros((n, t.n_qd), np.float32), np.zeros((n, t.n_qd), np.float32)
+    dt, S, mm = 1.0 / 960.0, 1, 1
+    T = lambda a: torch.tensor(a, device=torch.device(DEV)).reshape(-1)  # noqa: E731
+    qo, qdo, ck = eng.forward(T(q), T(qd), T(act), None, dt, S, mm, True)
+    torch.cuda.synchronize()
+    o_q, o_qd, dbg = oracle_forward(t, q, qd, act, None, dt, S, mm, debug=True)
+    assert relerr(first_substep(t, ck.cpu().numpy())["X_sc"], dbg["X_sc"]) < 1e-6
+    assert relerr(qo.cpu().numpy().reshape(n, -1), o_q) < 1e-6
