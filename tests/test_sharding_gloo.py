@@ -31,7 +31,11 @@ def _worker(rank, world, port, q):
     elapsed = 1.0 + 0.5 * r
     job_t = sharding.max_over_ranks(elapsed)
     job_steps = sharding.sum_over_ranks((hi - lo) * 32)
-    q.put((r, lo, hi, job_t, job_steps))
+    # every rank builds its shard with the same seed and local environment indices 0..n-1: the key of the in-kernel restart
+    # noise must still differ between ranks (DFlexEnv._philox_key mixes the rank in), or all shards would draw the same restarts
+    from diffrl_amd import envs
+    e = envs.CartPoleSwingUpEnv(num_envs=4, device="cpu", no_grad=True, seed=7)
+    q.put((r, lo, hi, job_t, job_steps, e._philox_key()))
     import torch.distributed as td
     td.barrier()
     td.destroy_process_group()
@@ -51,3 +55,4 @@ def test_two_process_gloo():
     assert [(r[1], r[2]) for r in res] == [(0, 500), (500, 1000)]
     assert all(abs(r[3] - 1.5) < 1e-12 for r in res)          # max over ranks
     assert all(abs(r[4] - 32000) < 1e-9 for r in res)         # whole-job env-steps
+    assert res[0][5] != res[1][5] and all(0 <= r[5] < 2 ** 64 for r in res)   # rank-specific Philox keys
