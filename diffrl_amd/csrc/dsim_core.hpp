@@ -1557,6 +1557,15 @@ DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float*
     ex.mark(3);
     using D = decltype(c.d);
     constexpr int nd = D::nd, L = D::L;
+    // The detached side block below (checkpoint copy on the helper wavefront) is still reading X_sc .. qdd and H^-1 when the
+    // main wave returns: the NEXT substep's kinematics must therefore start behind a workgroup barrier, which only the
+    // fork_join / fork_join_mid forms of dsim_fwd_kinematics have.  A specialised model with a helper wave whose tree is deeper
+    // than DSIM_CHAIN_MAX / 2^DSIM_SCAN_ROUNDS_MAX would fall through to the plain ex.run() walk (no barrier) and overwrite
+    // the rows under the copy: refuse to compile that combination instead of corrupting checkpoints.
+    static_assert(!Exec::HAS_HELPER || DsimScanFk<Ctx, Exec::NL>::value || DsimContactsAfterWalk<Ctx, Exec::NL>::value ||
+                      DsimContactsInKin<Ctx, Exec::NL>::value,
+                  "helper-wave kernels need a kinematics phase that starts with a workgroup barrier (tree too deep for the chain "
+                  "registers and the scan): build this model without a helper wavefront (dsim_has_helper)");
     ex.fork_mid_detached([&](int lane) {
         constexpr int MASK = dsim_tmask_static<Ctx>();
         constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
@@ -2293,6 +2302,11 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
             a_hv.w = cross(r.w, v.w);
             a_hv.v = cross(r.w, v.v) + cross(r.v, v.w);
             a_v += inertia_mul(I, a_hv);
+#ifdef DSIM_INJECT_ADJ_ERROR
+            // developer / test builds ONLY (tests/test_probe_ledger.py, -DDSIM_INJECT_ADJ_ERROR=1.01f): a deliberate relative error
+            // in one adjoint phase, to show that the parity tests' probed tolerances cannot absorb a real adjoint defect
+            a_v = a_v * DSIM_INJECT_ADJ_ERROR;
+#endif
             inertia_bilinear_adj(g, r, a, 1.0f);
             inertia_bilinear_adj(g, a_hv, v, 1.0f);
             // pose wrench of the link: inertia + gravity (f_g = (c x m g, m g) enters f with a minus sign)

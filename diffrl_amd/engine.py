@@ -89,9 +89,10 @@ class Engine:
         """a checkpoint must be consumed with the geometry (substeps, mass-matrix frequency, checkpoint mode) it was written
         with: the row stride differs otherwise and the adjoint launch would read other rows' words"""
         words = int(self._lib.dsim_ckpt_floats_mm(self._h, substeps, mm_freq))
-        if ckpt.dim() != 2 or ckpt.shape[1] != words or ckpt.device != self.device or ckpt.dtype != torch.float32:
+        if (ckpt.dim() != 2 or ckpt.shape[1] != words or ckpt.device != self.device or ckpt.dtype != torch.float32
+                or not ckpt.is_contiguous()):   # (a strided view, e.g. ckpt[::2], has the right shape and the wrong row stride)
             raise capi.DsimError("checkpoint of shape %s does not match this model / step geometry (%d floats per environment "
-                                 "in '%s' mode on %s)" % (tuple(ckpt.shape), words, self.ckpt_mode, self.device))
+                                 "in '%s' mode on %s, contiguous rows)" % (tuple(ckpt.shape), words, self.ckpt_mode, self.device))
 
     def backward(self, ckpt, act, mact, dt, substeps, mm_freq, gq_out, gqd_out):
         self._check_ckpt(ckpt, substeps, mm_freq)

@@ -167,15 +167,28 @@ class DFlexEnv:
         # environment's start pose (start_pos, start_rotation, start_joint_q, ...) must not be silently ignored by the fused
         # step while the torch reset() path honours it
         # (identity + in-place version counter of the tensors: no device work, no host sync -- this runs on every step)
+        # (the key keeps a reference to each tensor: an id() alone could be recycled by a NEW tensor after the old one died)
         def stamp(v):
             return (id(v), v._version) if torch.is_tensor(v) else v
-        key = (bool(getattr(self, "stochastic_init", False)),) + tuple(
-            stamp(getattr(self, a, None)) for a in ("start_pos", "start_rotation", "start_joint_q", "start_joint_target", "start_height"))
-        if getattr(self, "_pool", None) is not None and getattr(self, "_pool_key", None) != key:
-            self._pool = None
-        if getattr(self, "_pool", None) is None:
+        attrs = tuple(getattr(self, a, None) for a in ("start_pos", "start_rotation", "start_joint_q", "start_joint_target", "start_height"))
+        self._pool_key_refs = attrs
+        key = (bool(getattr(self, "stochastic_init", False)),) + tuple(stamp(v) for v in attrs)
+        stale = getattr(self, "_pool", None) is not None and getattr(self, "_pool_key", None) != key
+        if stale and getattr(self, "_pool_pinned", False):
+            # a captured GraphedRollout holds the device pointers of the pool / noise tensors AND the launch arguments that
+            # were derived from them (noise on or off, the rotation amplitude): a replay cannot follow such a change
+            raise RuntimeError("%s: stochastic_init or a start-state attribute changed after a GraphedRollout was captured on "
+                               "this environment; build a new GraphedRollout (the captured launches keep the old start "
+                               "states)" % type(self).__name__)
+        if getattr(self, "_pool", None) is None or stale:
             self._pool_key = key
-            self._pool = self._deterministic_start_state()
+            q0, qd0 = self._deterministic_start_state()
+            if stale and self._pool[0].shape == q0.shape and self._pool[1].shape == qd0.shape:
+                # in place: tensors handed out earlier (EpisodeIO objects of earlier steps) stay valid
+                self._pool[0].copy_(q0)
+                self._pool[1].copy_(qd0)
+            else:
+                self._pool = (q0, qd0)
             if getattr(self, "_reset_count", None) is None:
                 self._reset_count = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
             self._noise = None

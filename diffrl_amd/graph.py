@@ -70,6 +70,9 @@ class GraphedRollout:
             self.loss = self._run_once(write_back=carry_state)
         self._frames_per_replay = env.num_frames - f0
         torch.cuda.synchronize(env.device)
+        # the captured launches hold the pointers of the environment's start-state pool and the noise settings: from now on a
+        # change of stochastic_init / start_* raises in DFlexEnv._episode_io instead of being silently ignored by replays
+        env._pool_pinned = True
 
     def _run_once(self, write_back):
         env = self.env
@@ -94,6 +97,7 @@ class GraphedRollout:
 
     def replay(self):
         """re-executes the captured rollout (forward + backward); returns the static loss tensor"""
+        self.env._episode_io()   # raises if the start-state settings changed since the capture (host-side check, no GPU work)
         self.graph.replay()
         if self._frames_per_replay:
             self.env.num_frames += self._frames_per_replay

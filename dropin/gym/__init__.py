@@ -1,65 +1,17 @@
 """Stand-in for the `gym` package, only as far as the reference's callers import it (externals/rl_games, envs/dflex_env.py:18):
-base classes that rl_games' wrappers subclass and the `spaces` it inspects.  Provided only when the real package is absent
+base classes that rl_games' wrappers subclass and the `spaces` it inspects.  Used only when the real package is absent: __init__ looks for an installed `gym` behind this directory on sys.path first
 (this directory sits on PYTHONPATH for the unmodified-caller runs; the diffrl_amd package itself never imports gym)."""
-from . import spaces  # noqa: F401
+import importlib.machinery as _mach
+import importlib.util as _util
+import os as _os
+import sys as _sys
 
-
-class Env:
-    metadata, reward_range, action_space, observation_space = {}, (-float("inf"), float("inf")), None, None
-
-    def step(self, action):
-        raise NotImplementedError
-
-    def reset(self, **kw):
-        raise NotImplementedError
-
-    @property
-    def unwrapped(self):
-        return self
-
-
-class Wrapper(Env):
-    def __init__(self, env):
-        self.env = env
-        self.action_space, self.observation_space = getattr(env, "action_space", None), getattr(env, "observation_space", None)
-
-    def __getattr__(self, name):
-        return getattr(self.env, name)
-
-    def step(self, action):
-        return self.env.step(action)
-
-    def reset(self, **kw):
-        return self.env.reset(**kw)
-
-    @property
-    def unwrapped(self):
-        return self.env.unwrapped
-
-
-class ObservationWrapper(Wrapper):
-    pass
-
-
-class RewardWrapper(Wrapper):
-    pass
-
-
-class ActionWrapper(Wrapper):
-    pass
-
-
-def make(*a, **kw):
-    raise RuntimeError("gym stand-in (dropin/gym): gym.make is not available; only DFlexEnv environments run here")
-
-
-class _Registry:
-    """gym.envs.register(...) calls of rl_games' bundled test environments: recorded, never instantiated"""
-    registered = {}
-
-    def register(self, id=None, **kw):
-        self.registered[id] = kw
-
-
-envs = _Registry()
-register = envs.register
+_dropin = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+_real = _mach.PathFinder.find_spec(__name__, [p for p in _sys.path if _os.path.abspath(p or ".") != _dropin])
+if _real is not None and _real.loader is not None:
+    # the real package is installed somewhere behind this directory on sys.path: step aside and load it under this name
+    _m = _util.module_from_spec(_real)
+    _sys.modules[__name__] = _m
+    _real.loader.exec_module(_m)
+else:
+    from ._standin import *  # noqa: F401,F403

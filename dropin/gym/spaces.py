@@ -2,8 +2,11 @@
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from diffrl_amd.envs.dflex_env import Box  # noqa: F401,E402
+try:
+    from diffrl_amd.envs.dflex_env import Box  # noqa: F401
+except ImportError:   # the repository root is not on sys.path yet (PYTHONPATH=<repo>/dropin only): add it, once
+    sys.path.append(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from diffrl_amd.envs.dflex_env import Box  # noqa: F401,E402
 
 
 class Space:

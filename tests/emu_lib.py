@@ -16,8 +16,11 @@ _lib = None
 def emu():
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-C", EMU_DIR, "-s"])
-        _lib = C.CDLL(os.path.join(EMU_DIR, "libdsim_emu.so"))
+        # DSIM_EMU_LIB: another build of the harness (tests/test_probe_ledger.py runs the parity tests against the one with
+        # an injected adjoint error, libdsim_emu_inject.so)
+        name = os.environ.get("DSIM_EMU_LIB") or "libdsim_emu.so"
+        subprocess.check_call(["make", "-C", EMU_DIR, "-s", name] if name != "libdsim_emu.so" else ["make", "-C", EMU_DIR, "-s"])
+        _lib = C.CDLL(os.path.join(EMU_DIR, name))
     return _lib
 
 
