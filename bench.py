@@ -121,18 +121,39 @@ def pmc_record(name, n, mm):
 
 SIMDS = 1024            # MI355X: 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 FP32_VALU_PEAK = 157.3e12
+CLOCK_HZ = 2.4e9        # shader clock (MI355X_MICROARCH.md)
+SIMD_VALU_CYCLES = 2.0  # a wave64 fp32 VALU instruction occupies its SIMD-32 for 2 cycles (guide, per-instruction constants)
+LONE_WAVE_CADENCE = 4.3 # cycles between two instructions of ONE wavefront, dependent or not (tools/micro/issue_cadence.hip)
 
 
-def issue_view(sq, n):
-    """VALU-issue view of one launch from its SQ counters (quad-cycles summed over the launch's wavefronts): one wave64 VALU
-    instruction occupies its SIMD's issue port for one quad-cycle, so busy fraction of the port = SQ_ACTIVE_INST_VALU per
-    occupied SIMD / lifetime of a wave (SQ_WAVE_CYCLES per wave).  None where a counter is missing."""
+def issue_view(sq, n, t_kernel=None, helper=False):
+    """VALU-issue view of one launch from its SQ counters (quad-cycles summed over the launch's wavefronts).
+    valu_issue_frac: busy fraction of the issue slots ONE wavefront can use (SQ_ACTIVE_INST_VALU per occupied SIMD / lifetime of
+      a wave; 1.0 = an instruction every quad-cycle, the cadence of a lone wave -- which is HALF of what the SIMD can do).
+    valu_simd_frac: fraction of the SIMD-32's VALU rate -- VALU instructions per occupied SIMD x 2 cycles / kernel cycles
+      (t_kernel measured in this run x 2.4 GHz): the fraction of the MACHINE, the honest roof of a VALU-bound kernel.
+    stall_frac: 1 - issue cycles of an environment's critical wavefront / kernel cycles, the issue cycles being its
+      instructions of all kinds (VALU + SALU + LDS) x the 4.3-cycle cadence of a lone wave.  Helper-wave kernels: the main wave
+      is charged with ALL of the environment's instructions (the helper's ~15 % included), so this is a LOWER bound of the
+      stall share; kernels with W symmetric waves per environment: a W-th of them.
+    None where a counter is missing."""
     try:
         waves = sq.get("SQ_WAVES") or None
-        out = {"valu_insts_per_env_step": sq["SQ_INSTS_VALU"] / n, "lds_insts_per_env_step": sq["SQ_INSTS_LDS"] / n}
+        out = {"valu_insts_per_env_step": sq["SQ_INSTS_VALU"] / n, "lds_insts_per_env_step": sq["SQ_INSTS_LDS"] / n,
+               "salu_insts_per_env_step": sq.get("SQ_INSTS_SALU", 0.0) / n}
         if waves:
             out["waves_per_env"] = waves / n
             out["valu_issue_frac"] = (sq["SQ_ACTIVE_INST_VALU"] / min(SIMDS, waves)) / (sq["SQ_WAVE_CYCLES"] / waves)
+            if t_kernel:
+                cyc = t_kernel * CLOCK_HZ
+                out["valu_simd_frac"] = sq["SQ_INSTS_VALU"] / min(SIMDS, waves) * SIMD_VALU_CYCLES / cyc
+                per_env = (sq["SQ_INSTS_VALU"] + sq.get("SQ_INSTS_SALU", 0.0) + sq["SQ_INSTS_LDS"]) / n
+                crit = per_env if helper else per_env / max(waves / n, 1.0)
+                crit_waves = n if helper else waves
+                # (defined while every critical wave has a SIMD to itself; with several per SIMD their waiting overlaps)
+                out["stall_frac"] = 1.0 - crit * LONE_WAVE_CADENCE / cyc if crit_waves <= SIMDS else None
+        if sq.get("SQ_LDS_BANK_CONFLICT") is not None and sq.get("SQ_ACTIVE_INST_LDS"):
+            out["lds_bank_conflict_frac"] = sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_ACTIVE_INST_LDS"]
         if sq.get("SQ_THREAD_CYCLES_VALU"):
             out["valu_active_lanes_avg"] = sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"]
         return out
@@ -162,21 +183,33 @@ def roofline_record(env, name, n, H, mm, device, reps, counters=True):
          "frac": achieved / HBM_PEAK_GBS, "alg_bytes_per_launch": bwd_bytes, "kernel_ms": t_bwd * 1e3,
          "fwd_kernel_ms": t_fwd * 1e3, "fwd_alg_bytes_per_launch": fwd_bytes, "csrc_hash": csrc_hash(),
          "ckpt_bytes_per_env_step": 4 * ckpt_floats, "ckpt_bytes_per_rollout": 4 * ckpt_floats * n * H,
-         "valu_issue_frac": None, "fwd_valu_issue_frac": None, "valu_insts_per_env_step": None,
+         "valu_issue_frac": None, "fwd_valu_issue_frac": None, "valu_simd_frac": None, "fwd_valu_simd_frac": None,
+         "stall_frac": None, "fwd_stall_frac": None, "valu_insts_per_env_step": None,
          "note": "achieved / frac: ALGORITHMIC bytes of the adjoint launch against the HBM peak, as BASELINE.json asks -- not what "
-                 "binds these kernels (~1,900 flop per algorithmic byte, SURVEY 8d).  bound: the VALU issue port of the SIMD an "
-                 "environment's wavefronts run on; valu_issue_frac = busy fraction of that port (1.0 = an instruction every "
-                 "4 cycles), hbm_measured_frac = counter traffic / kernel time / 8 TB/s (the traffic is the saved forward "
-                 "block the adjoint reads back instead of recomputing, DESIGN.md section 4)"}
+                 "binds these kernels (~1,900 flop per algorithmic byte, SURVEY 8d).  bound: the instruction stream of the ONE "
+                 "wavefront an environment's phases run on.  valu_simd_frac = VALU instructions per occupied SIMD x 2 cycles "
+                 "/ kernel cycles: the fraction of the SIMD-32's VALU rate, i.e. of the machine; valu_issue_frac = busy fraction "
+                 "of the issue slots a LONE wave can use (1.0 = an instruction every 4 cycles = half the SIMD's rate); stall_frac "
+                 "= 1 - (the environment's instructions x the 4.3-cycle lone-wave cadence) / kernel cycles, a lower bound of the "
+                 "share of the kernel spent waiting (LDS / cross-lane round trips, barriers, sqrt / div); hbm_measured_frac = "
+                 "counter traffic / kernel time / 8 TB/s (the traffic is the saved forward block the adjoint reads back instead "
+                 "of recomputing, DESIGN.md section 4)"}
     if pmc:
         traffic, traffic_src = pmc["traffic_bytes_per_launch"], "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), " + pmc["file"]
         r["counters"] = pmc["file"]
-        b, f = issue_view(pmc.get("sq_adjoint") or {}, n), issue_view(pmc.get("sq_forward") or {}, n)
+        def helper_kernels(sq):   # one-wave mapping + helper wavefront: two waves per environment
+            return bool(sq.get("SQ_WAVES")) and abs(sq["SQ_WAVES"] / n - 2.0) < 1e-6
+        sa, sf = pmc.get("sq_adjoint") or {}, pmc.get("sq_forward") or {}
+        b, f = issue_view(sa, n, t_bwd, helper_kernels(sa)), issue_view(sf, n, t_fwd, helper_kernels(sf))
         if b:
             r["valu_issue_frac"] = b.get("valu_issue_frac")
+            r["valu_simd_frac"] = b.get("valu_simd_frac")
+            r["stall_frac"] = b.get("stall_frac")
             r["adjoint"] = b
         if f:
             r["fwd_valu_issue_frac"] = f.get("valu_issue_frac")
+            r["fwd_valu_simd_frac"] = f.get("valu_simd_frac")
+            r["fwd_stall_frac"] = f.get("stall_frac")
             r["forward"] = f
         if b and f:
             r["valu_insts_per_env_step"] = b["valu_insts_per_env_step"] + f["valu_insts_per_env_step"]
@@ -284,6 +317,10 @@ def parse_args(argv=None):
     ap.add_argument("--strict", action="store_true", help="exit non-zero if the graph capture fell back to the eager loop")
     ap.add_argument("--launcher", action="store_true",
                     help="go through torch.distributed.run even for --gpus 1 (an RCCL group of one rank)")
+    ap.add_argument("--oversubscribe", type=int, default=1,
+                    help="R > 1: R ranks PER GPU (backend gloo; RCCL refuses two ranks on one device).  NOT a scaling measurement: "
+                         "it exists so that the launcher -> shard -> Engine -> timing all-reduce path executes with world_size > 1 "
+                         "against real kernels on a 1-GPU box; the line says oversubscribed: true and keeps n_gpus = --gpus")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch the ranks, rendezvous, exchange the timing all-reduce and print the JSON skeleton, "
                          "without touching the GPU engine (CPU test of the launcher; backend gloo when no GPU is visible)")
@@ -304,7 +341,7 @@ def launch_ranks(a, argv):
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus * a.oversubscribe),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -314,18 +351,21 @@ def launch_ranks(a, argv):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     a = parse_args(argv)
-    if a.gpus < 1:
-        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+    if a.gpus < 1 or a.oversubscribe < 1:
+        sys.stderr.write("bench.py: --gpus and --oversubscribe must be >= 1\n")
         return 2
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-    if not under_launcher and (a.gpus > 1 or a.launcher or a.dry_run):
+    if not under_launcher and (a.gpus > 1 or a.oversubscribe > 1 or a.launcher or a.dry_run):
         return launch_ranks(a, argv)
 
     from diffrl_amd import sharding
     rank, local, world = sharding.world()
-    if world != a.gpus:
-        sys.stderr.write("bench.py: launched with WORLD_SIZE=%d but --gpus %d; the label must match the job\n" % (world, a.gpus))
+    over = a.oversubscribe > 1
+    if world != a.gpus * a.oversubscribe:
+        sys.stderr.write("bench.py: launched with WORLD_SIZE=%d but --gpus %d%s; the label must match the job\n"
+                         % (world, a.gpus, (" x --oversubscribe %d" % a.oversubscribe) if over else ""))
         return 2
+    local = local // a.oversubscribe   # R consecutive local ranks share a device
     dist = under_launcher   # launched by torch.distributed.run: RCCL process group even for one rank
     use_gpu = torch.cuda.is_available()
     if not use_gpu and not a.dry_run:
@@ -342,9 +382,11 @@ def main(argv=None):
     rccl_ranks = 1
     if dist:
         import torch.distributed as td
-        sharding.init("nccl" if use_gpu else "gloo", device if use_gpu else None)
+        # (RCCL needs one device per rank: oversubscribed ranks talk over gloo, with host tensors)
+        sharding.init("nccl" if (use_gpu and not over) else "gloo", device if (use_gpu and not over) else None)
         rccl_ranks = td.get_world_size()
-        assert rccl_ranks == a.gpus
+        assert rccl_ranks == a.gpus * a.oversubscribe
+    red_dev = device if (use_gpu and not over) else torch.device("cpu")   # where the timing all-reduce lives
 
     def barrier():
         if dist:
@@ -360,11 +402,12 @@ def main(argv=None):
         t0 = time.perf_counter()
         time.sleep(0.01 * (1 + rank))
         barrier()
-        el = sharding.max_over_ranks(time.perf_counter() - t0, device)
-        owned = sharding.sum_over_ranks(hi - lo, device)
+        el = sharding.max_over_ranks(time.perf_counter() - t0, red_dev)
+        owned = sharding.sum_over_ranks(hi - lo, red_dev)
         if rank == 0:
             print(json.dumps({"metric": "fwd+adjoint env-steps/sec", "dry_run": True, "value": None, "unit": "env-steps/s",
-                              "n_gpus": world, "rccl_ranks": rccl_ranks, "backend": "nccl" if use_gpu else "gloo",
+                              "n_gpus": a.gpus, "rccl_ranks": rccl_ranks, "backend": "nccl" if (use_gpu and not over) else "gloo",
+                              "oversubscribed": over,
                               "steps": a.steps, "warmup": a.warmup, "scaling": "weak", "envs_total": int(owned),
                               "slowest_rank_s": el,
                               "config": {"workload": "%s %d envs/GPU x H=%d" % (a.env, n, H), "envs_per_gpu": n}}))
@@ -418,15 +461,23 @@ def main(argv=None):
         one()
     gc.collect()
     gc.disable()   # no cyclic-GC pause inside the timed region (a gen-2 collection costs tens of ms once every few rollouts)
+    # one HIP event per timed step on the launch stream (the replays and the eager launches go to torch's current stream):
+    # min / median / max per step next to the wall-clock figure, so that a sub-percent change can be told from noise
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)] if use_gpu else []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
+        if marks:
+            marks[i].record()
         grad = one()
+    if marks:
+        marks[a.steps].record()
     barrier()
     el = time.perf_counter() - t0
     gc.enable()
+    per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)) if marks else []
     assert torch.isfinite(grad).all()
-    el = sharding.max_over_ranks(el, device)
+    el = sharding.max_over_ranks(el, red_dev)
     total_env_steps = a.steps * world * n * H
     value = total_env_steps / el
     eager_value = None
@@ -447,9 +498,13 @@ def main(argv=None):
         rf = roofline_record(env, a.env, n, H, mm, device, 50)
         eng = env.model.engine()
         out = {
-            "metric": "fwd+adjoint env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
-            "rccl_ranks": rccl_ranks,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
+            "metric": "fwd+adjoint env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": a.gpus,
+            "rccl_ranks": rccl_ranks, "oversubscribed": over,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
+            "ms_per_step_min": per_step_ms[0] if per_step_ms else None,
+            "ms_per_step_median": per_step_ms[len(per_step_ms) // 2] if per_step_ms else None,
+            "ms_per_step_max": per_step_ms[-1] if per_step_ms else None,
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %d envs/GPU x H=%d through DFlexEnv.step, loss=-sum(rew), 1 backward"
                                    % (a.env, n, H), "envs_per_gpu": n, "envs_total": n * world, "horizon": H,
@@ -473,6 +528,10 @@ def main(argv=None):
                     q, qd, _, _, _ = eng.env_forward(spec, q, qd, actions[t % H], env.sim_dt, env.sim_substeps, mm, False)
                 torch.cuda.synchronize()
                 out["no_grad_forward_env_steps_per_s"] = 100 * n / (time.perf_counter() - t0)
+        if over:
+            out["backend"] = "gloo"
+            out["note"] = ("%d ranks share each GPU (--oversubscribe): the multi-rank launcher / sharding / timing path executed against "
+                           "real kernels, NOT a multi-GPU figure -- the ranks' launches time-slice one device" % a.oversubscribe)
         if not a.no_other_configs and world == 1 and a.env == "ant" and not a.eager:
             # BASELINE.json configs[2], configs[3] and the MM_caching_frequency = 1 variant of configs[1] (SURVEY.md 8(d):
             # "also report 1"), each a few seconds: driver-visible numbers next to the headline

@@ -111,7 +111,7 @@ class DsimError(RuntimeError):
 
 
 _lib = None
-EXPECTED_ABI = 104   # dsim_version() of the library this binding was written against (argument lists of include/dsim.h)
+EXPECTED_ABI = 105   # dsim_version() of the library this binding was written against (argument lists of include/dsim.h)
 
 
 def lib():
@@ -151,8 +151,11 @@ def lib():
     L.dsim_env_step_backward.argtypes = [vp, ep, C.c_int, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp,
                                          vp, vp, vp, vp]
     L.dsim_env_observe.argtypes = [vp, ep, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.dsim_model_status.argtypes = [vp, C.POINTER(C.c_int)]
+    L.dsim_body_transforms.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     for fn in (L.dsim_model_create, L.dsim_model_destroy, L.dsim_step_forward, L.dsim_step_backward,
-               L.dsim_env_step_forward, L.dsim_env_step_backward, L.dsim_env_observe):
+               L.dsim_env_step_forward, L.dsim_env_step_backward, L.dsim_env_observe, L.dsim_model_status,
+               L.dsim_body_transforms):
         fn.restype = C.c_int
     _lib = L
     return L
@@ -166,4 +169,4 @@ def check(rc):
 EXPORTS = ("dsim_last_error", "dsim_version", "dsim_model_create", "dsim_model_destroy", "dsim_model_variant", "dsim_model_device",
            "dsim_ckpt_floats", "dsim_ckpt_floats_mm", "dsim_model_set_ckpt_mode",
            "dsim_step_forward", "dsim_step_backward", "dsim_env_step_forward", "dsim_env_step_backward",
-           "dsim_env_observe")
+           "dsim_env_observe", "dsim_model_status", "dsim_body_transforms")

@@ -1726,6 +1726,32 @@ template <class Ctx> DSIM_FN float* dsim_ckpt_tail(const Ctx& c, float* g_ckpt, 
     return g_ckpt + (size_t)substeps * dsim_row(c) + (size_t)groups * dsim_hinv_words_d(c.d.nd);
 }
 
+// Precondition of the whole path (include/dsim.h, dsim_step_forward): every quaternion block of the state handed in is a UNIT
+// quaternion.  The kinematics, the 10-parameter inertia and the wrench form of the adjoint are rotations only there (the
+// reference evaluates its formulas literally off the manifold, quat.h:113-116, and gives something else: measured 5e-3 in qd
+// at |q| = 1.001).  Checked once per launch on the state as loaded: | |q|^2 - 1 | > 2e-4 (1e-4 in the norm) stores
+// (1, environment) into the model's status words, which live in host memory mapped into the device; the NEXT call on the
+// model returns DSIM_ERR_INVALID.  The integrator renormalises every substep (sim.py:1552, 1616), so states produced by the
+// path itself always pass.  One phase of a few instructions per launch; models without quaternion joints compile nothing.
+#define DSIM_UNIT_QUAT_TOL 2e-4f
+template <class Ctx, class Exec> DSIM_FN void dsim_check_unit_quats(const Ctx& c, Exec& ex, int* g_status, int env) {
+    constexpr int MASK = dsim_tmask_static<Ctx>();
+    if constexpr ((MASK & (DSIM_TM(DSIM_JOINT_BALL) | DSIM_TM(DSIM_JOINT_FREE))) != 0) {
+        if (!g_status) return;
+        ex.fire([&](int lane) {
+            for (int i = lane; i < c.d.L; i += Exec::NL) {
+                const int type = CI(jtype)[i], cs = CI(qstart)[i];
+                if (type != DSIM_JOINT_BALL && type != DSIM_JOINT_FREE) continue;
+                const q4 r = ldq(WF(q) + cs + (type == DSIM_JOINT_FREE ? 3 : 0));
+                if (!(fabsf(qdot(r, r) - 1.0f) <= DSIM_UNIT_QUAT_TOL)) {   // (also catches NaN)
+                    g_status[1] = env;
+                    g_status[0] = 1;
+                }
+            }
+        });
+    }
+}
+
 // one substep on the LDS-resident state; g_row / g_hinv: where to stream the saved block / the fresh inverse (or null)
 template <class Ctx, class Exec>
 DSIM_FN void dsim_fwd_substep(const Ctx& c, Exec& ex, bool update_mass, float* g_row = nullptr, float* g_hinv = nullptr) {
@@ -1759,7 +1785,7 @@ DSIM_FN void dsim_fwd_substep(const Ctx& c, Exec& ex, bool update_mass, float* g
 template <class Ctx, class Exec>
 DSIM_FN void dsim_sim_step_forward(const Ctx& c, Exec& ex, int substeps, int mm_freq, const float* g_q,
                                    const float* g_qd, const float* g_act, const float* g_mact, float* g_q_out,
-                                   float* g_qd_out, float* g_ckpt) {
+                                   float* g_qd_out, float* g_ckpt, int* g_status = nullptr, int env = 0) {
     const int nq = c.d.nq, nd = c.d.nd, M = c.d.M;
     ex.begin_request();
     ex.begin();
@@ -1773,12 +1799,42 @@ DSIM_FN void dsim_sim_step_forward(const Ctx& c, Exec& ex, int substeps, int mm_
         }
         for (int k = lane; k < M; k += Exec::NL) WF(mact)[k] = g_mact[k];
     });
+    dsim_check_unit_quats(c, ex, g_status, env);
     for (int s = 0; s < substeps; ++s)
         dsim_fwd_substep(c, ex, (s % mm_freq) == 0, g_ckpt ? g_ckpt + (size_t)s * dsim_row(c) : nullptr,
                          g_ckpt ? dsim_ckpt_hinv(c, g_ckpt, substeps, s / mm_freq) : nullptr);
     ex.run([&](int lane) {
         for (int k = lane; k < nq; k += Exec::NL) g_q_out[k] = WF(q)[k];
         for (int k = lane; k < nd; k += Exec::NL) g_qd_out[k] = WF(qd)[k];
+    });
+}
+
+// Derived body transforms of a given joint state (dsim_body_transforms, include/dsim.h): what the reference's State carries as
+// body_X_sc / body_X_sm (model.py:338-392, filled by eval_rigid_fk, sim.py:1638-1678).  The kinematics phase of the step
+// kernels, run once on q with qd = 0, then X_sc [L][7] and X_sm = X_sc o X_cm (joint_X_cm has an identity rotation,
+// model.py:1745-1747: p_sm = p_sc + R_sc com, r_sm = r_sc) go to global memory.
+template <class Ctx, class Exec>
+DSIM_FN void dsim_body_transforms_only(const Ctx& c, Exec& ex, const float* g_q, float* g_xsc, float* g_xsm) {
+    ex.begin_request();
+    ex.begin();
+    dsim_init_static(c, ex);
+    ex.run_both([&](int lane) { dsim_topo_init(c, ex, lane); });
+    ex.run([&](int lane) {
+        for (int k = lane; k < c.d.nq; k += Exec::NL) WF(q)[k] = g_q[k];
+        for (int k = lane; k < c.d.nd; k += Exec::NL) WF(qd)[k] = 0.f;
+    });
+    dsim_fwd_kinematics(c, ex);
+    ex.run([&](int lane) {
+        for (int it = lane; it < 7 * c.d.L; it += Exec::NL) g_xsc[it] = WF(xsc)[it];
+        if (g_xsm) {
+            for (int i = lane; i < c.d.L; i += Exec::NL) {
+                const v3 p = ld3(WF(xsc) + 7 * i);
+                const q4 r = ldq(WF(xsc) + 7 * i + 3);
+                const v3 pm = rotate(r, ld3(CF(com) + 3 * i)) + p;
+                float* o = g_xsm + 7 * i;
+                o[0] = pm.x; o[1] = pm.y; o[2] = pm.z; o[3] = r.x; o[4] = r.y; o[5] = r.z; o[6] = r.w;
+            }
+        }
     });
 }
 
@@ -2953,7 +3009,7 @@ template <class Ctx, class Exec>
 DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& sp, int substeps, int mm_freq,
                                     const float* g_q, const float* g_qd, const float* g_actions, float* g_q_out,
                                     float* g_qd_out, float* g_obs, float* g_rew, float* g_ckpt, const DsimEpisode& ep,
-                                    int e, int n_envs) {
+                                    int e, int n_envs, int* g_status = nullptr) {
     const int nq = c.d.nq, nd = c.d.nd;
     using IO = DsimIo<Ctx, Exec>;
     ex.begin_request();   // model constants first: memory returns loads in the order of their requests
@@ -2979,6 +3035,7 @@ DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& s
         if (lane == 0) WF(epf)[0] = 0.f;
     });
     dsim_env_load_actions(c, ex, sp, g_actions, true);
+    dsim_check_unit_quats(c, ex, g_status, e);
     for (int s = 0; s < substeps; ++s)
         dsim_fwd_substep(c, ex, (s % mm_freq) == 0, g_ckpt ? g_ckpt + (size_t)s * dsim_row(c) : nullptr,
                          g_ckpt ? dsim_ckpt_hinv(c, g_ckpt, substeps, s / mm_freq) : nullptr);

@@ -318,6 +318,7 @@ template <class O, class D> struct KCommonT {
     float h;
     int substeps, mm_freq, n_envs;
     long long ckpt_stride;  // floats per environment (dsim_ckpt_words)
+    int* status;            // the model's two status words (host memory mapped into the device): dsim_check_unit_quats
 };
 
 // prefetch registers a model's checkpoint row needs (compile-time layouts), or the generic default of 6 (rows up to 1536 floats
@@ -380,7 +381,7 @@ __global__ __launch_bounds__((DSIM_NL * NW * (HELP ? 2 : 1))) void dsim_fwd_kern
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_sim_step_forward(c, ex, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, act + e * nd,
                           M ? mact + e * M : nullptr, q_out + e * nq, qd_out + e * nd,
-                          ckpt ? ckpt + (size_t)e * k.ckpt_stride : nullptr);
+                          ckpt ? ckpt + (size_t)e * k.ckpt_stride : nullptr, k.status, e);
 }
 
 template <class O, class D, int NW, bool LEAN, bool HELP>
@@ -415,7 +416,7 @@ __global__ __launch_bounds__((DSIM_NL * NW * (HELP ? 2 : 1))) void dsim_env_fwd_
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_forward(c, ex, sp, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, actions + (size_t)e * sp.n_act,
                            q_out + e * nq, qd_out + e * nd, obs + (size_t)e * sp.n_obs, rew + e,
-                           ckpt ? ckpt + (size_t)e * k.ckpt_stride : nullptr, ep, e, k.n_envs);
+                           ckpt ? ckpt + (size_t)e * k.ckpt_stride : nullptr, ep, e, k.n_envs, k.status);
 }
 
 template <class O, class D, int NW, bool LEAN, bool HELP>
@@ -458,6 +459,17 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_obs_kernel(KCommonT<O, 
     DevExec<NW> ex;
     dsim_env_observe_only(c, ex, sp, q + (size_t)e * k.d.nq, qd + (size_t)e * k.d.nd, stored + (size_t)e * sp.n_act,
                           obs + (size_t)e * sp.n_obs, rew + e);
+}
+
+template <class O, class D, int NW>
+__global__ __launch_bounds__(DSIM_NL * NW) void dsim_body_xf_kernel(KCommonT<O, D> k, const float* __restrict__ q, float* xsc,
+                                                                  float* xsm) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int e = blockIdx.x;
+    if (e >= k.n_envs) return;
+    DevExec<NW, 6, dsim_const_words<O>(), false> ex;
+    auto c = start_env<false>(lds, k, k.o.fwd_words, ex);
+    dsim_body_transforms_only(c, ex, q + (size_t)e * k.d.nq, xsc + (size_t)e * 7 * k.d.L, xsm ? xsm + (size_t)e * 7 * k.d.L : nullptr);
 }
 
 #ifdef DSIM_ENABLE_PHASE_TIMER
@@ -586,6 +598,11 @@ struct dsim_model {
     int waves = 1;   // wavefronts per environment: 1 or DSIM_WAVES_WIDE
     int lean = 0;    // checkpoint mode (dsim_model_set_ckpt_mode)
     int device = 0;  // HIP device the constants live on (the current device of dsim_model_create); every call checks it
+    // Status words written by the kernels (dsim_core.hpp: dsim_check_unit_quats): [0] != 0 -- a launch was handed a non-unit
+    // quaternion, [1] -- the environment that saw it.  Pinned host memory mapped into the device: a kernel's store lands here
+    // without any copy, and the next call on the model reads it without touching the stream (no synchronisation anywhere).
+    volatile int* h_status = nullptr;
+    int* d_status = nullptr;
     int row_words() const { return lean ? lay.o.xsc - lay.o.q : lay.o.save_words; }
     // Helper-wave kernels (DevExec<..., HELPER>) are used while every environment of the launch is resident at once: the
     // helper takes a wave slot of its SIMD, so beyond that point (several rounds of workgroups) it would halve the
@@ -647,6 +664,7 @@ KCommonT<O, D> make_k(const dsim_model* m, O o, D d, int n_envs, float dt, int s
     k.mm_freq = mm_freq;
     k.n_envs = n_envs;
     k.ckpt_stride = dsim_ckpt_words(m->row_words(), m->lay.d.nq, m->lay.d.nd, substeps, mm_freq);
+    k.status = m->d_status;
     return k;
 }
 
@@ -663,9 +681,25 @@ int check_device(const dsim_model* m) {
     return DSIM_OK;
 }
 
+// A launch that was handed a non-unit quaternion leaves a mark in the model's status words; the next call that would launch
+// on the model reports it (once: the mark is cleared) instead of launching.  Asynchronous, like a HIP error of a kernel:
+// the state the marked launch returned is what the formulas give off the manifold, not what the reference gives there.
+int check_status(const dsim_model* m) {
+    if (m->h_status && m->h_status[0] != 0) {
+        const int env = m->h_status[1];
+        m->h_status[0] = 0;
+        return fail(DSIM_ERR_INVALID, "an earlier launch on this model was given a joint_q whose quaternion block is not a unit "
+                                      "quaternion (| |q| - 1 | > 1e-4; first seen in environment " + std::to_string(env) +
+                                          "): the path is defined on unit quaternions only (include/dsim.h, dsim_step_forward); "
+                                          "normalise the state before handing it in");
+    }
+    return DSIM_OK;
+}
+
 int check_common(const dsim_model* m, int n_envs, float dt, int substeps, int mm_freq) {
     if (!m) return fail(DSIM_ERR_INVALID, "null model");
     if (int rc = check_device(m)) return rc;
+    if (int rc = check_status(m)) return rc;
     if (n_envs <= 0) return fail(DSIM_ERR_INVALID, "n_envs must be positive");
     if (substeps <= 0 || mm_freq <= 0) return fail(DSIM_ERR_INVALID, "substeps and mm_freq must be positive");
     if (!(dt > 0.f)) return fail(DSIM_ERR_INVALID, "dt must be positive");
@@ -717,7 +751,7 @@ int make_spec(const dsim_model* m, const dsim_env_spec* e, DsimEnvSpec& sp) {
 extern "C" {
 
 const char* dsim_last_error(void) { return g_err.c_str(); }
-int dsim_version(void) { return 104; }
+int dsim_version(void) { return 105; }
 
 int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
     if (!desc || !out) return fail(DSIM_ERR_INVALID, "null argument");
@@ -736,6 +770,17 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
     m->variant = match_variant(m->lay);
     m->waves = pick_waves(m->lay, m->variant);
     hipError_t e = hipGetDevice(&m->device);
+    if (e == hipSuccess) {
+        void* hp = nullptr;
+        e = hipHostMalloc(&hp, 2 * sizeof(int), hipHostMallocMapped);
+        if (e == hipSuccess) {
+            m->h_status = static_cast<volatile int*>(hp);
+            m->h_status[0] = m->h_status[1] = 0;
+            void* dp = nullptr;
+            e = hipHostGetDevicePointer(&dp, hp, 0);
+            m->d_status = static_cast<int*>(dp);
+        }
+    }
     if (e == hipSuccess) e = hipMalloc(&m->d_cblob, sizeof(uint32_t) * m->lay.cblob.size());
     if (e == hipSuccess)
         e = hipMemcpy(m->d_cblob, m->lay.cblob.data(), sizeof(uint32_t) * m->lay.cblob.size(), hipMemcpyHostToDevice);
@@ -765,11 +810,15 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsim_env_obs_kernel<O, D, NW>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsim_body_xf_kernel<O, D, NW>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             return 0;
         });
     }
     if (e != hipSuccess) {
         if (m->d_cblob) (void)hipFree(m->d_cblob);
+        if (m->h_status) (void)hipHostFree(const_cast<int*>(m->h_status));
         delete m;
         return hip_fail(e, "dsim_model_create");
     }
@@ -817,7 +866,18 @@ extern "C" {
 int dsim_model_destroy(dsim_model* m) {
     if (!m) return DSIM_OK;
     if (m->d_cblob) (void)hipFree(m->d_cblob);
+    if (m->h_status) (void)hipHostFree(const_cast<int*>(m->h_status));
     delete m;
+    return DSIM_OK;
+}
+
+int dsim_model_status(dsim_model* m, int* first_env) {
+    if (!m) return fail(DSIM_ERR_INVALID, "null model");
+    if (first_env) *first_env = -1;
+    if (m->h_status && m->h_status[0] != 0) {
+        if (first_env) *first_env = m->h_status[1];
+        return check_status(m);
+    }
     return DSIM_OK;
 }
 
@@ -967,6 +1027,21 @@ int dsim_env_observe(const dsim_model* m, const dsim_env_spec* env, int n_envs, 
         hipLaunchKernelGGL((dsim_env_obs_kernel<decltype(o), decltype(d), NW>), dim3(n_envs), dim3(DSIM_NL * NW),
                            (size_t)m->lay.o.fwd_words * 4, st, k, sp, q, qd, stored_actions, obs, rew);
         return launched("launch dsim_env_obs_kernel");
+    });
+}
+
+int dsim_body_transforms(const dsim_model* m, int n_envs, const float* q, float* X_sc, float* X_sm, void* hip_stream) {
+    int rc = check_common(m, n_envs, 1.0f, 1, 1);
+    if (rc) return rc;
+    if (!q || !X_sc) return fail(DSIM_ERR_INVALID, "null pointer");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    return dispatch(m, [&](auto o, auto d, auto nw) {
+        constexpr int NW = decltype(nw)::value;
+        auto k = make_k(m, o, d, n_envs, 1.0f, 1, 1);
+        k.status = nullptr;   // a read-back of whatever state the caller holds: no precondition to enforce here
+        hipLaunchKernelGGL((dsim_body_xf_kernel<decltype(o), decltype(d), NW>), dim3(n_envs), dim3(DSIM_NL * NW),
+                           (size_t)m->lay.o.fwd_words * 4, st, k, q, X_sc, X_sm);
+        return launched("launch dsim_body_xf_kernel");
     });
 }
 

@@ -289,11 +289,39 @@ class State:
     DFlexEnv boundary exist; the derived per-substep tensors of the reference live in LDS.
     `joint_act` is allocated (zeros) on first access: the fused env path never touches it."""
 
-    def __init__(self, act_like=None):
+    def __init__(self, act_like=None, model=None):
         self.joint_q = None
         self.joint_qd = None
         self._joint_act = None
         self._act_like = act_like
+        self._xf_model = model   # whoever produces the state passes the Model (Model.state, the integrator, DFlexEnv.step)
+        self._xf_ckpt = None     # (checkpoint, substeps) of the step that produced this state, when gradients were on
+        self._xf = None
+
+    # Derived tensors of the reference's State (model.py:338-392) that leave LDS only on request: body_X_sc / body_X_sm
+    # ([n_envs * n_links, 7], no grad_fn -- the reference's are plain outputs of eval_rigid_fk too).  One small launch on first
+    # access (dsim_body_transforms), cached per state object.  After forward() the reference's tensors belong to the joint
+    # coordinates that ENTERED the last substep (eval_rigid_fk runs before the integrator, sim.py:2316-2601); the integrator
+    # remembers the step's checkpoint (`_xf_ckpt`) when gradients are on, whose last row starts with exactly those coordinates,
+    # so the values match; in no-grad mode there is no checkpoint and the transforms are those of this state's own joint_q
+    # (one substep ahead of the reference's: h later).  A state that did not come out of a step (Model.state(), reset) has no
+    # such lag in the reference either... it has zeros there; here: the transforms of its joint_q.
+    def _body_xf(self):
+        if self._xf is None:
+            if self._xf_model is None:
+                raise RuntimeError("this State was not produced by a Model / integrator: no engine to derive body transforms with")
+            eng = self._xf_model.engine()
+            q = eng.last_substep_q(*self._xf_ckpt) if self._xf_ckpt is not None else self.joint_q
+            self._xf = eng.body_transforms(q)
+        return self._xf
+
+    @property
+    def body_X_sc(self):
+        return self._body_xf()[0]
+
+    @property
+    def body_X_sm(self):
+        return self._body_xf()[1]
 
     @property
     def joint_act(self):
@@ -393,7 +421,7 @@ class Model:
         self._engine = None
 
     def state(self):
-        s = State(act_like=self.joint_qd)
+        s = State(act_like=self.joint_qd, model=self)
         s.joint_q = self.joint_q.clone()
         s.joint_qd = self.joint_qd.clone()
         return s

@@ -18,7 +18,7 @@ class SemiImplicitIntegrator:
     def forward(self, model: Model, state_in: State, dt: float, substeps: int, mass_matrix_freq: int) -> State:
         eng = model.engine()
         mact = model.muscle_activation if model.muscle_count else None
-        out = State(act_like=model.joint_qd)
+        out = State(act_like=model.joint_qd, model=model)
         if config.no_grad:
             with torch.no_grad():
                 q, qd, _ = eng.forward(state_in.joint_q.contiguous(), state_in.joint_qd.contiguous(),
@@ -28,6 +28,7 @@ class SemiImplicitIntegrator:
         else:
             out.joint_q, out.joint_qd = SimStep.apply(eng, float(dt), int(substeps), int(mass_matrix_freq),
                                                       state_in.joint_q, state_in.joint_qd, state_in.joint_act, mact)
+        out._xf_ckpt = eng.last_ckpt   # None in no-grad mode (State.body_X_sc then derives from out.joint_q)
         if config.verify_fp and not (torch.isfinite(out.joint_q).all() and torch.isfinite(out.joint_qd).all()):
             raise FloatingPointError("non-finite state after SemiImplicitIntegrator.forward")
         return out

@@ -42,6 +42,7 @@ class Engine:
         assert int(self._lib.dsim_model_device(h)) == self.device.index
         self.variant = int(self._lib.dsim_model_variant(h))  # 0 = generic kernels, > 0 = specialised for this model
         self.n_q, self.n_qd, self.n_muscles = template.n_q, template.n_qd, template.n_muscles
+        self.last_ckpt = None
 
     def __del__(self):
         try:
@@ -50,6 +51,32 @@ class Engine:
                 self._h = None
         except Exception:
             pass
+
+    def status(self):
+        """Raises DsimError if a forward launch since the last report was handed a non-unit quaternion (include/dsim.h:
+        the path is defined on unit quaternions only).  Host-side read of two mapped words; synchronise first for a
+        definitive answer about launches still in flight."""
+        capi.check(self._lib.dsim_model_status(self._h, None))
+
+    def body_transforms(self, q):
+        """(X_sc, X_sm), each [n_envs * n_links, 7]: link frames and centre-of-mass frames in the world for the joint
+        coordinates q -- the reference's State.body_X_sc / body_X_sm (dflex/dflex/model.py:338-392)."""
+        q = q.detach().contiguous()
+        self._check(q, self.n_q, "joint_q")
+        n = q.numel() // self.n_q
+        L = self.template.n_links
+        xsc = torch.empty((n * L, 7), dtype=torch.float32, device=self.device)
+        xsm = torch.empty((n * L, 7), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            capi.check(self._lib.dsim_body_transforms(self._h, n, _ptr(q), _ptr(xsc), _ptr(xsm), st))
+        return xsc, xsm
+
+    def last_substep_q(self, ckpt, substeps):
+        """joint_q ENTERING the last substep of the step that wrote `ckpt` (the head of that substep's checkpoint row): what the
+        reference's eval_rigid_fk saw when it filled the returned State's body_X_sc (sim.py:2316-2601)."""
+        row = int(self._lib.dsim_ckpt_floats_mm(self._h, 2, 1 << 30)) - int(self._lib.dsim_ckpt_floats_mm(self._h, 1, 1 << 30))
+        return ckpt[:, (substeps - 1) * row:(substeps - 1) * row + self.n_q].contiguous()
 
     def _alloc_ckpt(self, n, substeps, mm_freq):
         """[n][dsim_ckpt_floats_mm]: per substep the saved forward block (starts with q, qd), then the H^-1 per group"""
@@ -78,6 +105,7 @@ class Engine:
         ckpt = None
         if need_ckpt:
             ckpt = self._alloc_ckpt(n, substeps, mm_freq)
+        self.last_ckpt = (ckpt, substeps) if ckpt is not None else None   # (State.body_X_sc reads its last row's q on request)
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             capi.check(self._lib.dsim_step_forward(self._h, n, _ptr(q), _ptr(qd), _ptr(act),
@@ -125,6 +153,7 @@ class Engine:
         obs = torch.empty((n, spec.n_obs), dtype=torch.float32, device=self.device)
         rew = torch.empty(n, dtype=torch.float32, device=self.device)
         ckpt = self._alloc_ckpt(n, substeps, mm_freq) if need_ckpt else None
+        self.last_ckpt = (ckpt, substeps) if ckpt is not None else None
         ep, extra = None, ()
         if episode is not None:
             ep, extra = episode.bind(self, n, spec.n_obs)

@@ -234,8 +234,9 @@ class DFlexEnv:
             q, qd, obs, rew, obs_before, done = EnvStep.apply(eng, spec, epi, float(self.sim_dt), self.sim_substeps,
                                                               self.MM_caching_frequency, self.state.joint_q,
                                                               self.state.joint_qd, actions)
-        st = df.State(act_like=self.model.joint_qd)
+        st = df.State(act_like=self.model.joint_qd, model=self.model)
         st.joint_q, st.joint_qd = q, qd
+        # (derived body transforms on request: of the returned joint_q -- a restarted environment has none in the checkpoint)
         self.state = st
         # self.actions (clipped / remapped, zero for restarted environments) is materialised on first use
         self._lazy_actions = (obs, spec.obs_actions, actions.detach(), done)
@@ -359,7 +360,7 @@ class DFlexEnv:
         """Cuts the graph between the current state and everything before it."""
         with torch.no_grad():
             act = self.state.joint_act.clone() if self.keep_act_on_clear else None
-            st = df.State(act_like=self.model.joint_qd)
+            st = df.State(act_like=self.model.joint_qd, model=self.model)
             if checkpoint is None:
                 # same result as restoring get_checkpoint(), without copying everything twice
                 st.joint_q, st.joint_qd = self.state.joint_q.detach().clone(), self.state.joint_qd.detach().clone()
@@ -390,6 +391,23 @@ class DFlexEnv:
         self.clear_grad()
         return self._refresh_obs()
 
+    def _require_unit_quaternions(self, q):
+        """The simulation path is defined on unit quaternions only (include/dsim.h, dsim_step_forward: 5e-3 error in qd at
+        |q| = 1.001 against the reference's literal off-manifold formulas).  A state handed in from outside is checked here,
+        where a host synchronisation is harmless; the step kernels check again asynchronously."""
+        t = self.model.template()
+        blocks = [int(cs) + (3 if int(ty) == df.JOINT_FREE else 0) for ty, cs in zip(t.joint_type, t.joint_q_start)
+                  if int(ty) in (df.JOINT_FREE, df.JOINT_BALL)]
+        if not blocks or q.numel() == 0:
+            return
+        with torch.no_grad():
+            norms = torch.stack([q[:, b:b + 4].norm(dim=1) for b in blocks], dim=1)
+            worst = float((norms - 1.0).abs().max())    # (nan compares false below and is reported too)
+        if not worst <= 1e-4:
+            raise ValueError("%s.reset_with_state: a quaternion block of joint_q is off the unit sphere by %.3g (> 1e-4); the "
+                             "MI355X path is defined on unit quaternions only -- normalise the state first"
+                             % (type(self).__name__, worst))
+
     def get_checkpoint(self):
         return {"joint_q": self.state.joint_q.clone(), "joint_qd": self.state.joint_qd.clone(),
                 "actions": self.actions.clone(), "progress_buf": self.progress_buf.clone()}
@@ -401,6 +419,7 @@ class DFlexEnv:
         if env_ids is None and force_reset:
             env_ids = torch.arange(self.num_envs, dtype=torch.long, device=self.device)
         if env_ids is not None:
+            self._require_unit_quaternions(init_joint_q.view(-1, self.num_joint_q)[env_ids, :])
             self.state.joint_q = self.state.joint_q.clone()
             self.state.joint_qd = self.state.joint_qd.clone()
             self._q()[env_ids, :] = init_joint_q.view(-1, self.num_joint_q)[env_ids, :].clone()

@@ -77,7 +77,7 @@ class GraphedRollout:
     def _run_once(self, write_back):
         env = self.env
         # start from the static copies (fresh tensors: the body builds a new autograd graph on them)
-        st = type(env.state)(act_like=env.model.joint_qd)
+        st = type(env.state)(act_like=env.model.joint_qd, model=env.model)
         st.joint_q, st.joint_qd = self._q.clone(), self._qd.clone()
         env.state = st
         env.actions = self._act.clone()
@@ -108,7 +108,7 @@ class GraphedRollout:
         """after replays with carry_state: point the environment object at the carried state (for eager use afterwards)"""
         env = self.env
         with torch.no_grad():
-            st = type(env.state)(act_like=env.model.joint_qd)
+            st = type(env.state)(act_like=env.model.joint_qd, model=env.model)
             st.joint_q, st.joint_qd = self._q.clone(), self._qd.clone()
             env.state = st
             env.actions = self._act.clone()

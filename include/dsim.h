@@ -126,11 +126,30 @@ int64_t dsim_ckpt_floats(const dsim_model* m, int substeps);
  * substeps i with i % mm_freq == 0 (sim.py:2113).
  *   ckpt: [N][dsim_ckpt_floats_mm(m, substeps, mm_freq)] or NULL (no-grad fast path == dflex.config.no_grad,
  *   sim.py:2201); every row starts with the (q, qd) entering its substep
- *   muscle_act may be NULL when n_muscles == 0.  q_out/qd_out may alias q_in/qd_in. */
+ *   muscle_act may be NULL when n_muscles == 0.  q_out/qd_out may alias q_in/qd_in.
+ *
+ * PRECONDITION -- THE PATH IS DEFINED ON UNIT QUATERNIONS ONLY, FORWARD AND ADJOINT.  Every quaternion block of q_in (free
+ * joint: q[cs+3 .. cs+6], ball joint: q[cs .. cs+3]) must be a unit quaternion to 1e-4.  The reference evaluates its rotation
+ * formulas literally off the manifold (quat.h:113-116 rotate, spatial.h:559-586 / sim.py:1117-1134 T^T I_m T with a
+ * non-orthogonal R); this library uses forms that agree with them ON the manifold only (10-parameter rigid-body inertia, pose
+ * cotangents as wrenches).  Measured on the Ant step recording with the root quaternion scaled (host harness vs the
+ * reference-order oracle): |q| = 1.001 -> 5.3e-3 relative error in qd_out, 1.01 -> 4.7e-2, 1.1 -> 0.64, against the 1e-4
+ * state tolerance on the manifold.  States produced by the path itself always qualify: the integrator renormalises every
+ * quaternion in every substep (sim.py:1552, 1616), so only states a caller constructs (reset_with_state, hand-made inputs)
+ * can violate this.
+ * ENFORCEMENT: the forward kernels check the state as loaded, once per launch; | |q|^2 - 1 | > 2e-4 in any block of any
+ * environment marks the model, and the NEXT dsim_* call that takes the model returns DSIM_ERR_INVALID (once; the mark is
+ * cleared) instead of launching -- asynchronous, like the error of a HIP kernel, no synchronisation on the step path.
+ * dsim_model_status() asks explicitly (synchronise the stream first for a definitive answer about launches in flight). */
 int dsim_step_forward(const dsim_model* m, int n_envs,
                       const float* q_in, const float* qd_in, const float* act, const float* muscle_act,
                       float dt, int substeps, int mm_freq,
                       float* q_out, float* qd_out, float* ckpt, void* hip_stream);
+
+/* DSIM_OK, or DSIM_ERR_INVALID if a forward launch since the last report was handed a non-unit quaternion (see the
+ * precondition above); *first_env (may be NULL) receives an environment index that saw one, -1 otherwise.  Reads two words
+ * of host memory the kernels write to; never touches a stream.  Reporting clears the mark. */
+int dsim_model_status(dsim_model* m, int* first_env);
 
 /* Reverse sweep of the same step.  Needs the checkpoint of the forward call and the same act /
  * muscle_act.  Outputs: gq_in[N][n_q], gqd_in[N][n_qd], gact[N][n_qd], gmuscle_act[N][M]
@@ -139,6 +158,7 @@ int dsim_step_forward(const dsim_model* m, int n_envs,
  * the substeps that reuse a factor (matnn.h:310-336), min/max/clamp/step/normalize rules of
  * adjoint.h:129-190 and vec3.h:204-222.
  *
+ * Defined on unit quaternions only, like the forward call whose checkpoint it consumes (precondition at dsim_step_forward).
  * ONE STATED DEVIATION from what the reference's SimulateFunc.backward (sim.py:2127-2154) returns: for every quaternion
  * block of joint_q (free joint: q[cs+3 .. cs+6], ball joint: q[cs .. cs+3]) gq_in has NO component along the quaternion
  * itself.  The reference differentiates its rotation formulas literally (quat.h:232-288 adj_mul / adj_rotate,
@@ -157,6 +177,14 @@ int dsim_step_backward(const dsim_model* m, int n_envs,
                        float dt, int substeps, int mm_freq,
                        const float* gq_out, const float* gqd_out,
                        float* gq_in, float* gqd_in, float* gact, float* gmuscle_act, void* hip_stream);
+
+/* Derived body transforms of a joint state: X_sc[N][L][7] (link frames in the world, what eval_rigid_fk writes to
+ * State.body_X_sc, sim.py:1638-1678) and, if X_sm is not NULL, X_sm[N][L][7] = X_sc o X_cm (State.body_X_sm: the bodies'
+ * centre-of-mass frames).  The reference's State carries them after every forward() (model.py:338-392; read by
+ * envs/snu_humanoid.py:209,227 for rendering) -- computed from the joint coordinates ENTERING the last substep; the
+ * step functions above keep them in LDS / the checkpoint only, so this is the read-back: pass the q of interest (for the
+ * reference's literal value: the head of the last substep's checkpoint row, which is that substep's input q). */
+int dsim_body_transforms(const dsim_model* m, int n_envs, const float* q, float* X_sc, float* X_sm, void* hip_stream);
 
 /* ---- fused environment surface -------------------------------------
  * The per-step torch glue of the reference environments -- action clip + scale into joint_act /
@@ -218,7 +246,8 @@ typedef struct dsim_episode {
 } dsim_episode;
 
 /* actions[N][n_act] -> q_out, qd_out, obs[N][n_obs], rew[N]  (+ ckpt as in dsim_step_forward; use dsim_ckpt_floats_mm).
- * episode may be NULL: plain step, no bookkeeping. */
+ * episode may be NULL: plain step, no bookkeeping.  Same precondition and enforcement as dsim_step_forward: q_in holds
+ * unit quaternions (the states this function returns, restarts included, always do). */
 int dsim_env_step_forward(const dsim_model* m, const dsim_env_spec* env, int n_envs,
                           const float* q_in, const float* qd_in, const float* actions,
                           float dt, int substeps, int mm_freq,

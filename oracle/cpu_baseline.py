@@ -138,6 +138,11 @@ def main():
         note = None
     if out is None:
         out = port_leg(name, seconds, threads)
+        # the port on ONE thread next to the multi-threaded figure (its taped reverse sweep allocates
+        # heavily and does not scale linearly with threads: the single-thread figure is the comparable per-core number)
+        if threads > 1:
+            st = port_leg(name, max(2.0, seconds / 4), 1)
+            out["single_thread"] = {k: st[k] for k in ("value", "unit", "cores", "sample")}
         if note:
             out["note"] = note
         if name in REFERENCE_RECORDED:
@@ -146,6 +151,9 @@ def main():
         # the port's figure next to the reference's, same run (half the budget)
         p = port_leg(name, max(2.0, seconds / 2), threads)
         out["port"] = {k: p[k] for k in ("value", "unit", "cores", "sample")}
+        if threads > 1:
+            st = port_leg(name, max(2.0, seconds / 4), 1)
+            out["port"]["single_thread"] = {k: st[k] for k in ("value", "unit", "cores", "sample")}
     print(json.dumps(out))
 
 

@@ -19,7 +19,7 @@ import os
 import warnings
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LEDGER_PATH = os.path.join(ROOT, "gpurun_out", "probe_ledger.jsonl")
+LEDGER_PATH = os.environ.get("DSIM_PROBE_LEDGER") or os.path.join(ROOT, "gpurun_out", "probe_ledger.jsonl")
 STATED = 1e-3
 FACTOR = 3.0
 CEILING = {"step": 5e-3, "rollout": 5e-2}

@@ -36,6 +36,16 @@ def test_dry_run_launches_two_ranks_on_cpu():
     assert j["slowest_rank_s"] >= 0.02                                     # MAX over ranks (rank 1 sleeps longer)
 
 
+def test_dry_run_oversubscribed_keeps_the_gpu_label():
+    """--oversubscribe R: R ranks per GPU over gloo; the line keeps n_gpus = --gpus and says oversubscribed"""
+    out = _run(["--gpus", "1", "--oversubscribe", "2", "--dry-run", "--envs-per-gpu", "512"],
+               env={"CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": ""})
+    assert out.returncode == 0, out.stderr[-800:]
+    j = _json_line(out)
+    assert j["n_gpus"] == 1 and j["oversubscribed"] is True and j["rccl_ranks"] == 2 and j["backend"] == "gloo"
+    assert j["envs_total"] == 1024
+
+
 def test_more_gpus_than_visible_fails_loudly():
     """a `--gpus 2` invocation on a box with fewer GPUs must not print `n_gpus: 1`"""
     import torch
@@ -72,3 +82,18 @@ def test_bench_through_the_launcher_rccl_group_of_one():
     assert j["config"]["submission_fallback"] is False
     assert j["value"] > 1e5 and j["roofline"]["traffic"] > j["roofline"]["alg_bytes_per_launch"]
     assert j["roofline"]["bound"] == "valu-issue" and "valu_issue_frac" in j["roofline"] and "hbm_measured_frac" in j["roofline"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_oversubscribed_on_one_device():
+    """SURVEY 8(e) on a 1-GPU lease: the launcher -> two ranks -> rank-local Engine + shard -> timing all-reduce (MAX over ranks)
+    path executes with world_size 2 against the real kernels.  Both ranks share cuda:0 (gloo; RCCL refuses two ranks per device),
+    so this is a functional run, never a scaling figure: the line says so and keeps n_gpus = 1."""
+    out = _run(["--gpus", "1", "--oversubscribe", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs",
+                "--no-extras", "--strict"], timeout=900)
+    assert out.returncode == 0, out.stderr[-1500:]
+    j = _json_line(out)
+    assert j["n_gpus"] == 1 and j["oversubscribed"] is True and j["rccl_ranks"] == 2 and j["backend"] == "gloo"
+    assert j["config"]["envs_total"] == 2048 and j["config"]["envs_per_gpu"] == 1024
+    assert j["value"] > 1e5 and j["config"]["submission_fallback"] is False
+    assert "NOT a multi-GPU figure" in j["note"]

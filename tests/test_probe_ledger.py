@@ -36,6 +36,7 @@ def _run_parity(test_id, env):
     e = dict(os.environ)
     e.update(env)
     e.pop("PYTEST_CURRENT_TEST", None)
+    e["DSIM_PROBE_LEDGER"] = os.path.join(ROOT, "gpurun_out", "probe_ledger_injected.jsonl")   # not the outer run's ledger
     r = subprocess.run([sys.executable, "-m", "pytest", test_id, "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, env=e,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
     return r.returncode, r.stdout

@@ -35,13 +35,14 @@ fetch_f = counters("fetch", "dsim_env_fwd_kernel").get("FETCH_SIZE")
 write_f = counters("write", "dsim_env_fwd_kernel").get("WRITE_SIZE")
 sq = counters("sq ", "dsim_env_bwd_kernel")
 sqf = counters("sq ", "dsim_env_fwd_kernel")
-try:   # wave count and lane-cycles of the VALU (their own pass)
-    for dst, k in ((sq, "dsim_env_bwd_kernel"), (sqf, "dsim_env_fwd_kernel")):
-        for name_, val in counters("sq3", k).items():
-            if name_ != "SQ_INSTS_VALU":
-                dst[name_] = val
-except ValueError:
-    pass
+for sect in ("sq3", "sq2"):   # wave count and lane-cycles of the VALU; LDS bank conflicts, VMEM instruction counts (own passes)
+    try:
+        for dst, k in ((sq, "dsim_env_bwd_kernel"), (sqf, "dsim_env_fwd_kernel")):
+            for name_, val in counters(sect, k).items():
+                if name_ != "SQ_INSTS_VALU":
+                    dst[name_] = val
+    except ValueError:
+        pass
 header = [
     "# rocprofv3 summary, %s, MI355X, ROCm 7.2, tools/profile.sh %s %s %d%s" % (name, tag, env, n, ("  -- " + note) if note else ""),
     "# command profiled: %s   (kernel sources: csrc hash %s)" % (cmd, h),
