@@ -27,7 +27,11 @@
 #define DSIM_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 #include "dsim_core.hpp"
+#ifdef DSIM_STATIC_LAYOUTS_FILE   // (python -m diffrl_amd.specialise --header-out: a generated header outside the tree)
+#include DSIM_STATIC_LAYOUTS_FILE
+#else
 #include "dsim_static_layouts.hpp"
+#endif
 
 namespace {
 

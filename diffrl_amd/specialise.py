@@ -1,0 +1,216 @@
+"""One command from a user model to its own specialised kernel set:
+
+    python -m diffrl_amd.specialise my_robot.npz --name MyRobot          # template saved with ArticulationTemplate.save()
+
+A model whose LDS layout matches none of the compiled tables runs the GENERIC kernels (run-time offsets and sizes in SGPRs:
+same results, about half the speed).  The specialised kernels are the same phase code instantiated with the model's offsets
+and sizes as compile-time constants.  This module
+  1. computes the model's layout with the builder the library itself runs at dsim_model_create (csrc/dsim_layout.hpp, here as
+     a host-only shared object: no GPU needed),
+  2. keeps the template under csrc/user_models/<Name>.npz (so the generated header is reproducible from inputs),
+  3. regenerates csrc/dsim_static_layouts.hpp: the six shipped models + every user model, and
+  4. rebuilds csrc/libdsim_hip.so with hipcc (the flags of __graft_entry__.build(); ~40 s per model).
+At run time dsim_model_create compares the layout it builds with the tables and uses a specialised set only on an exact match;
+`dsim_model_variant(m) > 0` (Engine.variant) confirms it.  Build-time constants only: nothing is generated or compiled at run
+time.  (tools/gen_static_layouts.py, the developer tool that regenerates the shipped tables, calls render() below.)
+"""
+import argparse
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+
+from . import capi
+from .template import ArticulationTemplate
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+USER_DIR = os.path.join(CSRC, "user_models")
+HEADER = os.path.join(CSRC, "dsim_static_layouts.hpp")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize",
+               "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+DIMS = "L nq nd C M W NS D flags tmask".split()
+PMASK_N = 10
+TRUNK_MAX, TRUNK_CH = 6, 4
+# DsimDims behind pmask, struct order: (name, length); length 0 = scalar (csrc/dsim_layout.hpp)
+EXTRA = [("NT", 0), ("NLT", 0), ("LCAP", 0), ("CCAP", 0), ("trunk", TRUNK_MAX), ("tr_par", TRUNK_MAX), ("tr_nch", TRUNK_MAX),
+         ("tr_ch", TRUNK_MAX * TRUNK_CH), ("tr_cb0", TRUNK_MAX), ("tr_ncb", TRUNK_MAX), ("tr_d0", TRUNK_MAX), ("tr_nd", TRUNK_MAX),
+         ("MK", 0), ("pident", 0)]
+_host = None
+
+
+def _host_lib():
+    """csrc/libdsim_layout_host.so, built on first use (g++, about a second)"""
+    global _host
+    if _host is None:
+        so, src = os.path.join(CSRC, "libdsim_layout_host.so"), os.path.join(CSRC, "dsim_layout_host.cpp")
+        deps = [src, os.path.join(CSRC, "dsim_layout.hpp"), os.path.join(os.path.dirname(HERE), "include", "dsim.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps if os.path.exists(d)):
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", src, "-o", so])
+        _host = C.CDLL(so)
+    return _host
+
+
+def off_names():
+    """field names of struct DsimOff, in order (parsed from the header the kernels are compiled with)"""
+    src = open(os.path.join(CSRC, "dsim_layout.hpp")).read()
+    body = src[src.index("struct DsimOff {"):]
+    body = re.sub(r"//.*", "", body[:body.index("};")])
+    names = []
+    for stmt in body.split(";"):
+        stmt = stmt.strip()
+        if stmt.startswith("struct"):
+            stmt = stmt[stmt.index("{") + 1:].strip()
+        if stmt.startswith("int "):
+            names += [n.strip() for n in stmt[4:].split(",")]
+    return names
+
+
+def layout(t):
+    """(offsets: dict name -> words, dims: dict) of template t, from the library's own layout builder"""
+    desc, keep = capi.make_desc(t)
+    n_off, err = C.c_int(0), C.c_char_p()
+    buf = np.zeros(1024, np.int32)
+    n = _host_lib().dsim_layout_dump(C.byref(desc), buf.ctypes.data_as(C.c_void_p), C.c_int(buf.size), C.byref(n_off), C.byref(err))
+    if n < 0:
+        raise capi.DsimError("the layout builder refuses this model: %s" % (err.value or b"?").decode())
+    names = off_names()
+    assert n_off.value == len(names) and n <= buf.size, (n_off.value, len(names), n)
+    dims = buf[n_off.value:n]
+    d = dict(zip(DIMS, dims.tolist()))
+    d["pmask"] = dims[len(DIMS):len(DIMS) + PMASK_N].tolist()
+    pos = len(DIMS) + PMASK_N
+    for name, cnt in EXTRA:
+        if cnt == 0:
+            d[name] = int(dims[pos]); pos += 1
+        else:
+            d[name] = dims[pos:pos + cnt].tolist(); pos += cnt
+    assert pos == len(dims), "DsimDims has fields this module does not know: update EXTRA (%d of %d ints)" % (pos, len(dims))
+    return dict(zip(names, buf[:n_off.value].tolist())), d
+
+
+def shipped_templates():
+    """(tag, template) of the six environments of the package, in the order of the shipped header"""
+    from . import envs
+    out = []
+    for tag, cls in [("Cartpole", "CartPoleSwingUpEnv"), ("Ant", "AntEnv"), ("Humanoid", "HumanoidEnv"), ("Snu", "SNUHumanoidEnv"),
+                     ("Hopper", "HopperEnv"), ("Cheetah", "CheetahEnv")]:
+        out.append((tag, getattr(envs, cls)(num_envs=1, device="cpu", no_grad=True).model.template()))
+    return out
+
+
+def user_templates(user_dir=USER_DIR):
+    if not os.path.isdir(user_dir):
+        return []
+    return [(f[:-4], ArticulationTemplate.load(os.path.join(user_dir, f))) for f in sorted(os.listdir(user_dir)) if f.endswith(".npz")]
+
+
+def flat_table(off, dims):
+    """the ints dsim_model_create compares (match_variant): DsimOff then DsimDims, struct order"""
+    names = off_names()
+    flat = [off[n] for n in names] + [dims[n] for n in DIMS] + list(dims["pmask"])
+    for name, n in EXTRA:
+        flat += [dims[name]] if n == 0 else list(dims[name])
+    return flat
+
+
+def render(models):
+    """text of dsim_static_layouts.hpp for [(tag, template)]"""
+    names = off_names()
+    lines = ["// GENERATED by diffrl_amd/specialise.py (tools/gen_static_layouts.py) from dsim_layout.hpp -- do not edit by hand.",
+             "// Per-model compile-time LDS layouts; see the generator's docstring.", "#pragma once", ""]
+    tags = []
+    for tag, t in models:
+        if not re.fullmatch(r"[A-Za-z][A-Za-z0-9]*", tag):
+            raise ValueError("model name %r: letters and digits only (it becomes part of C++ identifiers)" % tag)
+        if tag in tags:
+            raise ValueError("two models named %s" % tag)
+        off, dims = layout(t)
+        tags.append(tag)
+        lines.append("struct DsimOff%s {" % tag)
+        lines.append("    static constexpr int " + ", ".join("%s = %d" % (n, off[n]) for n in names) + ";")
+        lines.append("};")
+        lines.append("struct DsimDims%s {" % tag)
+        lines.append("    static constexpr int " + ", ".join("%s = %d" % (n, dims[n]) for n in DIMS) + ";")
+        lines.append("    static constexpr int pmask[%d] = {%s};" % (PMASK_N, ", ".join(str(v) for v in dims["pmask"])))
+        for name, n in EXTRA:
+            v = dims[name]
+            if n == 0:
+                lines.append("    static constexpr int %s = %d;" % (name, v))
+            else:
+                lines.append("    static constexpr int %s[%d] = {%s};" % (name, n, ", ".join(str(x) for x in v)))
+        lines.append("};")
+        lines.append("static const int kDsimStatic%s[] = {%s};" % (tag, ", ".join(str(v) for v in flat_table(off, dims))))
+        lines.append("")
+    lines.append("#ifndef DSIM_STATIC_VARIANTS  // (developer builds compile a subset: -D'DSIM_STATIC_VARIANTS(X)=X(Ant)')")
+    lines.append("#define DSIM_STATIC_VARIANTS(X) " + " ".join("X(%s)" % t for t in tags))
+    lines.append("#endif")
+    return "\n".join(lines) + "\n"
+
+
+def matches(t, header_text):
+    """name of the table in `header_text` that template t's layout equals exactly (what dsim_model_create will pick), or None"""
+    flat = flat_table(*layout(t))
+    for m in re.finditer(r"static const int kDsimStatic(\w+)\[\] = \{([^}]*)\};", header_text):
+        if [int(x) for x in m.group(2).split(",")] == flat:
+            return m.group(1)
+    return None
+
+
+def build_library(out, header=None, only=None):
+    """hipcc: csrc/dsim_hip.hip -> out.  header: another generated layouts header than csrc/dsim_static_layouts.hpp;
+    only: list of model names to compile specialised sets for (the generic kernels are always there)"""
+    cmd = ["hipcc"] + HIPCC_FLAGS
+    if header:
+        cmd.append('-DDSIM_STATIC_LAYOUTS_FILE="%s"' % os.path.abspath(header))
+    if only:
+        cmd.append("-DDSIM_STATIC_VARIANTS(X)=" + " ".join("X(%s)" % m for m in only))
+    cmd += [os.path.join(CSRC, "dsim_hip.hip"), "-o", out]
+    subprocess.check_call(cmd)
+    return out
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m diffrl_amd.specialise", description=__doc__.split("\n\n")[0])
+    ap.add_argument("template", help=".npz written by ArticulationTemplate.save()")
+    ap.add_argument("--name", required=True, help="name of the kernel set (letters / digits)")
+    ap.add_argument("--header-out", help="write the generated header here instead of csrc/dsim_static_layouts.hpp (the in-tree header "
+                                         "and csrc/user_models/ stay untouched)")
+    ap.add_argument("--lib-out", help="build this library instead of csrc/libdsim_hip.so (use it with DSIM_LIB=<path>)")
+    ap.add_argument("--only", action="store_true", help="compile the generic kernels + this model's set only (~40 s instead of minutes)")
+    ap.add_argument("--no-build", action="store_true", help="generate the header, do not run hipcc")
+    a = ap.parse_args(argv)
+    t = ArticulationTemplate.load(a.template)
+    models = shipped_templates()
+    known = matches(t, render(models))
+    if known:
+        print("this model already has a specialised kernel set: %s (nothing to do)" % known)
+        return 0
+    if a.header_out:
+        models = models + [(n, u) for n, u in user_templates() if n != a.name] + [(a.name, t)]
+        header = a.header_out
+    else:
+        os.makedirs(USER_DIR, exist_ok=True)
+        t.save(os.path.join(USER_DIR, a.name + ".npz"))
+        models = models + user_templates()
+        header = HEADER
+    txt = render(models)
+    open(header, "w").write(txt)
+    assert matches(t, txt) == a.name
+    off, dims = layout(t)
+    print("wrote %s: %d models, %s = %d links, %d dofs, %d contacts, LDS image %d / %d words (forward / adjoint)"
+          % (header, len(models), a.name, dims["L"], dims["nd"], dims["C"], off["fwd_words"], off["total_words"]))
+    if a.no_build:
+        return 0
+    out = a.lib_out or os.path.join(CSRC, "libdsim_hip.so")
+    build_library(out, header if a.header_out else None, [a.name] if a.only else None)
+    print("built %s; a model created from this template now reports dsim_model_variant > 0%s"
+          % (out, "" if not a.lib_out else " (run with DSIM_LIB=%s)" % os.path.abspath(out)))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

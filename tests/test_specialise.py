@@ -1,0 +1,109 @@
+"""`python -m diffrl_amd.specialise <template.npz> --name X`: one command from a user model to its own specialised kernel set
+(INTEGRATION.md section 2(f)).  CPU: the generated tables are what dsim_model_create will match; GPU: a seeded random tree goes
+generic -> specialised through the library build() made with exactly that command, and gets the same results."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from diffrl_amd import specialise
+from diffrl_amd.template import ArticulationTemplate
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIXTURE = os.path.join(ROOT, "tests", "golden", "user_tree.npz")
+USER_LIB = os.path.join(ROOT, "tests", "inject", "libdsim_user.so")
+
+
+def test_fixture_is_the_seeded_random_tree():
+    from test_edge_cases_cpu import _random_tree
+    t, _ = _random_tree(2, True)
+    f = ArticulationTemplate.load(FIXTURE)
+    for k in ArticulationTemplate._ARRAYS:
+        np.testing.assert_array_equal(getattr(t, k), getattr(f, k), err_msg=k)
+
+
+def test_shipped_header_is_what_the_generator_renders_and_every_model_matches_its_own_table():
+    models = specialise.shipped_templates()
+    txt = specialise.render(models + specialise.user_templates())
+    shipped = open(specialise.HEADER).read()
+    assert txt.split("\n", 1)[1] == shipped.split("\n", 1)[1], "csrc/dsim_static_layouts.hpp is stale: python tools/gen_static_layouts.py"
+    for tag, t in models:
+        assert specialise.matches(t, shipped) == tag
+    assert specialise.matches(ArticulationTemplate.load(FIXTURE), shipped) is None      # a user model: generic kernels as shipped
+
+
+def test_one_command_generates_a_matching_table(tmp_path):
+    hdr = tmp_path / "layouts.hpp"
+    r = subprocess.run([sys.executable, "-m", "diffrl_amd.specialise", FIXTURE, "--name", "UserTree", "--header-out", str(hdr),
+                        "--no-build"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    txt = hdr.read_text()
+    t = ArticulationTemplate.load(FIXTURE)
+    assert specialise.matches(t, txt) == "UserTree" and "struct DsimOffUserTree" in txt and "X(UserTree)" in txt
+    # anything the layout depends on changes -> no match (generic kernels), never a wrong table
+    d = t.to_dict()
+    d["contact_body"] = np.concatenate([d["contact_body"], d["contact_body"][:1]])
+    d["contact_point"] = np.concatenate([d["contact_point"], d["contact_point"][:1]])
+    d["contact_dist"] = np.concatenate([d["contact_dist"], d["contact_dist"][:1]])
+    d["contact_material"] = np.concatenate([d["contact_material"], d["contact_material"][:1]])
+    assert specialise.matches(ArticulationTemplate.from_dict(d), txt) is None
+    # a shipped model is recognised: nothing to generate
+    from oracle_lib import template_from_golden
+    ant = tmp_path / "ant.npz"
+    template_from_golden("ant").save(str(ant))
+    r = subprocess.run([sys.executable, "-m", "diffrl_amd.specialise", str(ant), "--name", "MyAnt", "--header-out", str(hdr), "--no-build"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "already has a specialised kernel set: Ant" in r.stdout
+
+
+_GPU_SCRIPT = r'''
+import os, sys, hashlib
+import numpy as np, torch
+sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, %(root)r)
+from diffrl_amd.engine import Engine
+from diffrl_amd.template import ArticulationTemplate
+from test_edge_cases_cpu import _tree_states
+t = ArticulationTemplate.load(%(fixture)r)
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(7)
+for n in (5, 2048):            # helper-wave kernels (all environments resident) and the single-wave kernels
+    q, qd, act = _tree_states(t, rng, n)
+    gq, gqd = rng.normal(0, 1, q.shape).astype(np.float32), rng.normal(0, 1, qd.shape).astype(np.float32)
+    T = lambda a: torch.tensor(a, device=dev).reshape(-1)
+    outs = []
+    for generic in (True, False):
+        if generic: os.environ["DSIM_FORCE_GENERIC"] = "1"
+        else: os.environ.pop("DSIM_FORCE_GENERIC", None)
+        eng = Engine(t, dev)
+        assert (eng.variant == 0) == generic, (eng.variant, generic)
+        qo, qdo, ck = eng.forward(T(q), T(qd), T(act), None, 4 / 960.0, 4, 2, True)
+        g = eng.backward(ck, T(act), None, 4 / 960.0, 4, 2, T(gq), T(gqd))
+        torch.cuda.synchronize()
+        outs.append([x.cpu().numpy() for x in (qo, qdo) + tuple(y for y in g if y is not None)])
+    worst = max(float(np.abs(a - b).max() / (np.abs(a).max() + 1e-30)) for a, b in zip(*outs))
+    same = all(np.array_equal(a, b) for a, b in zip(*outs))
+    print("RESULT n=%%d bit_identical=%%s worst_rel=%%.3e" %% (n, same, worst))
+'''
+
+
+@pytest.mark.gpu
+def test_random_tree_goes_generic_to_specialised_with_the_same_results():
+    if not os.path.exists(USER_LIB):
+        pytest.fail("tests/inject/libdsim_user.so is missing: __graft_entry__.build() makes it with python -m diffrl_amd.specialise")
+    e = dict(os.environ)
+    e["DSIM_LIB"] = USER_LIB
+    e.pop("DSIM_FORCE_GENERIC", None)
+    r = subprocess.run([sys.executable, "-c", _GPU_SCRIPT % dict(root=ROOT, fixture=FIXTURE)], cwd=ROOT, env=e, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+    res = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert len(res) == 2, r.stdout
+    from emu_lib import reorders
+    exact = not reorders(ArticulationTemplate.load(FIXTURE))
+    for l in res:   # same phase code, compile-time vs run-time layout: bit for bit unless the specialised set re-associates sums
+        if exact:
+            assert "bit_identical=True" in l, l
+        else:
+            assert float(l.split("worst_rel=")[1]) < 2e-5, l

@@ -1,72 +1,15 @@
-"""Generates diffrl_amd/csrc/dsim_static_layouts.hpp: the LDS layout (offsets + sizes) of the known models
-as all-constexpr structs, so that per-model specialised kernels get every LDS offset as an instruction
-immediate and every size as a compile-time loop bound.  The numbers come from the SAME layout builder the
-library runs at dsim_model_create (dsim_layout.hpp, called through the host test harness); at run time the
-library compares the layout it builds with these tables and only uses a specialised kernel on an exact
-match -- any other model runs the generic kernels.  Build-time constants only: no run-time code generation."""
+"""Developer tool: regenerates diffrl_amd/csrc/dsim_static_layouts.hpp -- the LDS layouts (offsets + sizes) of the shipped
+models and of every user model under csrc/user_models/ as all-constexpr structs -- with the product's generator
+(diffrl_amd/specialise.py, which calls the layout builder the library runs at dsim_model_create).  Run after a change of
+dsim_layout.hpp.  Build-time constants only: no run-time code generation."""
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from emu_lib import _off_names, layout  # noqa: E402
-
-DIMS = "L nq nd C M W NS D flags tmask".split()
-PMASK_N = 10
-# fields behind pmask, in struct order: (name, length); length 0 = scalar  (DsimDims in dsim_layout.hpp)
-TRUNK_MAX, TRUNK_CH = 6, 4
-EXTRA = [("NT", 0), ("NLT", 0), ("LCAP", 0), ("CCAP", 0), ("trunk", TRUNK_MAX), ("tr_par", TRUNK_MAX), ("tr_nch", TRUNK_MAX),
-         ("tr_ch", TRUNK_MAX * TRUNK_CH), ("tr_cb0", TRUNK_MAX), ("tr_ncb", TRUNK_MAX), ("tr_d0", TRUNK_MAX), ("tr_nd", TRUNK_MAX), ("MK", 0), ("pident", 0)]
-
-
-def templates():
-    from diffrl_amd import envs
-    out = []
-    for tag, cls in [("Cartpole", envs.CartPoleSwingUpEnv), ("Ant", envs.AntEnv), ("Humanoid", envs.HumanoidEnv),
-                     ("Snu", envs.SNUHumanoidEnv)] + [(t, getattr(envs, c)) for t, c in
-                                                      [("Hopper", "HopperEnv"), ("Cheetah", "CheetahEnv")]
-                                                      if hasattr(envs, c)]:
-        e = cls(num_envs=1, device="cpu", no_grad=True)
-        out.append((tag, e.model.template()))
-    return out
-
-
-def render():
-    names = _off_names()
-    lines = ["// GENERATED by tools/gen_static_layouts.py from dsim_layout.hpp -- do not edit by hand.",
-             "// Per-model compile-time LDS layouts; see the generator's docstring.", "#pragma once", ""]
-    tags = []
-    for tag, t in templates():
-        off, dims = layout(t)
-        tags.append(tag)
-        lines.append("struct DsimOff%s {" % tag)
-        lines.append("    static constexpr int " + ", ".join("%s = %d" % (n, off[n]) for n in names) + ";")
-        lines.append("};")
-        lines.append("struct DsimDims%s {" % tag)
-        lines.append("    static constexpr int " + ", ".join("%s = %d" % (n, dims[n]) for n in DIMS) + ";")
-        lines.append("    static constexpr int pmask[%d] = {%s};" % (PMASK_N, ", ".join(str(v) for v in dims["pmask"])))
-        flat = []
-        for name, n in EXTRA:
-            v = dims[name]
-            if n == 0:
-                lines.append("    static constexpr int %s = %d;" % (name, v))
-                flat.append(v)
-            else:
-                lines.append("    static constexpr int %s[%d] = {%s};" % (name, n, ", ".join(str(x) for x in v)))
-                flat += list(v)
-        lines.append("};")
-        lines.append("static const int kDsimStatic%s[] = {%s};" % (
-            tag, ", ".join(str(off[n]) for n in names) + ", " + ", ".join(str(dims[n]) for n in DIMS) + ", " +
-            ", ".join(str(v) for v in dims["pmask"]) + ", " + ", ".join(str(v) for v in flat)))
-        lines.append("")
-    lines.append("#ifndef DSIM_STATIC_VARIANTS  // (developer builds compile a subset: -D'DSIM_STATIC_VARIANTS(X)=X(Ant)')")
-    lines.append("#define DSIM_STATIC_VARIANTS(X) " + " ".join("X(%s)" % t for t in tags))
-    lines.append("#endif")
-    return "\n".join(lines) + "\n"
-
+sys.path.insert(0, ROOT)
+from diffrl_amd import specialise  # noqa: E402
 
 if __name__ == "__main__":
-    path = os.path.join(ROOT, "diffrl_amd", "csrc", "dsim_static_layouts.hpp")
-    txt = render()
-    open(path, "w").write(txt)
-    print("wrote", path, len(txt), "bytes")
+    txt = specialise.render(specialise.shipped_templates() + specialise.user_templates())
+    open(specialise.HEADER, "w").write(txt)
+    print("wrote", specialise.HEADER, len(txt), "bytes")
