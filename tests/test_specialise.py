@@ -100,10 +100,8 @@ def test_random_tree_goes_generic_to_specialised_with_the_same_results():
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
     res = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
     assert len(res) == 2, r.stdout
-    from emu_lib import reorders
-    exact = not reorders(ArticulationTemplate.load(FIXTURE))
-    for l in res:   # same phase code, compile-time vs run-time layout: bit for bit unless the specialised set re-associates sums
-        if exact:
-            assert "bit_identical=True" in l, l
-        else:
-            assert float(l.split("worst_rel=")[1]) < 2e-5, l
+    for l in res:
+        # same phase code with a compile-time instead of a run-time layout.  hipcc contracts multiply-adds differently in the two
+        # instantiations, so the last bits may differ (measured 4.5e-6 here); the bound is the one the shipped models are held to
+        # (tests/test_gpu_parity.py::test_specialised_kernels_match_generic)
+        assert float(l.split("worst_rel=")[1]) < 1e-5, l
