@@ -178,6 +178,14 @@ DSIM_FN float dsim_dot_n(const float* a, const float* b, int n) {
     return acc;
 }
 
+// compile-time loop with a constexpr index (per-position joint-type masks of the specialised kernels)
+template <int I, int N, class F> DSIM_FN void dsim_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        dsim_static_for<I + 1, N>(f);
+    }
+}
+
 // ================================================================================================
 // forward
 // ================================================================================================
@@ -210,6 +218,8 @@ template <class Ctx, class Exec> DSIM_FN void dsim_init_static(const Ctx& c, Exe
 // index records of those roles never change, so they are read from the LDS tables once per launch (dsim_topo_init)
 // instead of being the first of two or three DEPENDENT LDS round trips of a phase in every substep.  Fields a kernel
 // does not use cost nothing (dead registers).
+#define DSIM_GX_PASSES 3   // 12 L <= 192 items over 64 lanes
+#define DSIM_GX_CAP 12     // most contacts on one body the register form handles (DsimDims::CBMAX; more: the row-tree form is off)
 struct DsimTopoRegs {
     int chain[4 * DSIM_CHAIN_MAX + 1];       // ancestors of link `lane`, root first: (link, type, q start, qd start); [last] = length
     int own_type, own_cs, own_ds, own_nd;    // joint of link `lane`
@@ -226,6 +236,30 @@ struct DsimTopoRegs {
     float tw_l[DSIM_TR_PASSES][DSIM_LIGHT_CAP], tw_c[DSIM_TR_PASSES][DSIM_LIGHT_CAP];   // 1 / 0 weights of the light sums' entries (adjoint kernels)
     int adof[16], adof_n;                    // dofs of the ancestors-or-self of link `(63 - lane) / 6` (adjoint of tau)
     int jmp[DSIM_SCAN_ROUNDS_MAX];           // lane of the ancestor of link `lane` at distance 2^r (none: the last lane): DsimScanFk
+    float rt_w[DSIM_RT_MAX];                 // row-tree sums: 1 if link `lane` has a child of step s's level at lane + rt_d[s], else 0
+    // per-body gather of the contact cotangent rows (row-tree body level): item `lane + 64 p` = (link, one of 12 components);
+    // first word of the body's first contact row for that component (an in-range word where the body has none), contact count
+    // (selects, not 1 / 0 weight registers: the records live in registers for the whole launch, of BOTH waves)
+    int gx_row[DSIM_GX_PASSES], gx_n[DSIM_GX_PASSES];
+};
+
+// Row-tree form of the body-level adjoint (dsim_bwd_bodies_rowtree): specialised one-wave kernels of trees that fit one 16-lane
+// DPP row (DsimDims::RT_N > 0: L <= 16, pre-order ranges, no muscles), without ball joints (none of the shipped small models has
+// one; a model with ball joints keeps the phase-per-sum form).
+template <class Ctx, class Exec> struct DsimRowTree {
+    static constexpr bool value = []() {
+#ifdef DSIM_NO_ROWTREE   // (A/B builds)
+        return false;
+#else
+        if constexpr (std::is_empty<decltype(Ctx::d)>::value && Exec::WAVE_OPS) {
+            using D = decltype(Ctx::d);
+            return D::RT_N > 0 && D::NS == 0 && (D::tmask & DSIM_TM(DSIM_JOINT_BALL)) == 0 && (D::flags & DSIM_F_RANGES) != 0 &&
+                   D::CBMAX <= DSIM_GX_CAP;
+        } else {
+            return false;
+        }
+#endif
+    }();
 };
 template <class Ctx> struct DsimChainRegs {
     static constexpr bool value = []() {
@@ -326,7 +360,8 @@ template <class Ctx, int NL> struct DsimContactsInKin {
         else return false;
     }();
 };
-template <class Ctx, class Exec> DSIM_FN void dsim_topo_init(const Ctx& c, Exec& ex, int lane) {
+// ADJ: the launch runs adjoint phases (the forward kernels skip the records only those use)
+template <bool ADJ = true, class Ctx, class Exec> DSIM_FN void dsim_topo_init(const Ctx& c, Exec& ex, int lane) {
     if constexpr (DsimTrunk<Ctx, Exec>::value) {
         using D = decltype(c.d);
         DsimTopoRegs& tp = ex.topo(lane);
@@ -422,6 +457,36 @@ template <class Ctx, class Exec> DSIM_FN void dsim_topo_init(const Ctx& c, Exec&
         tp.dof_cs = CI(qstart)[l];
         tp.dof_ds = CI(qdstart)[l];
     }
+    if constexpr (ADJ && DsimRowTree<Ctx, Exec>::value) {
+        using D = decltype(c.d);
+        DsimTopoRegs& tp = ex.topo(lane);
+        // link `lane` has a child rt_d[s] lanes above iff that link's parent is `lane` (its level is then rt_lvl[s] or the step
+        // belongs to another level): two independent loads per step, one LDS round trip for all of them
+        int pr[D::RT_N], lv[D::RT_N];
+        dsim_static_for<0, D::RT_N>([&](auto ss) {
+            constexpr int s_ = decltype(ss)::value;
+            const int ch = lane + D::rt_d[s_] < D::L ? lane + D::rt_d[s_] : 0;
+            pr[s_] = CI(linfo)[8 * ch];
+            lv[s_] = CI(linfo)[8 * ch + 4];
+        });
+        dsim_static_for<0, D::RT_N>([&](auto ss) {
+            constexpr int s_ = decltype(ss)::value;
+            tp.rt_w[s_] = (lane + D::rt_d[s_] < D::L && pr[s_] == lane && lv[s_] == D::rt_lvl[s_]) ? 1.f : 0.f;
+            DSIM_OPAQUE(tp.rt_w[s_]);
+        });
+        constexpr int GXP = (12 * D::L + Exec::NL - 1) / Exec::NL;
+        static_assert(GXP <= DSIM_GX_PASSES, "per-body gather passes");
+#pragma unroll
+        for (int p = 0; p < GXP; ++p) {
+            const int it = lane + Exec::NL * p, li = it < 12 * D::L ? it / 12 : 0, r = it < 12 * D::L ? it - 12 * li : 0;
+            const int b0 = CI(cb_start)[li], n = it < 12 * D::L ? CI(cb_start)[li + 1] - b0 : 0;
+            // (pre-order ranges: the contacts of a body are consecutive, cb_list[b0] is the first; a body without contacts and
+            // the lanes past the last item point at row 0 with all-zero weights)
+            const int first = (n > 0 && D::C > 0) ? CI(cb_list)[b0] : 0;
+            tp.gx_row[p] = 12 * first + r;
+            tp.gx_n[p] = n;
+        }
+    }
     if constexpr (DsimContactRegs<Ctx, Exec::NL>::value) {
         DsimTopoRegs& tp = ex.topo(lane);
         const int kf = lane < c.d.C ? lane : 0, kb = (Exec::NL - 1 - lane) < c.d.C ? (Exec::NL - 1 - lane) : 0;
@@ -474,13 +539,6 @@ template <class Ctx> struct DsimFreeRootIdent {
         }
     }();
 };
-// compile-time loop with a constexpr index (per-position joint-type masks of the specialised kernels)
-template <int I, int N, class F> DSIM_FN void dsim_static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        dsim_static_for<I + 1, N>(f);
-    }
-}
 // joint types that can occur at chain position P (specialised kernels: a compile-time constant, so the branches of
 // types that do not occur there -- and their loads -- are not even compiled)
 template <class D, int P> constexpr int dsim_pos_mask() { return P < DSIM_PMASK_N ? D::pmask[P] : D::tmask; }
@@ -1790,7 +1848,7 @@ DSIM_FN void dsim_sim_step_forward(const Ctx& c, Exec& ex, int substeps, int mm_
     ex.begin_request();
     ex.begin();
     dsim_init_static(c, ex);
-    ex.run_both([&](int lane) { dsim_topo_init(c, ex, lane); });   // every wave keeps its own topology records
+    ex.run_both([&](int lane) { dsim_topo_init<false>(c, ex, lane); });   // every wave keeps its own topology records
     ex.run([&](int lane) {
         for (int k = lane; k < nq; k += Exec::NL) WF(q)[k] = g_q[k];
         for (int k = lane; k < nd; k += Exec::NL) {
@@ -1818,7 +1876,7 @@ DSIM_FN void dsim_body_transforms_only(const Ctx& c, Exec& ex, const float* g_q,
     ex.begin_request();
     ex.begin();
     dsim_init_static(c, ex);
-    ex.run_both([&](int lane) { dsim_topo_init(c, ex, lane); });
+    ex.run_both([&](int lane) { dsim_topo_init<false>(c, ex, lane); });
     ex.run([&](int lane) {
         for (int k = lane; k < c.d.nq; k += Exec::NL) WF(q)[k] = g_q[k];
         for (int k = lane; k < c.d.nd; k += Exec::NL) WF(qd)[k] = 0.f;
@@ -2572,6 +2630,167 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
     });
 }
 
+// Subtree sums of a per-link 6-vector held in REGISTERS (link i on lane i, the whole tree in one 16-lane DPP row): bottom-up by
+// levels; in step s every parent adds the finished total of its child rt_d[s] lanes above (Exec::from_above: a DPP row shift --
+// VALU latency, no LDS), weighted 1 / 0.  Replaces an LDS store, a phase, ~34 loads + ~34 multiply-adds on (link, component)
+// lanes and the load of the result in the next phase.  Lanes that hold no link must carry zeros.  Same terms as the range sums,
+// associated by tree level instead of by index: not bit-identical to them (the tests hold both to the reference).
+template <class Ctx, class Exec> DSIM_FN void dsim_rowtree_sum(const Ctx&, Exec& ex, const DsimTopoRegs& tp, sv6& x) {
+    using D = decltype(Ctx::d);
+    dsim_static_for<0, D::RT_N>([&](auto ss) {
+        constexpr int s_ = decltype(ss)::value, dist = D::rt_d[s_];
+        ex.template add_from_above<dist>(x.w.x, x.w.y, x.w.z, x.v.x, x.v.y, x.v.z, tp.rt_w[s_]);   // x_k += x_k[lane + dist] * w
+    });
+}
+
+// Body level of the adjoint substep for row trees (DsimRowTree): ONE phase on the link lanes.  dsim_bwd_bodies below is the
+// general form -- per-link block, subtree sum, per-link block, subtree sum, per-link block, subtree sum, per-link block: seven
+// phases, each paying an LDS round trip for values that only change lanes inside the tree.  Here the three subtree sums are
+// row-tree sums on registers and everything a link lane computes stays in its registers from the first load to the cotangents of
+// its joint coordinates.  The one thing that comes from other lanes' ITEMS is the contact terms: the side block (the helper
+// wavefront where there is one) evaluates contacts^T per contact and reduces them per body (agx: pose wrench 6, twist cotangent
+// 6); the link lanes pick their body's row up at Exec::side_done(), after the first third of their work.
+template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx& c, Exec& ex, bool update_mass) {
+    ex.mark(10);
+    using D = decltype(c.d);
+    constexpr int L = D::L, MASK = D::tmask;
+    constexpr bool HAS_FREE = (MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0;
+    ex.fork_side([&](int lane) {
+        const DsimTopoRegs& tp = ex.topo(lane);
+        const bool on = lane < L;
+        const int i = on ? lane : 0;
+        int type = tp.own_type;
+        DSIM_OPAQUE(type);
+        const int cs = tp.own_cs, ds = tp.own_ds, par = tp.own_parent;
+        const bool hinge = type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE, fr = type == DSIM_JOINT_FREE;
+        // ---- every operand that does not come out of this phase, in one round trip
+        const inertia10 I = ld_i10(WF(i10) + 10 * i);
+        const sv6 v = ldsv(WF(v) + 6 * i), a = ldsv(WF(a) + 6 * i), r = ldsv(WF(af) + 6 * i);
+        const v3 grav = ld3(CF(grav));
+        float g[10];
+        for (int k = 0; k < 10; ++k) g[k] = update_mass ? WF(ai10m)[10 * i + k] : 0.f;
+        const sv6 S0 = ldsv(WF(S) + 6 * ds), aS0 = ldsv(WF(aS) + 6 * ds);
+        float* aq = WF(aq);
+        float* aqd = WF(aqd);
+        const float qd0 = WF(qd)[ds], g0 = aqd[ds], gq0 = aq[cs];
+        sv6 qd6 = zerosv(), g6 = zerosv();
+        v3 pc = zero3(), gp = zero3();
+        q4 rc = mkq(0.f, 0.f, 0.f, 1.f), gr = mkq(0.f, 0.f, 0.f, 0.f);
+        if constexpr (HAS_FREE) {
+            qd6 = mksv(mk3(qd0, WF(qd)[ds + 1], WF(qd)[ds + 2]), ld3(WF(qd) + ds + 3));
+            g6 = mksv(mk3(g0, aqd[ds + 1], aqd[ds + 2]), ld3(aqd + ds + 3));
+            pc = ld3(WF(xsc) + 7 * i);
+            rc = ldq(WF(xsc) + 7 * i + 3);
+            gp = mk3(gq0, aq[cs + 1], aq[cs + 2]);
+            gr = ldq(aq + cs + 3);
+        }
+        // ---- f^T, velocity / acceleration recursions^T of the link itself, pose wrench of inertia + gravity (dsim_bwd_bodies)
+        const sv6 hv = inertia_mul(I, v);
+        sv6 a_v, a_hv;
+        a_v.w = cross(hv.w, r.w) + cross(hv.v, r.v);
+        a_v.v = cross(hv.v, r.w);
+        a_hv.w = cross(r.w, v.w);
+        a_hv.v = cross(r.w, v.v) + cross(r.v, v.w);
+        a_v += inertia_mul(I, a_hv);
+#ifdef DSIM_INJECT_ADJ_ERROR
+        a_v = a_v * DSIM_INJECT_ADJ_ERROR;   // (developer / test builds only, see dsim_bwd_bodies)
+#endif
+        inertia_bilinear_adj(g, r, a, 1.0f);
+        inertia_bilinear_adj(g, a_hv, v, 1.0f);
+        sv6 W = inertia_pose_wrench(I, g);
+        const v3 rg = cross(r.w, grav);
+        W.w += cross(I.h, rg);
+        W.v += rg * I.m;
+        sv6 A = inertia_mul(I, r);   // aa
+        if (!on) {                   // lanes without a link computed on link 0's operands: they must add nothing to the sums
+            A = zerosv();
+            a_v = zerosv();
+            W = zerosv();
+        }
+        // ---- aatot = subtree sum of aa; joint motion^T
+        dsim_rowtree_sum(c, ex, tp, A);
+        sv6 vj = zerosv();
+        if constexpr (HAS_FREE) {
+            if (fr) vj = qd6;
+        }
+        if (hinge) vj = S0 * qd0;
+        a_v.w += cross(vj.w, A.w) + cross(vj.v, A.v);
+        a_v.v += cross(vj.w, A.v);
+        sv6 a_vj;
+        a_vj.w = cross(A.w, v.w) + cross(A.v, v.v);
+        a_vj.v = cross(A.v, v.w);
+        ex.stamp();
+        // ---- the contact terms of the own body, reduced by the side block
+        ex.side_done();
+        sv6 cpose = ldsv(WF(agx) + 12 * i), ctw = ldsv(WF(agx) + 12 * i + 6);
+        if (!on) {
+            cpose = zerosv();
+            ctw = zerosv();
+            a_vj = zerosv();
+        }
+        // ---- avtot = subtree sum of (a_v + contact twist cotangents); cotangents of qd and of S; S is attached to the joint frame
+        sv6 T = a_v + ctw;
+        dsim_rowtree_sum(c, ex, tp, T);
+        a_vj += T;
+        sv6 Wp = zerosv();
+        float aqd_new = g0;
+        if (hinge && on) {
+            Wp = scross_dual(S0, aS0 + a_vj * qd0);
+            aqd_new = g0 + sdot(S0, a_vj);
+        }
+        // ---- azs = subtree sum of the pose wrenches (inertia + gravity, joint frame of the children's S, contacts)
+        sv6 Z = W + Wp + cpose;
+        dsim_rowtree_sum(c, ex, tp, Z);
+        const sv6 Wt = Z - Wp;   // without the part attached to the link's own joint frame
+        ex.stamp();
+        // ---- adj q_d = S_d . Wt; all stores of the phase
+        if (on) {
+            if (hinge) {
+                aqd[ds] = aqd_new;
+                aq[cs] = gq0 + sdot(S0, Wt);
+            }
+            if constexpr (HAS_FREE) {
+                if (fr) {
+                    stsv(aqd + ds, g6 + a_vj);
+                    const v3 tc = Wt.w - cross(pc, Wt.v);
+                    if constexpr (DsimFreeRootIdent<Ctx>::value) {
+                        (void)par;
+                        st3(aq + cs, gp + Wt.v);
+                        stq(aq + cs + 3, gr + qmul_v(tc, rc) * 2.0f);
+                    } else {
+                        const q4 rpj = ldq(CF(xpj) + 7 * i + 3);
+                        q4 rj = rpj;
+                        if (par >= 0) rj = qmul(ldq(WF(xsc) + 7 * par + 3), rpj);
+                        st3(aq + cs, gp + rotate_inv(rj, Wt.v));
+                        stq(aq + cs + 3, gr + qmul(qmul(qconj(rj), mkq(tc.x, tc.y, tc.z, 0.f)), rc) * 2.0f);
+                    }
+                }
+            }
+        }
+    }, [&](int lane) {
+        // side block: contacts^T per contact, then the per-body sums of their 12-float rows (bodies without contacts: zeros)
+        dsim_bwd_external_items(c, ex, lane);
+        ex.lds_fence();
+        const DsimTopoRegs& tp = ex.topo(lane);
+        constexpr int GXP = (12 * L + Exec::NL - 1) / Exec::NL, CB = D::CBMAX > 0 ? D::CBMAX : 1;
+        float x[GXP][CB];
+#pragma unroll
+        for (int p = 0; p < GXP; ++p)   // all loads first: addresses are register + immediate (rows past a body's last contact are
+#pragma unroll                          // other contacts' rows or the arrays behind acx: selected away)
+            for (int e = 0; e < CB; ++e) x[p][e] = WF(acx)[tp.gx_row[p] + 12 * e];
+#pragma unroll
+        for (int p = 0; p < GXP; ++p) {
+            float acc = 0.f;
+            int n = tp.gx_n[p];
+            DSIM_OPAQUE(n);   // (the e < n masks are recomputed here, not kept as loop invariants in spilled SGPR pairs)
+#pragma unroll
+            for (int e = 0; e < CB; ++e) acc += (e < n) ? x[p][e] : 0.f;
+            const int it = lane + Exec::NL * p;
+            if (it < 12 * L) WF(agx)[it] = acc;
+        }
+    });
+}
+
 // Lean checkpoint mode: the row holds only (q, qd); the forward intermediates of the substep are recomputed here with the
 // forward pass's own phases (same code, same inputs: bit-identical to what the full mode reads back from HBM).
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_recompute_forward(const Ctx& c, Exec& ex) {
@@ -2584,7 +2803,8 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_recompute_forward(const C
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_substep(const Ctx& c, Exec& ex, bool update_mass) {
     dsim_bwd_joint_space(c, ex, update_mass);
     if (update_mass) dsim_bwd_mass(c, ex);
-    dsim_bwd_bodies(c, ex, update_mass);
+    if constexpr (DsimRowTree<Ctx, Exec>::value) dsim_bwd_bodies_rowtree(c, ex, update_mass);
+    else dsim_bwd_bodies(c, ex, update_mass);
 }
 
 // Reverse sweep of one env.step().  g_ckpt is this environment's [substeps][nq+nd] checkpoint.
@@ -3027,7 +3247,7 @@ DSIM_FN void dsim_env_fused_forward(const Ctx& c, Exec& ex, const DsimEnvSpec& s
     const int cnt = ep.progress ? ep.reset_count[e] : 0;
     ex.begin();
     dsim_init_static(c, ex);
-    ex.run_both([&](int lane) { dsim_topo_init(c, ex, lane); });   // every wave keeps its own topology records
+    ex.run_both([&](int lane) { dsim_topo_init<false>(c, ex, lane); });   // every wave keeps its own topology records
     ex.run([&](int lane) {
         const float* io = ex.io(lane);
         dsim_io_each<IO::CQ, Exec::NL>(nq, lane, [&](int k, int u) { WF(q)[k] = IO::PRE ? io[IO::Q + u] : g_q[k]; });

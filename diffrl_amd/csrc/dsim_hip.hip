@@ -173,6 +173,35 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
     __device__ __forceinline__ float bcast(float v, int src) {
         return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
     }
+    // value of v in lane + D of the same 16-lane ROW (0 beyond the row's end, 0 from an inactive lane): a DPP row shift on the
+    // operand -- VALU latency, no LDS, no SGPR.  Pinned on hardware by tools/micro/dpp_semantics.hip (row_shl:D, bound_ctrl on).
+    template <int D> __device__ __forceinline__ float from_above(float v) {
+        static_assert(D >= 1 && D <= 15, "row shifts reach 1 .. 15 lanes");
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + D, 0xf, 0xf, true));
+    }
+    // a_k += a_k[lane + D of the row] * w for six values at once: v_fmac_f32 with the DPP shift ON ITS OPERAND (the compiler
+    // keeps a v_mov_b32_dpp + v_fmac pair for the builtin form: twice the instructions on a path where every issue slot counts).
+    // A VGPR written by a VALU instruction may be read through DPP two wait states later at the earliest: the six lines are
+    // independent of each other, so only the first needs the s_nop, and a_k's own update is five instructions behind its read.
+    template <int D>
+    __device__ __forceinline__ void add_from_above(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
+        static_assert(D >= 1 && D <= 15, "row shifts reach 1 .. 15 lanes");
+#ifdef DSIM_NO_DPP_ASM   // (A/B builds: the builtin form)
+        a0 = __builtin_fmaf(from_above<D>(a0), w, a0); a1 = __builtin_fmaf(from_above<D>(a1), w, a1);
+        a2 = __builtin_fmaf(from_above<D>(a2), w, a2); a3 = __builtin_fmaf(from_above<D>(a3), w, a3);
+        a4 = __builtin_fmaf(from_above<D>(a4), w, a4); a5 = __builtin_fmaf(from_above<D>(a5), w, a5);
+#else
+        asm volatile("s_nop 1\n\t"
+                     "v_fmac_f32_dpp %0, %0, %6 row_shl:%7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_fmac_f32_dpp %1, %1, %6 row_shl:%7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_fmac_f32_dpp %2, %2, %6 row_shl:%7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_fmac_f32_dpp %3, %3, %6 row_shl:%7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_fmac_f32_dpp %4, %4, %6 row_shl:%7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_fmac_f32_dpp %5, %5, %6 row_shl:%7 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5)
+                     : "v"(w), "n"(D));
+#endif
+    }
     // this wave's earlier LDS stores are visible to its later LDS loads (DS operations of a wave execute in order)
     __device__ __forceinline__ void lds_fence() { dsim_wave_sync(); }
     __device__ __forceinline__ void sync() {
@@ -249,6 +278,32 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
             fh((int)threadIdx.x);
             sync();
         }
+    }
+    // fh is a side block whose RESULTS fm needs part-way through: fm calls side_done() exactly once, at the point from which it
+    // reads what fh wrote (the row-tree body level: the link lanes pick up the per-body contact sums after the first third of
+    // their work).  With a helper: the helper runs fh and arrives at the barrier that side_done() is for the main wave; no barrier
+    // before (fh must read nothing the main wave wrote since the last barrier both waves took) and none after (the helper is
+    // idle until the next fork).  Without: fh, then fm.
+    template <class FM, class FH> __device__ __forceinline__ void fork_side(FM&& fm, FH&& fh) {
+        if constexpr (HELPER) {
+            if (helper_) {
+                fh(lane_());
+                group_barrier();
+            } else {
+                fm(lane_());
+            }
+            asm volatile("" ::: "memory");
+            stamp();
+        } else {
+            fh((int)threadIdx.x);
+            dsim_wave_sync();
+            fm((int)threadIdx.x);
+            sync();
+        }
+    }
+    __device__ __forceinline__ void side_done() {
+        if constexpr (HELPER) group_barrier();
+        else dsim_wave_sync();
     }
     // phase that only writes global memory nobody in this launch reads back: no vmcnt wait.  One wave: no barrier either
     // (its LDS reads precede, in program order, whatever the next phase stores); several waves: the LDS words it reads
@@ -501,6 +556,23 @@ template <int NW> struct TimingExec {
     }
     template <class FM, class FH> __device__ __forceinline__ void fork_join_mid(FM&& fm, FH&& fh) { fork_join(fm, fh); }
     template <class FM, class FH> __device__ __forceinline__ void fork_mid_detached(FM&& fm, FH&& fh) { fork_join(fm, fh); }
+    template <class FM, class FH> __device__ __forceinline__ void fork_side(FM&& fm, FH&& fh) {
+        run([&](int lane) {
+            fh(lane);
+            __syncthreads();
+            fm(lane);
+        });
+    }
+    __device__ __forceinline__ void side_done() { __syncthreads(); }
+    template <int D> __device__ __forceinline__ float from_above(float v) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + D, 0xf, 0xf, true));
+    }
+    template <int D>
+    __device__ __forceinline__ void add_from_above(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
+        a0 = __builtin_fmaf(from_above<D>(a0), w, a0); a1 = __builtin_fmaf(from_above<D>(a1), w, a1);
+        a2 = __builtin_fmaf(from_above<D>(a2), w, a2); a3 = __builtin_fmaf(from_above<D>(a3), w, a3);
+        a4 = __builtin_fmaf(from_above<D>(a4), w, a4); a5 = __builtin_fmaf(from_above<D>(a5), w, a5);
+    }
     __device__ __forceinline__ void mid() { __syncthreads(); }
     __device__ __forceinline__ void stamp() {}
     DsimImage<NW, 0> img_;

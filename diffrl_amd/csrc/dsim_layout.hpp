@@ -20,6 +20,7 @@
 #define DSIM_LIGHT_CAP 8    // register budget of the light sums: LCAP, CCAP <= this
 #define DSIM_MUSCLE_CHUNK 12
 #define DSIM_TAIL_PAD 384
+#define DSIM_RT_MAX 12      // steps of a row-tree sum (DsimDims::RT_N)
 struct DsimDims {
     int L, nq, nd, C, M, W, NS, D;  // links, coords, dofs, contacts, muscles, waypoints, active muscle segments, tree levels
     int flags;                      // DSIM_F_*
@@ -38,6 +39,13 @@ struct DsimDims {
     int tr_d0[DSIM_TRUNK_MAX], tr_nd[DSIM_TRUNK_MAX];    // its own dofs [d0, d0 + nd)
     int MK;                                        // chunks of the per-body muscle-row gather (DsimOff::mc_row)
     int pident;                                    // bit p set: every joint at chain position p has an identity X_pj ROTATION
+    // Row-tree sums (RT_N == 0: none; dsim_core.hpp: dsim_rowtree_sum).  A tree of at most 16 links sits in ONE 16-lane DPP row
+    // of the wavefront (link i on lane i), so a subtree sum over per-link values held in REGISTERS is a handful of row shifts:
+    // bottom-up by levels, one step per distinct distance d = child - parent among the links of a level -- every parent adds
+    // the (finished) total of its child d lanes above, weighted 1 / 0.  rt_lvl[s] / rt_d[s]: level of the children and distance
+    // of step s, deepest level first.  CBMAX: most contacts on one body (the per-body contact gather that feeds those sums).
+    int RT_N, CBMAX;
+    int rt_lvl[DSIM_RT_MAX], rt_d[DSIM_RT_MAX];
 };
 #define DSIM_TM(t) (1 << (t))
 #define DSIM_F_RANGES 1  // subtree(i) == links [i, i+n_i) and its contacts == one contiguous contact range (pre-order numbering)
@@ -432,6 +440,27 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     }
     dd.L = L; dd.nq = nq; dd.nd = nd; dd.C = C; dd.M = M; dd.W = W; dd.NS = NS; dd.D = D;
     dd.flags = ranges ? DSIM_F_RANGES : 0;
+    for (int i = 0; i < L; ++i)
+        if ((int)cb[i].size() > dd.CBMAX) dd.CBMAX = (int)cb[i].size();
+    if (L <= 16 && ranges && M == 0) {
+        // steps of the row-tree sums: levels deepest first, distances ascending within a level
+        int n = 0;
+        bool ok = true;
+        for (int lv = D - 1; lv >= 1 && ok; --lv)
+            for (int dist = 1; dist < 16 && ok; ++dist) {
+                bool any = false;
+                for (int i = 0; i < L; ++i) any = any || (level[i] == lv && i - m.joint_parent[i] == dist);
+                if (!any) continue;
+                if (n == DSIM_RT_MAX) { ok = false; break; }
+                dd.rt_lvl[n] = lv;
+                dd.rt_d[n] = dist;
+                ++n;
+            }
+        for (int i = 1; i < L; ++i) ok = ok && m.joint_parent[i] >= 0;   // one tree
+        dd.RT_N = (ok && L > 1) ? n : 0;
+        if (!dd.RT_N)
+            for (int k = 0; k < DSIM_RT_MAX; ++k) dd.rt_lvl[k] = dd.rt_d[k] = 0;
+    }
     for (int i = 0; i < L; ++i) {
         dd.tmask |= DSIM_TM(m.joint_type[i]);
         for (size_t p = 0; p < anc[i].size() && p < DSIM_PMASK_N; ++p) dd.pmask[p] |= DSIM_TM(m.joint_type[anc[i][p]]);

@@ -81,6 +81,18 @@ template <int NW> struct HostExecT {
         return slot_[p][src & (NL - 1)];
     }
     float bcast(float v, int src) { return shfl(v, src); }
+    // DPP row shift of the device executor: lane + D of the same 16-lane row, 0 beyond the row's end
+    template <int D> float from_above(float v) {
+        const int lane = cur_, src = lane + D;
+        const float r = shfl(v, src < NL ? src : lane);
+        return (src < NL && (src >> 4) == (lane >> 4)) ? r : 0.f;
+    }
+    template <int D> void add_from_above(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
+        const float y0 = from_above<D>(a0), y1 = from_above<D>(a1), y2 = from_above<D>(a2), y3 = from_above<D>(a3),
+                    y4 = from_above<D>(a4), y5 = from_above<D>(a5);
+        a0 = __builtin_fmaf(y0, w, a0); a1 = __builtin_fmaf(y1, w, a1); a2 = __builtin_fmaf(y2, w, a2);
+        a3 = __builtin_fmaf(y3, w, a3); a4 = __builtin_fmaf(y4, w, a4); a5 = __builtin_fmaf(y5, w, a5);
+    }
     void lds_fence() { arrive(); }
     template <class F> void fire(F&& f) { run(f); }
     // the helper wavefront of the device executor (dsim_hip.hip) does not exist here: both blocks of a split phase run in
@@ -97,6 +109,15 @@ template <int NW> struct HostExecT {
     template <class FM, class FH> void fork_join_mid(FM&& fm, FH&& fh) { fork_join(fm, fh); }
     template <class FM, class FH> void fork_mid_detached(FM&& fm, FH&& fh) { fork_join(fm, fh); }
     void mid() { arrive(); }
+    // side block first, then the main block, whose side_done() is a point every lane passes (device: the helper's barrier)
+    template <class FM, class FH> void fork_side(FM&& fm, FH&& fh) {
+        run([&](int lane) {
+            fh(lane);
+            arrive();
+            fm(lane);
+        });
+    }
+    void side_done() { arrive(); }
     void stamp() {}
     // host form of the register / v_readlane Gauss-Jordan of the kernels (dsim_hip.hip: dsim_wave_gj): same formulas
     template <int N> void wave_gj(float* H) {

@@ -60,23 +60,9 @@ def _c(a):
 
 
 def layout(t):
-    desc, keep = make_desc(t)
-    names = _off_names()
-    off = np.zeros(len(names) + 8, np.int32)
-    dims = np.zeros(128, np.int32)
-    n = layout_lib().dsim_emu_layout(C.byref(desc), _p(off), C.c_int(off.size), _p(dims))
-    assert n == len(names), (n, len(names))
-    d = dict(zip("L nq nd C M W NS D flags tmask".split(), dims.tolist()))
-    d["pmask"] = dims[10:20].tolist()
-    # trunk decomposition (DsimDims behind pmask, struct order)
-    pos = 20
-    for name, cnt in [("NT", 0), ("NLT", 0), ("LCAP", 0), ("CCAP", 0), ("trunk", 6), ("tr_par", 6), ("tr_nch", 6), ("tr_ch", 24),
-                      ("tr_cb0", 6), ("tr_ncb", 6), ("tr_d0", 6), ("tr_nd", 6), ("MK", 0), ("pident", 0)]:
-        if cnt == 0:
-            d[name] = int(dims[pos]); pos += 1
-        else:
-            d[name] = dims[pos:pos + cnt].tolist(); pos += cnt
-    return dict(zip(names, off[:n].tolist())), d
+    """(offsets, dims) of template t from the library's layout builder (the product's host-only build of it)"""
+    from diffrl_amd import specialise
+    return specialise.layout(t)
 
 
 SCAN_MIN_DEPTH = 5   # dsim_core.hpp: DSIM_SCAN_MIN_DEPTH
@@ -88,7 +74,8 @@ def reorders(t):
     kinematics of deep trees (dsim_fwd_kinematics_scan).  Such pairs agree to a tolerance, all others bit for bit."""
     d = layout(t)[1]
     scan = d["D"] >= SCAN_MIN_DEPTH and d["L"] <= 64 and d["nd"] <= 64 and d["C"] <= 64 and d["NS"] <= 64
-    return d["NT"] > 0 or scan
+    rowtree = d["RT_N"] > 0 and not (d["tmask"] & (1 << 2))   # dsim_core.hpp: DsimRowTree (subtree sums by DPP row shifts)
+    return d["NT"] > 0 or scan or rowtree
 
 
 def substep_image(t, q, qd, act, mact, h):
