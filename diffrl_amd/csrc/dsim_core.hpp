@@ -241,6 +241,7 @@ struct DsimTopoRegs {
     // first word of the body's first contact row for that component (an in-range word where the body has none), contact count
     // (selects, not 1 / 0 weight registers: the records live in registers for the whole launch, of BOTH waves)
     int gx_row[DSIM_GX_PASSES], gx_n[DSIM_GX_PASSES];
+    int gf_row[2], gf_n[2];                  // the same for the forward pass's contact wrench rows (6 components per item, 6 L <= 96 items)
 };
 
 // Row-tree form of the body-level adjoint (dsim_bwd_bodies_rowtree): specialised one-wave kernels of trees that fit one 16-lane
@@ -457,7 +458,7 @@ template <bool ADJ = true, class Ctx, class Exec> DSIM_FN void dsim_topo_init(co
         tp.dof_cs = CI(qstart)[l];
         tp.dof_ds = CI(qdstart)[l];
     }
-    if constexpr (ADJ && DsimRowTree<Ctx, Exec>::value) {
+    if constexpr (DsimRowTree<Ctx, Exec>::value) {
         using D = decltype(c.d);
         DsimTopoRegs& tp = ex.topo(lane);
         // link `lane` has a child rt_d[s] lanes above iff that link's parent is `lane` (its level is then rt_lvl[s] or the step
@@ -474,8 +475,16 @@ template <bool ADJ = true, class Ctx, class Exec> DSIM_FN void dsim_topo_init(co
             tp.rt_w[s_] = (lane + D::rt_d[s_] < D::L && pr[s_] == lane && lv[s_] == D::rt_lvl[s_]) ? 1.f : 0.f;
             DSIM_OPAQUE(tp.rt_w[s_]);
         });
-        constexpr int GXP = (12 * D::L + Exec::NL - 1) / Exec::NL;
-        static_assert(GXP <= DSIM_GX_PASSES, "per-body gather passes");
+        constexpr int GXP = ADJ ? (12 * D::L + Exec::NL - 1) / Exec::NL : 0, GFP = (6 * D::L + Exec::NL - 1) / Exec::NL;
+        static_assert(GXP <= DSIM_GX_PASSES && GFP <= 2, "per-body gather passes");
+#pragma unroll
+        for (int p = 0; p < GFP; ++p) {
+            const int it = lane + Exec::NL * p, li = it < 6 * D::L ? it / 6 : 0, r = it < 6 * D::L ? it - 6 * li : 0;
+            const int b0 = CI(cb_start)[li], n = it < 6 * D::L ? CI(cb_start)[li + 1] - b0 : 0;
+            const int first = (n > 0 && D::C > 0) ? CI(cb_list)[b0] : 0;
+            tp.gf_row[p] = 6 * first + r;
+            tp.gf_n[p] = n;
+        }
 #pragma unroll
         for (int p = 0; p < GXP; ++p) {
             const int it = lane + Exec::NL * p, li = it < 12 * D::L ? it / 12 : 0, r = it < 12 * D::L ? it - 12 * li : 0;
@@ -789,6 +798,33 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_contacts(const Ctx& c, Ex
     }
 }
 
+// Row-tree models: the contact wrenches of a body summed per body right behind their evaluation (same lanes, same wave: the side
+// block of the kinematics phase), so that the dynamics phase finds ONE row per link and sums subtrees on registers
+// (dsim_fwd_ftot_rowtree) instead of walking 9 + 25 rows per (link, component) lane.
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_contacts_per_body(const Ctx& c, Exec& ex, int lane) {
+    if constexpr (DsimRowTree<Ctx, Exec>::value) {
+        using D = decltype(c.d);
+        ex.lds_fence();
+        const DsimTopoRegs& tp = ex.topo(lane);
+        constexpr int GFP = (6 * D::L + Exec::NL - 1) / Exec::NL, CB = D::CBMAX > 0 ? D::CBMAX : 1;
+        float x[GFP][CB];
+#pragma unroll
+        for (int p = 0; p < GFP; ++p)
+#pragma unroll
+            for (int e = 0; e < CB; ++e) x[p][e] = WF(cw)[tp.gf_row[p] + 6 * e];
+#pragma unroll
+        for (int p = 0; p < GFP; ++p) {
+            float acc = 0.f;
+            int n = tp.gf_n[p];
+            DSIM_OPAQUE(n);
+#pragma unroll
+            for (int e = 0; e < CB; ++e) acc += (e < n) ? x[p][e] : 0.f;
+            const int it = lane + Exec::NL * p;
+            if (it < 6 * D::L) WF(cwb)[it] = acc;
+        }
+    }
+}
+
 // Log-depth forward kinematics (DsimScanFk).  One lane per link, every lane executes every step (lanes past the last link
 // compute on link 0's inputs and store nothing): the rounds exchange their operands between lanes with ds_bpermute (Exec::shfl),
 // which needs uniform control flow, and the results go to LDS once -- poses, twists and bias accelerations as they become final:
@@ -967,6 +1003,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_scan(const Ctx
         }
     }, [&](int lane) {
         dsim_fwd_contacts(c, ex, lane);
+        dsim_fwd_contacts_per_body(c, ex, lane);
         if (g_row) dsim_ckpt_store_row<Ctx, Exec::NL, 1>(c, lane, g_row);   // head of the checkpoint row: (q, qd) entering the substep
     });
 }
@@ -1049,6 +1086,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_walk_mid(const
         }
     }, [&](int lane) {
         dsim_fwd_contacts(c, ex, lane);
+        dsim_fwd_contacts_per_body(c, ex, lane);
         if (g_row) dsim_ckpt_store_row<Ctx, Exec::NL, 1>(c, lane, g_row);   // head of the checkpoint row: (q, qd) entering the substep
     });
 }
@@ -1199,7 +1237,10 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Ex
                             DsimContactsAfterWalk<Ctx, Exec::NL>::value;  // contacts were done by the kinematics phase
     if ((c.d.C == 0 || in_kin) && c.d.NS == 0) return;
     ex.run([&](int lane) {
-        if constexpr (!in_kin) dsim_fwd_contacts(c, ex, lane);
+        if constexpr (!in_kin) {
+            dsim_fwd_contacts(c, ex, lane);
+            dsim_fwd_contacts_per_body(c, ex, lane);
+        }
         for (int s = lane; s < c.d.NS; s += Exec::NL) {
             const int w = CI(seg_wp)[s];
             const int l0 = CI(mlinks)[w], l1 = CI(mlinks)[w + 1];
@@ -1378,10 +1419,50 @@ DSIM_FN void dsim_trunk_sum(const Ctx& c, Exec& ex, int lane, const float* ldata
     ex.lds_fence();
 }
 
+// Subtree sums of a per-link 6-vector held in REGISTERS (link i on lane i, the whole tree in one 16-lane DPP row): bottom-up by
+// levels; in step s every parent adds the finished total of its child rt_d[s] lanes above (Exec::from_above: a DPP row shift --
+// VALU latency, no LDS), weighted 1 / 0.  Replaces an LDS store, a phase, ~34 loads + ~34 multiply-adds on (link, component)
+// lanes and the load of the result in the next phase.  Lanes that hold no link must carry zeros.  Same terms as the range sums,
+// associated by tree level instead of by index: not bit-identical to them (the tests hold both to the reference).
+template <class Ctx, class Exec> DSIM_FN void dsim_rowtree_sum(const Ctx&, Exec& ex, const DsimTopoRegs& tp, sv6& x) {
+    using D = decltype(Ctx::d);
+    dsim_static_for<0, D::RT_N>([&](auto ss) {
+        constexpr int s_ = decltype(ss)::value, dist = D::rt_d[s_];
+        ex.template add_from_above<dist, s_ == 0>(x.w.x, x.w.y, x.w.z, x.v.x, x.v.y, x.v.z, tp.rt_w[s_]);   // x_k += x_k[lane + dist] * w
+    });
+}
+
+// value that lane `lane - SH` of the row holds (SH = 0: the lane's own): link -> dof lane of a row tree is SH = DSH, dof -> link -DSH
+template <int SH, class Exec> DSIM_FN float dsim_row_shift(Exec& ex, float v) {
+    if constexpr (SH > 0) return ex.template from_below<SH>(v);
+    else if constexpr (SH < 0) return ex.template from_above<-SH>(v);
+    else return v;
+}
+template <class Ctx, class Exec> struct DsimDofShift {
+    static constexpr bool value = []() {
+        if constexpr (DsimRowTree<Ctx, Exec>::value) return decltype(Ctx::d)::DSH_OK != 0;
+        else return false;
+    }();
+};
+// f_tot of link `lane` for row-tree models, on the link lanes: own body force + the body's contact wrenches (summed per body by the
+// kinematics phase's side block), then the row-tree subtree sum.  Every lane of the wave calls it (DPP needs uniform control flow).
+template <class Ctx, class Exec> DSIM_FN sv6 dsim_fwd_ftot_rowtree(const Ctx& c, Exec& ex, int lane) {
+    using D = decltype(c.d);
+    const int i = lane < D::L ? lane : 0;
+    sv6 x = ldsv(WF(f) + 6 * i) + ldsv(WF(cwb) + 6 * i);   // (lanes without a link: link 0's values, which no step's weight selects)
+    dsim_rowtree_sum(c, ex, ex.topo(lane), x);
+    return x;
+}
+
 // f_tot[i] = sum over subtree(i) of (inverse-dynamics force [+ muscle wrenches, gathered per body]) + contact wrenches
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_ftot(const Ctx& c, Exec& ex) {
     ex.mark(3);
     ex.run([&](int lane) {
+        if constexpr (DsimRowTree<Ctx, Exec>::value) {
+            const sv6 t = dsim_fwd_ftot_rowtree(c, ex, lane);
+            if (lane < c.d.L) stsv(WF(ftot) + 6 * lane, t);
+            return;
+        }
         if constexpr (DsimTrunk<Ctx, Exec>::value) {
             dsim_trunk_sum<true>(c, ex, lane, WF(f), WF(cw), 6, 0, WF(ftot));
             return;
@@ -1654,7 +1735,26 @@ DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float*
 #pragma unroll
         for (int k = 0; k < NDF; ++k) qdv[k] = WF(qd)[lds_ + k];
         sv6 F;
-        if constexpr (DsimWaveDyn<Ctx, Exec>::sums_inside) {
+        if constexpr (DsimRowTree<Ctx, Exec>::value && DsimWaveDyn<Ctx, Exec>::sums_inside) {
+            // ---- link role: f_tot = row-tree subtree sums on registers; f_tot[link(d)] -> dof lane d
+            const sv6 ftl = dsim_fwd_ftot_rowtree(c, ex, lane);
+            if (is_link) stsv(WF(ftot) + 6 * lane, ftl);   // the adjoint reads it from the checkpoint
+            ex.stamp();
+            if constexpr (DsimDofShift<Ctx, Exec>::value) {
+                // one row shift instead of six ds_bpermute round trips: dof lane d holds link d - DSH's total; the root's dofs
+                // take lane 0's by v_readlane
+                F.w.x = dsim_row_shift<D::DSH>(ex, ftl.w.x); F.w.y = dsim_row_shift<D::DSH>(ex, ftl.w.y); F.w.z = dsim_row_shift<D::DSH>(ex, ftl.w.z);
+                F.v.x = dsim_row_shift<D::DSH>(ex, ftl.v.x); F.v.y = dsim_row_shift<D::DSH>(ex, ftl.v.y); F.v.z = dsim_row_shift<D::DSH>(ex, ftl.v.z);
+                if constexpr (D::ND_ROOT > 0) {
+                    const sv6 Fr = mksv(mk3(ex.bcast(ftl.w.x, 0), ex.bcast(ftl.w.y, 0), ex.bcast(ftl.w.z, 0)),
+                                        mk3(ex.bcast(ftl.v.x, 0), ex.bcast(ftl.v.y, 0), ex.bcast(ftl.v.z, 0)));
+                    if (lane < D::ND_ROOT) F = Fr;
+                }
+            } else {
+                F.w.x = ex.shfl(ftl.w.x, di); F.w.y = ex.shfl(ftl.w.y, di); F.w.z = ex.shfl(ftl.w.z, di);
+                F.v.x = ex.shfl(ftl.v.x, di); F.v.y = ex.shfl(ftl.v.y, di); F.v.z = ex.shfl(ftl.v.z, di);
+            }
+        } else if constexpr (DsimWaveDyn<Ctx, Exec>::sums_inside) {
             // ---- (link, component) role: f_tot = subtree sums of the body forces and contact wrenches
             float ft = 0.f;
             if (lane < 6 * L) {
@@ -1689,8 +1789,16 @@ DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float*
         ex.stamp();
         // ---- qdd of a link's dofs -> the link's lane
         float av[NDF > 0 ? NDF : 1];
+        if constexpr (DsimDofShift<Ctx, Exec>::value) {
+            // link lane l <- dof lane l + DSH (its one dof); the root <- its ND_ROOT dofs on lanes 0 .. ND_ROOT - 1 (v_readlane)
 #pragma unroll
-        for (int k = 0; k < NDF; ++k) av[k] = ex.shfl(acc, lds_ + k);
+            for (int k = 0; k < NDF; ++k) av[k] = (k < D::ND_ROOT) ? ex.bcast(acc, k < D::ND_ROOT ? k : 0) : 0.f;
+            const float own = dsim_row_shift<-D::DSH>(ex, acc);
+            if (lane > 0 || D::ND_ROOT == 0) av[0] = own;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NDF; ++k) av[k] = ex.shfl(acc, lds_ + k);
+        }
         // ---- link role: semi-implicit Euler (sim.py:1505-1636).  The arithmetic comes first -- the inverse norm of the root's
         // quaternion update belongs to the saved block (DsimSavedIl) -- then the hand-over of the checkpoint copy, then the stores
         float qdn = 0.f, qn = 0.f;
@@ -2630,19 +2738,6 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
     });
 }
 
-// Subtree sums of a per-link 6-vector held in REGISTERS (link i on lane i, the whole tree in one 16-lane DPP row): bottom-up by
-// levels; in step s every parent adds the finished total of its child rt_d[s] lanes above (Exec::from_above: a DPP row shift --
-// VALU latency, no LDS), weighted 1 / 0.  Replaces an LDS store, a phase, ~34 loads + ~34 multiply-adds on (link, component)
-// lanes and the load of the result in the next phase.  Lanes that hold no link must carry zeros.  Same terms as the range sums,
-// associated by tree level instead of by index: not bit-identical to them (the tests hold both to the reference).
-template <class Ctx, class Exec> DSIM_FN void dsim_rowtree_sum(const Ctx&, Exec& ex, const DsimTopoRegs& tp, sv6& x) {
-    using D = decltype(Ctx::d);
-    dsim_static_for<0, D::RT_N>([&](auto ss) {
-        constexpr int s_ = decltype(ss)::value, dist = D::rt_d[s_];
-        ex.template add_from_above<dist>(x.w.x, x.w.y, x.w.z, x.v.x, x.v.y, x.v.z, tp.rt_w[s_]);   // x_k += x_k[lane + dist] * w
-    });
-}
-
 // Body level of the adjoint substep for row trees (DsimRowTree): ONE phase on the link lanes.  dsim_bwd_bodies below is the
 // general form -- per-link block, subtree sum, per-link block, subtree sum, per-link block, subtree sum, per-link block: seven
 // phases, each paying an LDS round trip for values that only change lanes inside the tree.  Here the three subtree sums are
@@ -2664,12 +2759,12 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
         const int cs = tp.own_cs, ds = tp.own_ds, par = tp.own_parent;
         const bool hinge = type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE, fr = type == DSIM_JOINT_FREE;
         // ---- every operand that does not come out of this phase, in one round trip
-        const inertia10 I = ld_i10(WF(i10) + 10 * i);
-        const sv6 v = ldsv(WF(v) + 6 * i), a = ldsv(WF(a) + 6 * i), r = ldsv(WF(af) + 6 * i);
+        inertia10 I = ld_i10(WF(i10) + 10 * i);
+        sv6 v = ldsv(WF(v) + 6 * i), a = ldsv(WF(a) + 6 * i), r = ldsv(WF(af) + 6 * i);
         const v3 grav = ld3(CF(grav));
         float g[10];
         for (int k = 0; k < 10; ++k) g[k] = update_mass ? WF(ai10m)[10 * i + k] : 0.f;
-        const sv6 S0 = ldsv(WF(S) + 6 * ds), aS0 = ldsv(WF(aS) + 6 * ds);
+        sv6 S0 = ldsv(WF(S) + 6 * ds), aS0 = ldsv(WF(aS) + 6 * ds);
         float* aq = WF(aq);
         float* aqd = WF(aqd);
         const float qd0 = WF(qd)[ds], g0 = aqd[ds], gq0 = aq[cs];
@@ -2684,6 +2779,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
             gp = mk3(gq0, aq[cs + 1], aq[cs + 2]);
             gr = ldq(aq + cs + 3);
         }
+        ex.loads_landed();
         // ---- f^T, velocity / acceleration recursions^T of the link itself, pose wrench of inertia + gravity (dsim_bwd_bodies)
         const sv6 hv = inertia_mul(I, v);
         sv6 a_v, a_hv;
@@ -2702,7 +2798,12 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
         W.w += cross(I.h, rg);
         W.v += rg * I.m;
         sv6 A = inertia_mul(I, r);   // aa
-        if (!on) {                   // lanes without a link computed on link 0's operands: they must add nothing to the sums
+        // Lanes without a link computed on link 0's operands: finite values that no sum picks up (a step's weight is 1 only where
+        // lane + distance is a child, i.e. a link).  They are zeroed all the same: measured (tools/ab_min.py, Ant 1024, same box,
+        // alternating runs) the adjoint launch takes 0.0538 ms with these 18 selects and 0.0586 ms without them -- 25 instructions
+        // more and 8 % faster; zeroing the lanes' OPERANDS instead changes nothing (0.0582 ms), so it is what the selects do to
+        // the compiler's schedule of the block, not the data.  Kept as measured.
+        if (!on) {
             A = zerosv();
             a_v = zerosv();
             W = zerosv();
@@ -2722,19 +2823,15 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
         ex.stamp();
         // ---- the contact terms of the own body, reduced by the side block
         ex.side_done();
-        sv6 cpose = ldsv(WF(agx) + 12 * i), ctw = ldsv(WF(agx) + 12 * i + 6);
-        if (!on) {
-            cpose = zerosv();
-            ctw = zerosv();
-            a_vj = zerosv();
-        }
+        const sv6 cpose = ldsv(WF(agx) + 12 * i), ctw = ldsv(WF(agx) + 12 * i + 6);
+        ex.loads_landed();
         // ---- avtot = subtree sum of (a_v + contact twist cotangents); cotangents of qd and of S; S is attached to the joint frame
         sv6 T = a_v + ctw;
         dsim_rowtree_sum(c, ex, tp, T);
         a_vj += T;
         sv6 Wp = zerosv();
         float aqd_new = g0;
-        if (hinge && on) {
+        if (hinge) {
             Wp = scross_dual(S0, aS0 + a_vj * qd0);
             aqd_new = g0 + sdot(S0, a_vj);
         }

@@ -179,20 +179,27 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
         static_assert(D >= 1 && D <= 15, "row shifts reach 1 .. 15 lanes");
         return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + D, 0xf, 0xf, true));
     }
+    // ... and lane - D of the row (row_shr:D)
+    template <int D> __device__ __forceinline__ float from_below(float v) {
+        static_assert(D >= 1 && D <= 15, "row shifts reach 1 .. 15 lanes");
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + D, 0xf, 0xf, true));
+    }
     // a_k += a_k[lane + D of the row] * w for six values at once: v_fmac_f32 with the DPP shift ON ITS OPERAND (the compiler
     // keeps a v_mov_b32_dpp + v_fmac pair for the builtin form: twice the instructions on a path where every issue slot counts).
     // A VGPR written by a VALU instruction may be read through DPP two wait states later at the earliest: the six lines are
     // independent of each other, so only the first needs the s_nop, and a_k's own update is five instructions behind its read.
-    template <int D>
+    // FIRST: the six values may have been written by the instructions right before (the s_nop); later steps of a sum read what
+    // the previous step's block wrote five instructions earlier.
+    template <int D, bool FIRST = true>
     __device__ __forceinline__ void add_from_above(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
         static_assert(D >= 1 && D <= 15, "row shifts reach 1 .. 15 lanes");
+        if constexpr (FIRST) asm volatile("s_nop 1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5));
 #ifdef DSIM_NO_DPP_ASM   // (A/B builds: the builtin form)
         a0 = __builtin_fmaf(from_above<D>(a0), w, a0); a1 = __builtin_fmaf(from_above<D>(a1), w, a1);
         a2 = __builtin_fmaf(from_above<D>(a2), w, a2); a3 = __builtin_fmaf(from_above<D>(a3), w, a3);
         a4 = __builtin_fmaf(from_above<D>(a4), w, a4); a5 = __builtin_fmaf(from_above<D>(a5), w, a5);
 #else
-        asm volatile("s_nop 1\n\t"
-                     "v_fmac_f32_dpp %0, %0, %6 row_shl:%7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        asm volatile("v_fmac_f32_dpp %0, %0, %6 row_shl:%7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                      "v_fmac_f32_dpp %1, %1, %6 row_shl:%7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                      "v_fmac_f32_dpp %2, %2, %6 row_shl:%7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                      "v_fmac_f32_dpp %3, %3, %6 row_shl:%7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -200,6 +207,15 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
                      "v_fmac_f32_dpp %5, %5, %6 row_shl:%7 row_mask:0xf bank_mask:0xf bound_ctrl:1"
                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5)
                      : "v"(w), "n"(D));
+#endif
+    }
+    // every LDS load issued so far has landed: ONE s_waitcnt lgkmcnt(0) behind a batch of loads instead of the partial waits
+    // (lgkmcnt(n), n counting down) the compiler otherwise puts in front of each first use.  A lone wave pays a full issue slot
+    // (~4.6 cycles, tools/micro/issue_mix.hip) for every s_waitcnt, satisfied or not, while the loads of a batch return a few
+    // cycles apart: after the phase's load batch the one full wait is cheaper than a dozen partial ones.
+    __device__ __forceinline__ void loads_landed() {
+#ifndef DSIM_NO_FULL_WAIT   // (A/B builds)
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // vmcnt 63, expcnt 7, lgkmcnt 0
 #endif
     }
     // this wave's earlier LDS stores are visible to its later LDS loads (DS operations of a wave execute in order)
@@ -567,12 +583,16 @@ template <int NW> struct TimingExec {
     template <int D> __device__ __forceinline__ float from_above(float v) {
         return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + D, 0xf, 0xf, true));
     }
-    template <int D>
+    template <int D> __device__ __forceinline__ float from_below(float v) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + D, 0xf, 0xf, true));
+    }
+    template <int D, bool FIRST = true>
     __device__ __forceinline__ void add_from_above(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
         a0 = __builtin_fmaf(from_above<D>(a0), w, a0); a1 = __builtin_fmaf(from_above<D>(a1), w, a1);
         a2 = __builtin_fmaf(from_above<D>(a2), w, a2); a3 = __builtin_fmaf(from_above<D>(a3), w, a3);
         a4 = __builtin_fmaf(from_above<D>(a4), w, a4); a5 = __builtin_fmaf(from_above<D>(a5), w, a5);
     }
+    __device__ __forceinline__ void loads_landed() {}
     __device__ __forceinline__ void mid() { __syncthreads(); }
     __device__ __forceinline__ void stamp() {}
     DsimImage<NW, 0> img_;

@@ -46,6 +46,11 @@ struct DsimDims {
     // of step s, deepest level first.  CBMAX: most contacts on one body (the per-body contact gather that feeds those sums).
     int RT_N, CBMAX;
     int rt_lvl[DSIM_RT_MAX], rt_d[DSIM_RT_MAX];
+    // Link <-> dof lane shifts of a row tree (DSH_OK): every link but the root has exactly one dof and its index is the link's
+    // index + DSH (pre-order trees whose only multi-dof joint is the root: Ant 5, the planar models 0, cartpole -1); the root has
+    // ND_ROOT dofs 0 .. ND_ROOT - 1 (0: a fixed root).  A per-link value then reaches its dof's lane by ONE row shift (the root's
+    // by v_readlane from lane 0) instead of a ds_bpermute round trip, and back.
+    int DSH_OK, DSH, ND_ROOT;
 };
 #define DSIM_TM(t) (1 << (t))
 #define DSIM_F_RANGES 1  // subtree(i) == links [i, i+n_i) and its contacts == one contiguous contact range (pre-order numbering)
@@ -78,6 +83,7 @@ struct DsimOff {
     int const_words;
     // ---- forward work arrays (floats)
     int q, qd, act, mact, ua, obs, xsc, S, v, a, i10, f, ftot, cw, tau, qdd, ic10, F, hinv, prow, pcol, mus;
+    int cwb;                    // [L][6] contact wrenches summed per body (row-tree models: the side block of the kinematics phase)
     int mpart;                  // [MK][6] chunk sums of the muscle-row gather
     int epf;                    // episode flags (fused env surface): [0] invalid state seen, [1] episode finished
     int qil;                    // one spare word of qdd's 16-byte padding INSIDE the saved block (-1: none): 1 / |r + dr h| of the
@@ -406,7 +412,7 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.save_words = cur - o.q;
     o.act = take(nd); o.mact = take(M);
     o.ua = take(M > nd ? M : nd); o.obs = take(16 + nq + nd + (M > nd ? M : nd));
-    o.f = take(6 * L); o.cw = take(6 * C); o.tau = take(nd);
+    o.f = take(6 * L); o.cw = take(6 * C); o.cwb = take(6 * L); o.tau = take(nd);
     o.ic10 = take(10 * L); o.F = take(6 * nd); o.hinv = take(nd * nd); o.prow = take(nd); o.pcol = take(nd);
     o.mus = take(13 * NS);  // 2 NS wrench rows of 6 floats, sorted by body (seg_slot), + (adjoint) NS activation cotangents
     o.mpart = take(6 * MK);
@@ -460,6 +466,21 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
         dd.RT_N = (ok && L > 1) ? n : 0;
         if (!dd.RT_N)
             for (int k = 0; k < DSIM_RT_MAX; ++k) dd.rt_lvl[k] = dd.rt_d[k] = 0;
+        if (dd.RT_N && nd <= 16) {
+            bool sh = true;
+            const int ndr = m.joint_qd_start[1] - m.joint_qd_start[0];
+            int dsh = 0;
+            for (int i = 1; i < L; ++i) {
+                sh = sh && (m.joint_qd_start[i + 1] - m.joint_qd_start[i] == 1);
+                if (i == 1) dsh = m.joint_qd_start[i] - i;
+                sh = sh && (m.joint_qd_start[i] - i == dsh);
+            }
+            if (sh && dsh >= -15 && dsh <= 15) {
+                dd.DSH_OK = 1;
+                dd.DSH = dsh;
+                dd.ND_ROOT = ndr;
+            }
+        }
     }
     for (int i = 0; i < L; ++i) {
         dd.tmask |= DSIM_TM(m.joint_type[i]);

@@ -87,7 +87,13 @@ template <int NW> struct HostExecT {
         const float r = shfl(v, src < NL ? src : lane);
         return (src < NL && (src >> 4) == (lane >> 4)) ? r : 0.f;
     }
-    template <int D> void add_from_above(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
+    template <int D> float from_below(float v) {
+        const int lane = cur_, src = lane - D;
+        const float r = shfl(v, src >= 0 ? src : lane);
+        return (src >= 0 && (src >> 4) == (lane >> 4)) ? r : 0.f;
+    }
+    void loads_landed() {}
+    template <int D, bool FIRST = true> void add_from_above(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
         const float y0 = from_above<D>(a0), y1 = from_above<D>(a1), y2 = from_above<D>(a2), y3 = from_above<D>(a3),
                     y4 = from_above<D>(a4), y5 = from_above<D>(a5);
         a0 = __builtin_fmaf(y0, w, a0); a1 = __builtin_fmaf(y1, w, a1); a2 = __builtin_fmaf(y2, w, a2);

@@ -27,7 +27,7 @@ for env, N in CASES:
         b = eng.backward(ck, a, m, dt, S, mm, gq, gqd)
     torch.cuda.synchronize()
     e0, e1, e2 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    K = 20
+    K = 50
     e0.record()
     for _ in range(K):
         qo, qdo, ck = eng.forward(q, qd, a, m, dt, S, mm, True)
@@ -38,4 +38,4 @@ for env, N in CASES:
     tf, tb = e0.elapsed_time(e1) / K, e1.elapsed_time(e2) / K
     import hashlib
     hsh = hashlib.sha1(b"".join(x.detach().cpu().numpy().tobytes() for x in (qo, qdo) + tuple(y for y in b if y is not None))).hexdigest()[:10]
-    print("%-9s N=%5d S=%2d  fwd %.3f ms  bwd %.3f ms  -> %.3e env-steps/s (kernels only)  outputs sha1 %s" % (env, N, S, tf, tb, N / ((tf + tb) * 1e-3), hsh))
+    print("%-9s N=%5d S=%2d  fwd %.4f ms  bwd %.4f ms  -> %.3e env-steps/s (kernels only)  outputs sha1 %s" % (env, N, S, tf, tb, N / ((tf + tb) * 1e-3), hsh))
