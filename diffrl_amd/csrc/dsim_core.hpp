@@ -218,7 +218,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_init_static(const Ctx& c, Exe
 // index records of those roles never change, so they are read from the LDS tables once per launch (dsim_topo_init)
 // instead of being the first of two or three DEPENDENT LDS round trips of a phase in every substep.  Fields a kernel
 // does not use cost nothing (dead registers).
-#define DSIM_GX_PASSES 3   // 12 L <= 192 items over 64 lanes
+#define DSIM_GX_PASSES 6   // 12 L <= 384 items over 64 lanes
 #define DSIM_GX_CAP 12     // most contacts on one body the register form handles (DsimDims::CBMAX; more: the row-tree form is off)
 struct DsimTopoRegs {
     int chain[4 * DSIM_CHAIN_MAX + 1];       // ancestors of link `lane`, root first: (link, type, q start, qd start); [last] = length
@@ -241,7 +241,7 @@ struct DsimTopoRegs {
     // first word of the body's first contact row for that component (an in-range word where the body has none), contact count
     // (selects, not 1 / 0 weight registers: the records live in registers for the whole launch, of BOTH waves)
     int gx_row[DSIM_GX_PASSES], gx_n[DSIM_GX_PASSES];
-    int gf_row[2], gf_n[2];                  // the same for the forward pass's contact wrench rows (6 components per item, 6 L <= 96 items)
+    int gf_row[3], gf_n[3];                  // the same for the forward pass's contact wrench rows (6 components per item, 6 L <= 192 items)
 };
 
 // Row-tree form of the body-level adjoint (dsim_bwd_bodies_rowtree): specialised one-wave kernels of trees that fit one 16-lane
@@ -466,17 +466,20 @@ template <bool ADJ = true, class Ctx, class Exec> DSIM_FN void dsim_topo_init(co
         int pr[D::RT_N], lv[D::RT_N];
         dsim_static_for<0, D::RT_N>([&](auto ss) {
             constexpr int s_ = decltype(ss)::value;
-            const int ch = lane + D::rt_d[s_] < D::L ? lane + D::rt_d[s_] : 0;
+            const int ch = (D::rt_kind[s_] != DSIM_RT_FAR && lane + D::rt_d[s_] < D::L) ? lane + D::rt_d[s_] : 0;
             pr[s_] = CI(linfo)[8 * ch];
             lv[s_] = CI(linfo)[8 * ch + 4];
         });
         dsim_static_for<0, D::RT_N>([&](auto ss) {
             constexpr int s_ = decltype(ss)::value;
-            tp.rt_w[s_] = (lane + D::rt_d[s_] < D::L && pr[s_] == lane && lv[s_] == D::rt_lvl[s_]) ? 1.f : 0.f;
+            if constexpr (D::rt_kind[s_] == DSIM_RT_FAR)   // one edge: child lane rt_d -> parent lane rt_lvl
+                tp.rt_w[s_] = lane == D::rt_lvl[s_] ? 1.f : 0.f;
+            else
+                tp.rt_w[s_] = (lane + D::rt_d[s_] < D::L && pr[s_] == lane && lv[s_] == D::rt_lvl[s_]) ? 1.f : 0.f;
             DSIM_OPAQUE(tp.rt_w[s_]);
         });
         constexpr int GXP = ADJ ? (12 * D::L + Exec::NL - 1) / Exec::NL : 0, GFP = (6 * D::L + Exec::NL - 1) / Exec::NL;
-        static_assert(GXP <= DSIM_GX_PASSES && GFP <= 2, "per-body gather passes");
+        static_assert(GXP <= DSIM_GX_PASSES && GFP <= 3, "per-body gather passes");
 #pragma unroll
         for (int p = 0; p < GFP; ++p) {
             const int it = lane + Exec::NL * p, li = it < 6 * D::L ? it / 6 : 0, r = it < 6 * D::L ? it - 6 * li : 0;
@@ -1419,7 +1422,7 @@ DSIM_FN void dsim_trunk_sum(const Ctx& c, Exec& ex, int lane, const float* ldata
     ex.lds_fence();
 }
 
-// Subtree sums of a per-link 6-vector held in REGISTERS (link i on lane i, the whole tree in one 16-lane DPP row): bottom-up by
+// Subtree sums of a per-link 6-vector held in REGISTERS (link i on lane i, the tree on the first lanes of the wave): bottom-up by
 // levels; in step s every parent adds the finished total of its child rt_d[s] lanes above (Exec::from_above: a DPP row shift --
 // VALU latency, no LDS), weighted 1 / 0.  Replaces an LDS store, a phase, ~34 loads + ~34 multiply-adds on (link, component)
 // lanes and the load of the result in the next phase.  Lanes that hold no link must carry zeros.  Same terms as the range sums,
@@ -1427,8 +1430,14 @@ DSIM_FN void dsim_trunk_sum(const Ctx& c, Exec& ex, int lane, const float* ldata
 template <class Ctx, class Exec> DSIM_FN void dsim_rowtree_sum(const Ctx&, Exec& ex, const DsimTopoRegs& tp, sv6& x) {
     using D = decltype(Ctx::d);
     dsim_static_for<0, D::RT_N>([&](auto ss) {
-        constexpr int s_ = decltype(ss)::value, dist = D::rt_d[s_];
-        ex.template add_from_above<dist, s_ == 0>(x.w.x, x.w.y, x.w.z, x.v.x, x.v.y, x.v.z, tp.rt_w[s_]);   // x_k += x_k[lane + dist] * w
+        constexpr int s_ = decltype(ss)::value, dist = D::rt_d[s_], kind = D::rt_kind[s_];
+        // x_k += x_k[source lane] * w: a row shift, the whole-wave shift by one lane, or one far edge by v_readlane
+        if constexpr (kind == DSIM_RT_ROW)
+            ex.template add_from_above<dist, s_ == 0>(x.w.x, x.w.y, x.w.z, x.v.x, x.v.y, x.v.z, tp.rt_w[s_]);
+        else if constexpr (kind == DSIM_RT_WAVE1)
+            ex.template add_from_next<s_ == 0>(x.w.x, x.w.y, x.w.z, x.v.x, x.v.y, x.v.z, tp.rt_w[s_]);
+        else
+            ex.template add_from_lane<dist>(x.w.x, x.w.y, x.w.z, x.v.x, x.v.y, x.v.z, tp.rt_w[s_]);
     });
 }
 

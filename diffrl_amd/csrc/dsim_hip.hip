@@ -218,6 +218,26 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
         __builtin_amdgcn_s_waitcnt(0xC07F);   // vmcnt 63, expcnt 7, lgkmcnt 0
 #endif
     }
+    // the same from the NEXT lane of the wave (wave_shl:1: crosses the 16-lane row boundaries; 0 into lane 63)
+    template <bool FIRST = true>
+    __device__ __forceinline__ void add_from_next(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
+        if constexpr (FIRST) asm volatile("s_nop 1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5));
+        asm volatile("v_fmac_f32_dpp %0, %0, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_fmac_f32_dpp %1, %1, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_fmac_f32_dpp %2, %2, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_fmac_f32_dpp %3, %3, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_fmac_f32_dpp %4, %4, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "v_fmac_f32_dpp %5, %5, %6 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5)
+                     : "v"(w));
+    }
+    // ... and from ONE given lane SRC (an edge of the tree that no shift reaches): v_readlane into an SGPR, weighted add
+    template <int SRC>
+    __device__ __forceinline__ void add_from_lane(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
+        const float s0 = bcast(a0, SRC), s1 = bcast(a1, SRC), s2 = bcast(a2, SRC), s3 = bcast(a3, SRC), s4 = bcast(a4, SRC), s5 = bcast(a5, SRC);
+        a0 = __builtin_fmaf(s0, w, a0); a1 = __builtin_fmaf(s1, w, a1); a2 = __builtin_fmaf(s2, w, a2);
+        a3 = __builtin_fmaf(s3, w, a3); a4 = __builtin_fmaf(s4, w, a4); a5 = __builtin_fmaf(s5, w, a5);
+    }
     // this wave's earlier LDS stores are visible to its later LDS loads (DS operations of a wave execute in order)
     __device__ __forceinline__ void lds_fence() { dsim_wave_sync(); }
     __device__ __forceinline__ void sync() {
@@ -591,6 +611,18 @@ template <int NW> struct TimingExec {
         a0 = __builtin_fmaf(from_above<D>(a0), w, a0); a1 = __builtin_fmaf(from_above<D>(a1), w, a1);
         a2 = __builtin_fmaf(from_above<D>(a2), w, a2); a3 = __builtin_fmaf(from_above<D>(a3), w, a3);
         a4 = __builtin_fmaf(from_above<D>(a4), w, a4); a5 = __builtin_fmaf(from_above<D>(a5), w, a5);
+    }
+    template <bool FIRST = true>
+    __device__ __forceinline__ void add_from_next(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
+        auto nx = [](float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true)); };
+        a0 = __builtin_fmaf(nx(a0), w, a0); a1 = __builtin_fmaf(nx(a1), w, a1); a2 = __builtin_fmaf(nx(a2), w, a2);
+        a3 = __builtin_fmaf(nx(a3), w, a3); a4 = __builtin_fmaf(nx(a4), w, a4); a5 = __builtin_fmaf(nx(a5), w, a5);
+    }
+    template <int SRC>
+    __device__ __forceinline__ void add_from_lane(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
+        const float s0 = bcast(a0, SRC), s1 = bcast(a1, SRC), s2 = bcast(a2, SRC), s3 = bcast(a3, SRC), s4 = bcast(a4, SRC), s5 = bcast(a5, SRC);
+        a0 = __builtin_fmaf(s0, w, a0); a1 = __builtin_fmaf(s1, w, a1); a2 = __builtin_fmaf(s2, w, a2);
+        a3 = __builtin_fmaf(s3, w, a3); a4 = __builtin_fmaf(s4, w, a4); a5 = __builtin_fmaf(s5, w, a5);
     }
     __device__ __forceinline__ void loads_landed() {}
     __device__ __forceinline__ void mid() { __syncthreads(); }

@@ -20,7 +20,7 @@
 #define DSIM_LIGHT_CAP 8    // register budget of the light sums: LCAP, CCAP <= this
 #define DSIM_MUSCLE_CHUNK 12
 #define DSIM_TAIL_PAD 384
-#define DSIM_RT_MAX 12      // steps of a row-tree sum (DsimDims::RT_N)
+#define DSIM_RT_MAX 16      // steps of a row-tree sum (DsimDims::RT_N)
 struct DsimDims {
     int L, nq, nd, C, M, W, NS, D;  // links, coords, dofs, contacts, muscles, waypoints, active muscle segments, tree levels
     int flags;                      // DSIM_F_*
@@ -39,13 +39,16 @@ struct DsimDims {
     int tr_d0[DSIM_TRUNK_MAX], tr_nd[DSIM_TRUNK_MAX];    // its own dofs [d0, d0 + nd)
     int MK;                                        // chunks of the per-body muscle-row gather (DsimOff::mc_row)
     int pident;                                    // bit p set: every joint at chain position p has an identity X_pj ROTATION
-    // Row-tree sums (RT_N == 0: none; dsim_core.hpp: dsim_rowtree_sum).  A tree of at most 16 links sits in ONE 16-lane DPP row
-    // of the wavefront (link i on lane i), so a subtree sum over per-link values held in REGISTERS is a handful of row shifts:
+    // Row-tree sums (RT_N == 0: none; dsim_core.hpp: dsim_rowtree_sum).  A tree of at most 32 links sits on the first lanes of
+    // the wavefront (link i on lane i), so a subtree sum over per-link values held in REGISTERS is a handful of lane shifts:
     // bottom-up by levels, one step per distinct distance d = child - parent among the links of a level -- every parent adds
-    // the (finished) total of its child d lanes above, weighted 1 / 0.  rt_lvl[s] / rt_d[s]: level of the children and distance
-    // of step s, deepest level first.  CBMAX: most contacts on one body (the per-body contact gather that feeds those sums).
+    // the (finished) total of its child d lanes above, weighted 1 / 0.  Step s, deepest level first, is of kind rt_kind[s]:
+    //   DSIM_RT_ROW    DPP row_shl:d, d = rt_d[s], children of level rt_lvl[s] (every such edge stays inside a 16-lane row)
+    //   DSIM_RT_WAVE1  DPP wave_shl:1 (d = 1; crosses row boundaries), children of level rt_lvl[s]
+    //   DSIM_RT_FAR    ONE edge that no row shift reaches: child lane rt_d[s] -> parent lane rt_lvl[s], by v_readlane
+    // CBMAX: most contacts on one body (the per-body contact gather that feeds those sums).
     int RT_N, CBMAX;
-    int rt_lvl[DSIM_RT_MAX], rt_d[DSIM_RT_MAX];
+    int rt_lvl[DSIM_RT_MAX], rt_d[DSIM_RT_MAX], rt_kind[DSIM_RT_MAX];
     // Link <-> dof lane shifts of a row tree (DSH_OK): every link but the root has exactly one dof and its index is the link's
     // index + DSH (pre-order trees whose only multi-dof joint is the root: Ant 5, the planar models 0, cartpole -1); the root has
     // ND_ROOT dofs 0 .. ND_ROOT - 1 (0: a fixed root).  A per-link value then reaches its dof's lane by ONE row shift (the root's
@@ -53,6 +56,9 @@ struct DsimDims {
     int DSH_OK, DSH, ND_ROOT;
 };
 #define DSIM_TM(t) (1 << (t))
+#define DSIM_RT_ROW 0
+#define DSIM_RT_WAVE1 1
+#define DSIM_RT_FAR 2
 #define DSIM_F_RANGES 1  // subtree(i) == links [i, i+n_i) and its contacts == one contiguous contact range (pre-order numbering)
 
 struct DsimOff {
@@ -448,24 +454,34 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     dd.flags = ranges ? DSIM_F_RANGES : 0;
     for (int i = 0; i < L; ++i)
         if ((int)cb[i].size() > dd.CBMAX) dd.CBMAX = (int)cb[i].size();
-    if (L <= 16 && ranges && M == 0) {
+    if (L <= 32 && ranges && M == 0) {
         // steps of the row-tree sums: levels deepest first, distances ascending within a level
         int n = 0;
         bool ok = true;
+        auto push = [&](int kind, int lv_or_parent, int d_or_child) {
+            if (n == DSIM_RT_MAX) { ok = false; return; }
+            dd.rt_kind[n] = kind; dd.rt_lvl[n] = lv_or_parent; dd.rt_d[n] = d_or_child;
+            ++n;
+        };
         for (int lv = D - 1; lv >= 1 && ok; --lv)
-            for (int dist = 1; dist < 16 && ok; ++dist) {
-                bool any = false;
-                for (int i = 0; i < L; ++i) any = any || (level[i] == lv && i - m.joint_parent[i] == dist);
+            for (int dist = 1; dist < 32 && ok; ++dist) {
+                bool any = false, in_row = dist <= 15;
+                for (int i = 0; i < L; ++i)
+                    if (level[i] == lv && i - m.joint_parent[i] == dist) {
+                        any = true;
+                        in_row = in_row && (i >> 4) == ((i - dist) >> 4);
+                    }
                 if (!any) continue;
-                if (n == DSIM_RT_MAX) { ok = false; break; }
-                dd.rt_lvl[n] = lv;
-                dd.rt_d[n] = dist;
-                ++n;
+                if (dist == 1) push(DSIM_RT_WAVE1, lv, 1);
+                else if (in_row) push(DSIM_RT_ROW, lv, dist);
+                else
+                    for (int i = 0; i < L && ok; ++i)
+                        if (level[i] == lv && i - m.joint_parent[i] == dist) push(DSIM_RT_FAR, m.joint_parent[i], i);
             }
         for (int i = 1; i < L; ++i) ok = ok && m.joint_parent[i] >= 0;   // one tree
         dd.RT_N = (ok && L > 1) ? n : 0;
         if (!dd.RT_N)
-            for (int k = 0; k < DSIM_RT_MAX; ++k) dd.rt_lvl[k] = dd.rt_d[k] = 0;
+            for (int k = 0; k < DSIM_RT_MAX; ++k) dd.rt_lvl[k] = dd.rt_d[k] = dd.rt_kind[k] = 0;
         if (dd.RT_N && nd <= 16) {
             bool sh = true;
             const int ndr = m.joint_qd_start[1] - m.joint_qd_start[0];

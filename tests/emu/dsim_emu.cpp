@@ -92,6 +92,18 @@ template <int NW> struct HostExecT {
         const float r = shfl(v, src >= 0 ? src : lane);
         return (src >= 0 && (src >> 4) == (lane >> 4)) ? r : 0.f;
     }
+    template <bool FIRST = true> void add_from_next(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
+        const int lane = cur_;
+        auto nx = [&](float v) { const float r = shfl(v, lane + 1 < NL ? lane + 1 : lane); return lane + 1 < NL ? r : 0.f; };
+        const float y0 = nx(a0), y1 = nx(a1), y2 = nx(a2), y3 = nx(a3), y4 = nx(a4), y5 = nx(a5);
+        a0 = __builtin_fmaf(y0, w, a0); a1 = __builtin_fmaf(y1, w, a1); a2 = __builtin_fmaf(y2, w, a2);
+        a3 = __builtin_fmaf(y3, w, a3); a4 = __builtin_fmaf(y4, w, a4); a5 = __builtin_fmaf(y5, w, a5);
+    }
+    template <int SRC> void add_from_lane(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
+        const float s0 = bcast(a0, SRC), s1 = bcast(a1, SRC), s2 = bcast(a2, SRC), s3 = bcast(a3, SRC), s4 = bcast(a4, SRC), s5 = bcast(a5, SRC);
+        a0 = __builtin_fmaf(s0, w, a0); a1 = __builtin_fmaf(s1, w, a1); a2 = __builtin_fmaf(s2, w, a2);
+        a3 = __builtin_fmaf(s3, w, a3); a4 = __builtin_fmaf(s4, w, a4); a5 = __builtin_fmaf(s5, w, a5);
+    }
     void loads_landed() {}
     template <int D, bool FIRST = true> void add_from_above(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
         const float y0 = from_above<D>(a0), y1 = from_above<D>(a1), y2 = from_above<D>(a2), y3 = from_above<D>(a3),
