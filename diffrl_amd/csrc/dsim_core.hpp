@@ -244,22 +244,30 @@ struct DsimTopoRegs {
     int gf_row[3], gf_n[3];                  // the same for the forward pass's contact wrench rows (6 components per item, 6 L <= 192 items)
 };
 
-// Row-tree form of the body-level adjoint (dsim_bwd_bodies_rowtree): specialised one-wave kernels of trees that fit one 16-lane
-// DPP row (DsimDims::RT_N > 0: L <= 16, pre-order ranges, no muscles), without ball joints (none of the shipped small models has
-// one; a model with ball joints keeps the phase-per-sum form).
+// Row-tree form of the body-level adjoint (dsim_bwd_bodies_rowtree): specialised kernels of pre-order trees of at most 32 links
+// (DsimDims::RT_N > 0).  Models without muscles: the one-wave mapping (contacts reduced per body by the side block / helper
+// wavefront).  Models WITH muscles (several wavefronts per environment): the per-item and per-body phases stay on all
+// wavefronts, the body level itself runs on the first wavefront alone (Exec::run_wave0), whose link lanes use the same row
+// shifts.  DsimRowTreeFwd: the forward-pass counterparts (f_tot on registers, link <-> dof lane shifts), one-wave models only.
 template <class Ctx, class Exec> struct DsimRowTree {
     static constexpr bool value = []() {
 #ifdef DSIM_NO_ROWTREE   // (A/B builds)
         return false;
 #else
-        if constexpr (std::is_empty<decltype(Ctx::d)>::value && Exec::WAVE_OPS) {
+        if constexpr (std::is_empty<decltype(Ctx::d)>::value) {
             using D = decltype(Ctx::d);
-            return D::RT_N > 0 && D::NS == 0 && (D::tmask & DSIM_TM(DSIM_JOINT_BALL)) == 0 && (D::flags & DSIM_F_RANGES) != 0 &&
-                   D::CBMAX <= DSIM_GX_CAP;
+            const bool tree = D::RT_N > 0 && (D::flags & DSIM_F_RANGES) != 0;
+            return tree && ((Exec::WAVE_OPS && D::NS == 0 && D::CBMAX <= DSIM_GX_CAP) || (Exec::WAVE0_OPS && D::NS > 0));
         } else {
             return false;
         }
 #endif
+    }();
+};
+template <class Ctx, class Exec> struct DsimRowTreeFwd {
+    static constexpr bool value = []() {
+        if constexpr (DsimRowTree<Ctx, Exec>::value) return Exec::WAVE_OPS && decltype(Ctx::d)::NS == 0;
+        else return false;
     }();
 };
 template <class Ctx> struct DsimChainRegs {
@@ -478,7 +486,8 @@ template <bool ADJ = true, class Ctx, class Exec> DSIM_FN void dsim_topo_init(co
                 tp.rt_w[s_] = (lane + D::rt_d[s_] < D::L && pr[s_] == lane && lv[s_] == D::rt_lvl[s_]) ? 1.f : 0.f;
             DSIM_OPAQUE(tp.rt_w[s_]);
         });
-        constexpr int GXP = ADJ ? (12 * D::L + Exec::NL - 1) / Exec::NL : 0, GFP = (6 * D::L + Exec::NL - 1) / Exec::NL;
+        constexpr bool FWD = DsimRowTreeFwd<Ctx, Exec>::value;   // (models with muscles gather per body in phases of their own)
+        constexpr int GXP = (ADJ && FWD) ? (12 * D::L + Exec::NL - 1) / Exec::NL : 0, GFP = FWD ? (6 * D::L + Exec::NL - 1) / Exec::NL : 0;
         static_assert(GXP <= DSIM_GX_PASSES && GFP <= 3, "per-body gather passes");
 #pragma unroll
         for (int p = 0; p < GFP; ++p) {
@@ -805,7 +814,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_contacts(const Ctx& c, Ex
 // block of the kinematics phase), so that the dynamics phase finds ONE row per link and sums subtrees on registers
 // (dsim_fwd_ftot_rowtree) instead of walking 9 + 25 rows per (link, component) lane.
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_contacts_per_body(const Ctx& c, Exec& ex, int lane) {
-    if constexpr (DsimRowTree<Ctx, Exec>::value) {
+    if constexpr (DsimRowTreeFwd<Ctx, Exec>::value) {
         using D = decltype(c.d);
         ex.lds_fence();
         const DsimTopoRegs& tp = ex.topo(lane);
@@ -1449,7 +1458,7 @@ template <int SH, class Exec> DSIM_FN float dsim_row_shift(Exec& ex, float v) {
 }
 template <class Ctx, class Exec> struct DsimDofShift {
     static constexpr bool value = []() {
-        if constexpr (DsimRowTree<Ctx, Exec>::value) return decltype(Ctx::d)::DSH_OK != 0;
+        if constexpr (DsimRowTreeFwd<Ctx, Exec>::value) return decltype(Ctx::d)::DSH_OK != 0;
         else return false;
     }();
 };
@@ -1467,7 +1476,7 @@ template <class Ctx, class Exec> DSIM_FN sv6 dsim_fwd_ftot_rowtree(const Ctx& c,
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_ftot(const Ctx& c, Exec& ex) {
     ex.mark(3);
     ex.run([&](int lane) {
-        if constexpr (DsimRowTree<Ctx, Exec>::value) {
+        if constexpr (DsimRowTreeFwd<Ctx, Exec>::value) {
             const sv6 t = dsim_fwd_ftot_rowtree(c, ex, lane);
             if (lane < c.d.L) stsv(WF(ftot) + 6 * lane, t);
             return;
@@ -1744,7 +1753,7 @@ DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float*
 #pragma unroll
         for (int k = 0; k < NDF; ++k) qdv[k] = WF(qd)[lds_ + k];
         sv6 F;
-        if constexpr (DsimRowTree<Ctx, Exec>::value && DsimWaveDyn<Ctx, Exec>::sums_inside) {
+        if constexpr (DsimRowTreeFwd<Ctx, Exec>::value && DsimWaveDyn<Ctx, Exec>::sums_inside) {
             // ---- link role: f_tot = row-tree subtree sums on registers; f_tot[link(d)] -> dof lane d
             const sv6 ftl = dsim_fwd_ftot_rowtree(c, ex, lane);
             if (is_link) stsv(WF(ftot) + 6 * lane, ftl);   // the adjoint reads it from the checkpoint
@@ -2758,8 +2767,9 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
     ex.mark(10);
     using D = decltype(c.d);
     constexpr int L = D::L, MASK = D::tmask;
-    constexpr bool HAS_FREE = (MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0;
-    ex.fork_side([&](int lane) {
+    constexpr bool HAS_FREE = (MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0, HAS_BALL = (MASK & DSIM_TM(DSIM_JOINT_BALL)) != 0;
+    constexpr bool MUSCLES = D::NS > 0;   // per-item / per-body phases on all wavefronts, the body level on the first one
+    auto fm = [&](int lane) __attribute__((always_inline)) {
         const DsimTopoRegs& tp = ex.topo(lane);
         const bool on = lane < L;
         const int i = on ? lane : 0;
@@ -2767,6 +2777,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
         DSIM_OPAQUE(type);
         const int cs = tp.own_cs, ds = tp.own_ds, par = tp.own_parent;
         const bool hinge = type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE, fr = type == DSIM_JOINT_FREE;
+        const bool ball = HAS_BALL && type == DSIM_JOINT_BALL;
         // ---- every operand that does not come out of this phase, in one round trip
         inertia10 I = ld_i10(WF(i10) + 10 * i);
         sv6 v = ldsv(WF(v) + 6 * i), a = ldsv(WF(a) + 6 * i), r = ldsv(WF(af) + 6 * i);
@@ -2788,6 +2799,22 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
             gp = mk3(gq0, aq[cs + 1], aq[cs + 2]);
             gr = ldq(aq + cs + 3);
         }
+        // ball joints: the other two columns of the motion subspace, their cotangents, the joint's quaternion and its cotangent
+        // (fetched by every lane: the words behind a hinge's single dof / coordinate are in range and unused)
+        sv6 S1 = zerosv(), S2 = zerosv(), aS1 = zerosv(), aS2 = zerosv();
+        float qd1 = 0.f, qd2 = 0.f, g1 = 0.f, g2 = 0.f;
+        q4 rb = mkq(0.f, 0.f, 0.f, 1.f), gb = mkq(0.f, 0.f, 0.f, 0.f);
+        if constexpr (HAS_BALL) {
+            S1 = ldsv(WF(S) + 6 * ds + 6); S2 = ldsv(WF(S) + 6 * ds + 12);
+            aS1 = ldsv(WF(aS) + 6 * ds + 6); aS2 = ldsv(WF(aS) + 6 * ds + 12);
+            qd1 = WF(qd)[ds + 1]; qd2 = WF(qd)[ds + 2];
+            g1 = aqd[ds + 1]; g2 = aqd[ds + 2];
+            rb = ldq(WF(q) + cs);
+            gb = mkq(gq0, aq[cs + 1], aq[cs + 2], aq[cs + 3]);
+        }
+        // the pose of the parent link's frame (free joints in a rotated joint frame only; read before the side block is waited for)
+        q4 rpar = mkq(0.f, 0.f, 0.f, 1.f);
+        if constexpr (HAS_FREE && !DsimFreeRootIdent<Ctx>::value) rpar = ldq(WF(xsc) + 7 * (par >= 0 ? par : 0) + 3);
         ex.loads_landed();
         // ---- f^T, velocity / acceleration recursions^T of the link itself, pose wrench of inertia + gravity (dsim_bwd_bodies)
         const sv6 hv = inertia_mul(I, v);
@@ -2824,13 +2851,20 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
             if (fr) vj = qd6;
         }
         if (hinge) vj = S0 * qd0;
+        if constexpr (HAS_BALL) {
+            if (ball) {
+                vj = S0 * qd0;
+                vj += S1 * qd1;
+                vj += S2 * qd2;
+            }
+        }
         a_v.w += cross(vj.w, A.w) + cross(vj.v, A.v);
         a_v.v += cross(vj.w, A.v);
         sv6 a_vj;
         a_vj.w = cross(A.w, v.w) + cross(A.v, v.v);
         a_vj.v = cross(A.v, v.w);
         ex.stamp();
-        // ---- the contact terms of the own body, reduced by the side block
+        // ---- the contact (and muscle) terms of the own body, reduced per body by the side block / the phases before this one
         ex.side_done();
         const sv6 cpose = ldsv(WF(agx) + 12 * i), ctw = ldsv(WF(agx) + 12 * i + 6);
         ex.loads_landed();
@@ -2839,12 +2873,22 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
         dsim_rowtree_sum(c, ex, tp, T);
         a_vj += T;
         sv6 Wp = zerosv();
-        float aqd_new = g0;
+        float aqd_new = g0, aqd_new1 = g1, aqd_new2 = g2;
         if (hinge) {
             Wp = scross_dual(S0, aS0 + a_vj * qd0);
             aqd_new = g0 + sdot(S0, a_vj);
         }
-        // ---- azs = subtree sum of the pose wrenches (inertia + gravity, joint frame of the children's S, contacts)
+        if constexpr (HAS_BALL) {
+            if (ball) {
+                Wp = scross_dual(S0, aS0 + a_vj * qd0);
+                Wp += scross_dual(S1, aS1 + a_vj * qd1);
+                Wp += scross_dual(S2, aS2 + a_vj * qd2);
+                aqd_new = g0 + sdot(S0, a_vj);
+                aqd_new1 = g1 + sdot(S1, a_vj);
+                aqd_new2 = g2 + sdot(S2, a_vj);
+            }
+        }
+        // ---- azs = subtree sum of the pose wrenches (inertia + gravity, joint frame of the children's S, contacts / muscles)
         sv6 Z = W + Wp + cpose;
         dsim_rowtree_sum(c, ex, tp, Z);
         const sv6 Wt = Z - Wp;   // without the part attached to the link's own joint frame
@@ -2854,6 +2898,15 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
             if (hinge) {
                 aqd[ds] = aqd_new;
                 aq[cs] = gq0 + sdot(S0, Wt);
+            }
+            if constexpr (HAS_BALL) {
+                if (ball) {
+                    aqd[ds] = aqd_new;
+                    aqd[ds + 1] = aqd_new1;
+                    aqd[ds + 2] = aqd_new2;
+                    const v3 t = mk3(sdot(S0, Wt), sdot(S1, Wt), sdot(S2, Wt));
+                    stq(aq + cs, gb + qmul_v(t, rb) * 2.0f);
+                }
             }
             if constexpr (HAS_FREE) {
                 if (fr) {
@@ -2866,35 +2919,59 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
                     } else {
                         const q4 rpj = ldq(CF(xpj) + 7 * i + 3);
                         q4 rj = rpj;
-                        if (par >= 0) rj = qmul(ldq(WF(xsc) + 7 * par + 3), rpj);
+                        if (par >= 0) rj = qmul(rpar, rpj);
                         st3(aq + cs, gp + rotate_inv(rj, Wt.v));
                         stq(aq + cs + 3, gr + qmul(qmul(qconj(rj), mkq(tc.x, tc.y, tc.z, 0.f)), rc) * 2.0f);
                     }
                 }
             }
         }
-    }, [&](int lane) {
-        // side block: contacts^T per contact, then the per-body sums of their 12-float rows (bodies without contacts: zeros)
-        dsim_bwd_external_items(c, ex, lane);
-        ex.lds_fence();
-        const DsimTopoRegs& tp = ex.topo(lane);
-        constexpr int GXP = (12 * L + Exec::NL - 1) / Exec::NL, CB = D::CBMAX > 0 ? D::CBMAX : 1;
-        float x[GXP][CB];
+    };
+    if constexpr (MUSCLES) {
+        // per item (all wavefronts): contacts^T, muscles^T; per muscle: the activation cotangent; chunk sums of the muscle rows;
+        // per body: muscle pose wrenches + contact pose wrenches (6), contact twist cotangents (6) -- the phases of dsim_bwd_bodies
+        ex.run([&](int lane) { dsim_bwd_external_items(c, ex, lane); });
+        ex.run([&](int lane) {
+            for (int m = lane; m < c.d.M; m += Exec::NL) {
+                const int s0 = CI(ms_start)[m], s1 = CI(ms_start)[m + 1];
+                const float gm = WF(amact)[m];
+                WF(amact)[m] = gm + dsim_range_sum(WF(mus) + 12 * c.d.NS, 1, 0, s0, s1 - s0, 0.f);
+            }
+            dsim_muscle_chunk_sums(c, lane, Exec::NL);
+        });
+        ex.run([&](int lane) {
+            for (int it = lane; it < 12 * c.d.L; it += Exec::NL) {
+                const int i = it / 12, r = it - 12 * i;
+                float acc = 0.f;
+                if (r < 6) acc = dsim_range_sum(WF(mpart), 6, r, CI(mb_start)[i], CI(mb_start)[i + 1] - CI(mb_start)[i], 0.f);
+                WF(agx)[it] = dsim_body_contact_sum(c, i, WF(acx), 12, r, acc);
+            }
+        });
+        ex.run_wave0(fm);
+    } else {
+        ex.fork_side(fm, [&](int lane) {
+            // side block: contacts^T per contact, then the per-body sums of their 12-float rows (bodies without contacts: zeros)
+            dsim_bwd_external_items(c, ex, lane);
+            ex.lds_fence();
+            const DsimTopoRegs& tp = ex.topo(lane);
+            constexpr int GXP = (12 * L + Exec::NL - 1) / Exec::NL, CB = D::CBMAX > 0 ? D::CBMAX : 1;
+            float x[GXP][CB];
 #pragma unroll
-        for (int p = 0; p < GXP; ++p)   // all loads first: addresses are register + immediate (rows past a body's last contact are
-#pragma unroll                          // other contacts' rows or the arrays behind acx: selected away)
-            for (int e = 0; e < CB; ++e) x[p][e] = WF(acx)[tp.gx_row[p] + 12 * e];
+            for (int p = 0; p < GXP; ++p)   // all loads first: addresses are register + immediate (rows past a body's last contact are
+#pragma unroll                              // other contacts' rows or the arrays behind acx: selected away)
+                for (int e = 0; e < CB; ++e) x[p][e] = WF(acx)[tp.gx_row[p] + 12 * e];
 #pragma unroll
-        for (int p = 0; p < GXP; ++p) {
-            float acc = 0.f;
-            int n = tp.gx_n[p];
-            DSIM_OPAQUE(n);   // (the e < n masks are recomputed here, not kept as loop invariants in spilled SGPR pairs)
+            for (int p = 0; p < GXP; ++p) {
+                float acc = 0.f;
+                int n = tp.gx_n[p];
+                DSIM_OPAQUE(n);   // (the e < n masks are recomputed here, not kept as loop invariants in spilled SGPR pairs)
 #pragma unroll
-            for (int e = 0; e < CB; ++e) acc += (e < n) ? x[p][e] : 0.f;
-            const int it = lane + Exec::NL * p;
-            if (it < 12 * L) WF(agx)[it] = acc;
-        }
-    });
+                for (int e = 0; e < CB; ++e) acc += (e < n) ? x[p][e] : 0.f;
+                const int it = lane + Exec::NL * p;
+                if (it < 12 * L) WF(agx)[it] = acc;
+            }
+        });
+    }
 }
 
 // Lean checkpoint mode: the row holds only (q, qd); the forward intermediates of the substep are recomputed here with the

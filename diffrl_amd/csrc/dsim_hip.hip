@@ -164,6 +164,8 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
     // Cross-lane primitives of the wavefront (one wave per environment only): the phase code uses them for the small
     // point-to-point exchanges between lanes that would otherwise be an LDS store, a phase boundary and an LDS load.
     static constexpr bool WAVE_OPS = NW == 1;
+    // ... and inside run_wave0 (a phase that only the FIRST wavefront of the environment executes) with any number of waves
+    static constexpr bool WAVE0_OPS = true;
     // value of v in lane `src` (any lane): ds_bpermute_b32 -- the LDS crossbar, no LDS memory, no phase boundary.  All
     // lanes of the wave must execute it (uniform control flow); values of lanes that hold nothing meaningful are ignored.
     __device__ __forceinline__ float shfl(float v, int src) {
@@ -248,6 +250,17 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
     template <class F> __device__ __forceinline__ void run(F&& f) {
         if (!helper_) f(lane_());
         sync();
+    }
+    // phase of the first wavefront alone: the link-lane phases of a model whose per-item phases need several wavefronts (row-tree
+    // body level of the muscle model).  Inside, the cross-lane primitives above are those of that one wave; side_done() is a no-op
+    // (everything the phase reads was finished behind the workgroup barrier in front of it).
+    template <class F> __device__ __forceinline__ void run_wave0(F&& f) {
+        if constexpr (NW == 1) {
+            run(f);
+        } else {
+            if (threadIdx.x < DSIM_NL) f((int)threadIdx.x);
+            sync();
+        }
     }
     // phase executed by the helper as well (register-only set-up such as the topology records: each wave keeps its own)
     template <class F> __device__ __forceinline__ void run_both(F&& f) {
@@ -339,7 +352,7 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
     }
     __device__ __forceinline__ void side_done() {
         if constexpr (HELPER) group_barrier();
-        else dsim_wave_sync();
+        else if constexpr (NW == 1) dsim_wave_sync();
     }
     // phase that only writes global memory nobody in this launch reads back: no vmcnt wait.  One wave: no barrier either
     // (its LDS reads precede, in program order, whatever the next phase stores); several waves: the LDS words it reads
@@ -572,6 +585,12 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_body_xf_kernel(KCommonT<O, 
 template <int NW> struct TimingExec {
     static constexpr int NL = DSIM_NL * NW;
     static constexpr bool WAVE_OPS = NW == 1;
+    static constexpr bool WAVE0_OPS = true;
+    template <class F> __device__ __forceinline__ void run_wave0(F&& f) {
+        run([&](int lane) {
+            if (lane < DSIM_NL) f(lane);
+        });
+    }
     __device__ __forceinline__ float shfl(float v, int src) {
         return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
     }

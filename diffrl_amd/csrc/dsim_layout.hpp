@@ -454,7 +454,7 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     dd.flags = ranges ? DSIM_F_RANGES : 0;
     for (int i = 0; i < L; ++i)
         if ((int)cb[i].size() > dd.CBMAX) dd.CBMAX = (int)cb[i].size();
-    if (L <= 32 && ranges && M == 0) {
+    if (L <= 32 && ranges) {
         // steps of the row-tree sums: levels deepest first, distances ascending within a level
         int n = 0;
         bool ok = true;

@@ -41,33 +41,40 @@ template <int NW> struct HostExecT {
         e->done_[lane] = true;
         swapcontext(&e->lane_ctx_[lane], &e->main_ctx_);
     }
+    // the first `n` lanes as lock-step coroutines (cross-lane primitives allowed inside f)
+    template <class F> void run_coro(F&& f, int n) {
+        if (stacks_.size() < STACK * (size_t)n) stacks_.resize(STACK * (size_t)n);
+        body_ = [&f](int lane) { f(lane); };
+        self() = this;
+        for (int lane = 0; lane < n; ++lane) {
+            done_[lane] = false;
+            parity_[lane] = 0;
+            getcontext(&lane_ctx_[lane]);
+            lane_ctx_[lane].uc_stack.ss_sp = stacks_.data() + STACK * lane;
+            lane_ctx_[lane].uc_stack.ss_size = STACK;
+            lane_ctx_[lane].uc_link = &main_ctx_;
+            makecontext(&lane_ctx_[lane], (void (*)())tramp, 1, lane);
+        }
+        for (int left = n; left > 0;) {
+            left = 0;
+            for (int lane = 0; lane < n; ++lane) {
+                if (done_[lane]) continue;
+                cur_ = lane;
+                swapcontext(&main_ctx_, &lane_ctx_[lane]);  // runs until the lane's next collective or its end
+                if (!done_[lane]) ++left;
+            }
+        }
+    }
     template <class F> void run(F&& f) {
         if constexpr (!WAVE_OPS) {
             for (int lane = 0; lane < NL; ++lane) f(lane);
         } else {
-            if (stacks_.empty()) stacks_.resize(STACK * NL);
-            body_ = [&f](int lane) { f(lane); };
-            self() = this;
-            for (int lane = 0; lane < NL; ++lane) {
-                done_[lane] = false;
-                parity_[lane] = 0;
-                getcontext(&lane_ctx_[lane]);
-                lane_ctx_[lane].uc_stack.ss_sp = stacks_.data() + STACK * lane;
-                lane_ctx_[lane].uc_stack.ss_size = STACK;
-                lane_ctx_[lane].uc_link = &main_ctx_;
-                makecontext(&lane_ctx_[lane], (void (*)())tramp, 1, lane);
-            }
-            for (int left = NL; left > 0;) {
-                left = 0;
-                for (int lane = 0; lane < NL; ++lane) {
-                    if (done_[lane]) continue;
-                    cur_ = lane;
-                    swapcontext(&main_ctx_, &lane_ctx_[lane]);  // runs until the lane's next collective or its end
-                    if (!done_[lane]) ++left;
-                }
-            }
+            run_coro(f, NL);
         }
     }
+    // a phase of the environment's FIRST wavefront alone (device: DevExec::run_wave0), with its cross-lane primitives
+    static constexpr bool WAVE0_OPS = true;
+    template <class F> void run_wave0(F&& f) { run_coro(f, DSIM_NL); }
     // collectives (only meaningful inside run(), NW == 1).  Every lane that is still running must call the same sequence.
     void arrive() {
         const int lane = cur_;

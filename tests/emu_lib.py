@@ -74,7 +74,8 @@ def reorders(t):
     kinematics of deep trees (dsim_fwd_kinematics_scan).  Such pairs agree to a tolerance, all others bit for bit."""
     d = layout(t)[1]
     scan = d["D"] >= SCAN_MIN_DEPTH and d["L"] <= 64 and d["nd"] <= 64 and d["C"] <= 64 and d["NS"] <= 64
-    rowtree = d["RT_N"] > 0 and not (d["tmask"] & (1 << 2))   # dsim_core.hpp: DsimRowTree (subtree sums by DPP row shifts)
+    # dsim_core.hpp: DsimRowTree (body-level adjoint with subtree sums by lane shifts; models with muscles on their first wave)
+    rowtree = d["RT_N"] > 0 and (d["flags"] & 1) and (d["NS"] > 0 or d["CBMAX"] <= 12)
     return d["NT"] > 0 or scan or rowtree
 
 
