@@ -264,6 +264,21 @@ template <class Ctx, class Exec> struct DsimRowTree {
 #endif
     }();
 };
+// The HELPER wavefront brings the next checkpoint row into LDS (row-tree models with a helper wave, full checkpoint mode): it
+// reaches the top of the next substep right behind the side block of the body level -- while the main wave still works through
+// the second half of that phase, which reads registers and the per-body rows only -- stores the row it prefetched one substep
+// earlier, requests the one after, and meets the main wave at a workgroup barrier.  The main wave's substep then starts with that
+// barrier instead of the copy (register -> LDS stores + the store -> load turnaround in front of integrate^T).
+template <class Ctx, class Exec> struct DsimHelperCommit {
+    static constexpr bool value = []() {
+#ifdef DSIM_NO_HELPER_COMMIT   // (A/B builds)
+        return false;
+#else
+        if constexpr (DsimRowTree<Ctx, Exec>::value) return Exec::HAS_HELPER && !Ctx::LEAN && decltype(Ctx::d)::NS == 0;
+        else return false;
+#endif
+    }();
+};
 template <class Ctx, class Exec> struct DsimRowTreeFwd {
     static constexpr bool value = []() {
         if constexpr (DsimRowTree<Ctx, Exec>::value) return Exec::WAVE_OPS && decltype(Ctx::d)::NS == 0;
@@ -3021,18 +3036,34 @@ DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
             // The row was requested one substep earlier (ex.prefetch keeps it in flight in registers while the
             // previous adjoint substep computes), so this phase only moves registers to LDS.
             const float* hv = (s == s1 - 1) ? dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, g) : nullptr;
-            if (s == substeps - 1) ex.prefetch(g_ckpt + (size_t)s * dsim_row(c), dsim_row(c));
-            ex.run([&](int lane) {
-                ex.commit(WF(q), dsim_row(c), lane);
-                if (hv) {
-                    for (int k = lane; k < nd * nd; k += Exec::NL) {
-                        WF(hinv)[k] = hv[k];
-                        WF(aH)[k] = 0.f;
-                    }
-                    dsim_hacc_zero(c, ex, lane);
+            if constexpr (DsimHelperCommit<Ctx, Exec>::value) {
+                if (s == substeps - 1) {
+                    ex.helper_prefetch(g_ckpt + (size_t)s * dsim_row(c), dsim_row(c));
+                    ex.group_sync();   // the main wave is done with the prologue's use of q / qd (the words the row lands on)
                 }
-            });
-            if (s > 0) ex.prefetch(g_ckpt + (size_t)(s - 1) * dsim_row(c), dsim_row(c));
+                ex.helper_commit(WF(q), dsim_row(c), s > 0 ? g_ckpt + (size_t)(s - 1) * dsim_row(c) : nullptr);
+                if (hv)
+                    ex.run([&](int lane) {
+                        for (int k = lane; k < nd * nd; k += Exec::NL) {
+                            WF(hinv)[k] = hv[k];
+                            WF(aH)[k] = 0.f;
+                        }
+                        dsim_hacc_zero(c, ex, lane);
+                    });
+            } else {
+                if (s == substeps - 1) ex.prefetch(g_ckpt + (size_t)s * dsim_row(c), dsim_row(c));
+                ex.run([&](int lane) {
+                    ex.commit(WF(q), dsim_row(c), lane);
+                    if (hv) {
+                        for (int k = lane; k < nd * nd; k += Exec::NL) {
+                            WF(hinv)[k] = hv[k];
+                            WF(aH)[k] = 0.f;
+                        }
+                        dsim_hacc_zero(c, ex, lane);
+                    }
+                });
+                if (s > 0) ex.prefetch(g_ckpt + (size_t)(s - 1) * dsim_row(c), dsim_row(c));
+            }
             if constexpr (Ctx::LEAN) dsim_bwd_recompute_forward(c, ex);
             if (s == s0) dsim_fwd_composite(c, ex);
             dsim_bwd_substep(c, ex, s == s0);  // aq / aqd (== aqn / aqdn, same LDS words) now belong to substep s - 1
@@ -3587,7 +3618,8 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
             dsim_io_fetch<IO::CO, Exec::NL>(io + IO::GOBSB, g_gobs_before, sp.n_obs, lane);
             io[IO::GREW] = g_grew ? g_grew[0] : 0.f;
         });
-        ex.prefetch(g_ckpt + (size_t)(substeps - 1) * dsim_row(c), dsim_row(c));
+        if constexpr (DsimHelperCommit<Ctx, Exec>::value) ex.helper_prefetch(g_ckpt + (size_t)(substeps - 1) * dsim_row(c), dsim_row(c));
+        else ex.prefetch(g_ckpt + (size_t)(substeps - 1) * dsim_row(c), dsim_row(c));
     }
     ex.begin();
     if (ep_flags == DSIM_EP_INVALID) {
@@ -3636,18 +3668,32 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
             // The row was requested one substep earlier (ex.prefetch keeps it in flight in registers while the
             // previous adjoint substep computes), so this phase only moves registers to LDS.
             const float* hv = (s == s1 - 1) ? dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, g) : nullptr;
-            if (!IO::PRE && s == substeps - 1) ex.prefetch(g_ckpt + (size_t)s * dsim_row(c), dsim_row(c));
-            ex.run([&](int lane) {
-                ex.commit(WF(q), dsim_row(c), lane);
-                if (hv) {
-                    for (int k = lane; k < nd * nd; k += Exec::NL) {
-                        WF(hinv)[k] = hv[k];
-                        WF(aH)[k] = 0.f;
+            if constexpr (DsimHelperCommit<Ctx, Exec>::value) {
+                static_assert(IO::PRE, "helper-side commit belongs to the specialised kernels");
+                if (s == substeps - 1) ex.group_sync();   // the main wave is done with the end state in q / qd (observation adjoint)
+                ex.helper_commit(WF(q), dsim_row(c), s > 0 ? g_ckpt + (size_t)(s - 1) * dsim_row(c) : nullptr);
+                if (hv)
+                    ex.run([&](int lane) {
+                        for (int k = lane; k < nd * nd; k += Exec::NL) {
+                            WF(hinv)[k] = hv[k];
+                            WF(aH)[k] = 0.f;
+                        }
+                        dsim_hacc_zero(c, ex, lane);
+                    });
+            } else {
+                if (!IO::PRE && s == substeps - 1) ex.prefetch(g_ckpt + (size_t)s * dsim_row(c), dsim_row(c));
+                ex.run([&](int lane) {
+                    ex.commit(WF(q), dsim_row(c), lane);
+                    if (hv) {
+                        for (int k = lane; k < nd * nd; k += Exec::NL) {
+                            WF(hinv)[k] = hv[k];
+                            WF(aH)[k] = 0.f;
+                        }
+                        dsim_hacc_zero(c, ex, lane);
                     }
-                    dsim_hacc_zero(c, ex, lane);
-                }
-            });
-            if (s > 0) ex.prefetch(g_ckpt + (size_t)(s - 1) * dsim_row(c), dsim_row(c));
+                });
+                if (s > 0) ex.prefetch(g_ckpt + (size_t)(s - 1) * dsim_row(c), dsim_row(c));
+            }
             if constexpr (Ctx::LEAN) dsim_bwd_recompute_forward(c, ex);
             if (s == s0) dsim_fwd_composite(c, ex);
             dsim_bwd_substep(c, ex, s == s0);  // aq / aqd (== aqn / aqdn, same LDS words) now belong to substep s - 1

@@ -405,6 +405,35 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
             if (4 * k < words) pf[r] = r4[k];
         }
     }
+    // ---- the same on the HELPER wavefront (dsim_core.hpp: DsimHelperCommit) ------------------------------------------------
+    // both waves: workgroup barrier (the helper waits for the main wave's prologue)
+    __device__ __forceinline__ void group_sync() {
+        if constexpr (HELPER) group_barrier();
+    }
+    __device__ __forceinline__ void helper_prefetch(const float* row, int words) {
+        if constexpr (HELPER) {
+            pf_src = row;
+            if (!helper_ || words > 4 * NL * DSIM_PF) return;
+            const v4f* r4 = reinterpret_cast<const v4f*>(row);
+#pragma unroll
+            for (int r = 0; r < DSIM_PF; ++r) {
+                const int k = lane_() + NL * r;
+                if (4 * k < words) pf[r] = r4[k];
+            }
+        }
+    }
+    // helper: the prefetched row -> LDS, then the request for the row after it (next != nullptr); both waves: barrier
+    __device__ __forceinline__ void helper_commit(float* dst, int words, const float* next) {
+        if constexpr (HELPER) {
+            if (helper_) {
+                commit(dst, words, lane_());
+                if (next) helper_prefetch(next, words);
+            }
+            asm volatile("" ::: "memory");
+            group_barrier();
+            stamp();
+        }
+    }
     __device__ __forceinline__ void commit(float* dst, int words, int lane) {
         if (words > 4 * NL * DSIM_PF) {
             for (int k = lane; k < words; k += NL) dst[k] = pf_src[k];
@@ -644,6 +673,9 @@ template <int NW> struct TimingExec {
         a3 = __builtin_fmaf(s3, w, a3); a4 = __builtin_fmaf(s4, w, a4); a5 = __builtin_fmaf(s5, w, a5);
     }
     __device__ __forceinline__ void loads_landed() {}
+    __device__ __forceinline__ void group_sync() {}
+    __device__ __forceinline__ void helper_prefetch(const float*, int) {}
+    __device__ __forceinline__ void helper_commit(float*, int, const float*) {}
     __device__ __forceinline__ void mid() { __syncthreads(); }
     __device__ __forceinline__ void stamp() {}
     DsimImage<NW, 0> img_;

@@ -112,6 +112,9 @@ template <int NW> struct HostExecT {
         a3 = __builtin_fmaf(s3, w, a3); a4 = __builtin_fmaf(s4, w, a4); a5 = __builtin_fmaf(s5, w, a5);
     }
     void loads_landed() {}
+    void group_sync() {}                                       // (no helper wavefront here: DsimHelperCommit is off)
+    void helper_prefetch(const float*, int) {}
+    void helper_commit(float*, int, const float*) {}
     template <int D, bool FIRST = true> void add_from_above(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
         const float y0 = from_above<D>(a0), y1 = from_above<D>(a1), y2 = from_above<D>(a2), y3 = from_above<D>(a3),
                     y4 = from_above<D>(a4), y5 = from_above<D>(a5);
