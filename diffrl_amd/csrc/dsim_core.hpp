@@ -2422,8 +2422,108 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external_items(const Ctx&
 // strict subtree of la -- the deeper link is theirs, the term is S_a . F_b with F_b = Ic[link(b)] S_b -- and (ii) the
 // dofs of the ancestors-or-self of la (the list adof(la)) -- the deeper link is la, the term is S_a . Ic[la] S_b.
 // Both sets are short lists (a contiguous dof range with pre-order numbering), walked two entries per LDS round trip.
+// The same for the specialised kernels of pre-order trees: both lists of a dof are BOUNDED at compile time (DsimDims::SDMAX,
+// ADMAX), so their entries are fetched in batches -- the strict-subtree dofs are a contiguous range (no index loads at all), the
+// ancestor dofs one batch of indices, one of operands -- and masked with 0 / 1 weights, instead of two run-time loops of
+// dependent loads, two entries per round trip (measured on the old form: Ant 7.9 k, SNUHumanoid 12.8 k cycles per refresh, the
+// latter six times per env-step).  Same terms in the same order: bit-identical to the loops.
+template <class Ctx, class Exec> DSIM_FN void dsim_bwd_mass_bounded(const Ctx& c, Exec& ex) {
+    using D = decltype(c.d);
+    // (batches of CH entries: all of a long list at once costs Humanoid > 256 VGPRs)
+    constexpr int nd = D::nd, CH = 4, B1 = (D::SDMAX + CH - 1) / CH * CH, B2 = (D::ADMAX + CH - 1) / CH * CH;
+    // the two lists are independent blocks (aS / aic10): the second goes to the helper wavefront, or to the upper half of a
+    // workgroup of several waves
+    constexpr int OFF = (!Exec::HAS_HELPER && Exec::NL >= 128) ? Exec::NL / 2 : 0;
+    ex.fork_join([&](int lane) {
+        const float* aH = WF(aH);
+        for (int a = lane; a < nd; a += Exec::NL) {
+            const int la = CI(dof_link)[a];
+            const int nsub = CI(linfo)[8 * la + 5], e0 = CI(adof_start)[la], cnt = CI(adof_start)[la + 1] - e0;
+            const int b0 = CI(qdstart)[la + 1], nb = CI(qdstart)[la + nsub] - b0;
+            sv6 acc = zerosv(), u = zerosv();
+#pragma unroll 1
+            for (int c0 = 0; c0 < B1; c0 += CH) {
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const bool in = c0 + e < nb;
+                    const int b = in ? b0 + c0 + e : a;   // (past the end: an in-range row, weight 0)
+                    const float w = aH[a * nd + b] + aH[b * nd + a];
+                    acc += ldsv(WF(F) + 6 * b) * (in ? w : 0.f);
+                }
+            }
+#pragma unroll 1
+            for (int c0 = 0; c0 < B2; c0 += CH) {
+                int dd[CH];
+#pragma unroll
+                for (int e = 0; e < CH; ++e) dd[e] = CI(adof_list)[e0 + (c0 + e < cnt ? c0 + e : 0)];
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const int d0 = dd[e];
+                    const float w = aH[a * nd + d0] + aH[d0 * nd + a];
+                    u += ldsv(WF(S) + 6 * d0) * ((c0 + e < cnt) ? w : 0.f);
+                }
+            }
+            acc += inertia_mul(ld_i10(WF(ic10) + 10 * la), u);
+            float* o = WF(aS) + 6 * a;
+            const sv6 g = ldsv(o);
+            stsv(o, g + acc);
+        }
+    }, [&](int lane) {
+        const float* aH = WF(aH);
+        for (int t = lane; t < nd + OFF; t += Exec::NL) {
+            const int b = t - OFF;
+            if (b < 0) continue;
+            float g[10];
+            for (int k = 0; k < 10; ++k) g[k] = 0.f;
+            const int j = CI(dof_link)[b];
+            const sv6 Sb = ldsv(WF(S) + 6 * b);
+            const int e0 = CI(adof_start)[j], cnt = CI(adof_start)[j + 1] - e0;
+#pragma unroll 1
+            for (int c0 = 0; c0 < B2; c0 += CH) {
+                int aa[CH];
+#pragma unroll
+                for (int e = 0; e < CH; ++e) aa[e] = CI(adof_list)[e0 + (c0 + e < cnt ? c0 + e : 0)];
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const int a0 = aa[e];
+                    const float w0 = (a0 == b) ? aH[a0 * nd + a0] : aH[a0 * nd + b] + aH[b * nd + a0];
+                    inertia_bilinear_adj(g, ldsv(WF(S) + 6 * a0), Sb, (c0 + e < cnt && a0 <= b) ? w0 : 0.f);
+                }
+            }
+            for (int k = 0; k < 10; ++k) WF(aic10)[10 * b + k] = g[k];
+        }
+    });
+    ex.run([&](int lane) {
+        for (int it = lane; it < 10 * c.d.L; it += Exec::NL) {
+            const int i = it / 10, k = it - 10 * i;
+            const int e0 = CI(adof_start)[i], cnt = CI(adof_start)[i + 1] - e0;
+            float acc = 0.f;
+#pragma unroll 1
+            for (int c0 = 0; c0 < B2; c0 += CH) {
+                int bb[CH];
+#pragma unroll
+                for (int e = 0; e < CH; ++e) bb[e] = CI(adof_list)[e0 + (c0 + e < cnt ? c0 + e : 0)];
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const float x = WF(aic10)[10 * bb[e] + k];
+                    acc += (c0 + e < cnt) ? x : 0.f;
+                }
+            }
+            WF(ai10m)[it] = acc;
+        }
+    });
+}
+
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_mass(const Ctx& c, Exec& ex) {
     ex.mark(9);
+    if constexpr (DsimIsStatic<Ctx>::value) {
+#ifndef DSIM_NO_BOUNDED_MASS   // (A/B builds)
+        if constexpr ((decltype(c.d)::flags & DSIM_F_RANGES) != 0) {
+            dsim_bwd_mass_bounded(c, ex);
+            return;
+        }
+#endif
+    }
     const int nd = c.d.nd;
     ex.run([&](int lane) {
         for (int a = lane; a < nd; a += Exec::NL) {

@@ -54,6 +54,9 @@ struct DsimDims {
     // ND_ROOT dofs 0 .. ND_ROOT - 1 (0: a fixed root).  A per-link value then reaches its dof's lane by ONE row shift (the root's
     // by v_readlane from lane 0) instead of a ds_bpermute round trip, and back.
     int DSH_OK, DSH, ND_ROOT;
+    // bounds of the mass-matrix adjoint's two lists per dof (dsim_core.hpp: dsim_bwd_mass): most dofs in the STRICT subtree of a
+    // link, longest list of dofs of the ancestors-or-self of a link
+    int SDMAX, ADMAX;
 };
 #define DSIM_TM(t) (1 << (t))
 #define DSIM_RT_ROW 0
@@ -452,6 +455,13 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     }
     dd.L = L; dd.nq = nq; dd.nd = nd; dd.C = C; dd.M = M; dd.W = W; dd.NS = NS; dd.D = D;
     dd.flags = ranges ? DSIM_F_RANGES : 0;
+    for (int i = 0; i < L; ++i) {
+        int sd = 0;
+        for (int j : sub[i])
+            if (j != i) sd += m.joint_qd_start[j + 1] - m.joint_qd_start[j];
+        if (sd > dd.SDMAX) dd.SDMAX = sd;
+        if ((int)adof[i].size() > dd.ADMAX) dd.ADMAX = (int)adof[i].size();
+    }
     for (int i = 0; i < L; ++i)
         if ((int)cb[i].size() > dd.CBMAX) dd.CBMAX = (int)cb[i].size();
     if (L <= 32 && ranges) {
