@@ -541,6 +541,9 @@ def main(argv=None):
             out["other_configs"] = [measure_other_config("humanoid", 1024, H, MM_FREQ["humanoid"], device),
                                     measure_other_config("snu", 512, H, MM_FREQ["snu"], device),
                                     measure_other_config("ant", n, H, 1, device),
+                                    # beyond the helper-wave capacity: forward with two environments per wavefront
+                                    # (dsim_hip.hip: DSIM_MODE_PAIR), adjoint with one
+                                    measure_other_config("ant", 8192, H, MM_FREQ["ant"], device, steps=5),
                                     # the headline workload on the GENERIC kernels (run-time layout: what a user model that
                                     # matches no specialised kernel set gets; tools/gen_static_layouts.py adds a set)
                                     measure_other_config("ant", n, H, MM_FREQ["ant"], device, generic=True)]

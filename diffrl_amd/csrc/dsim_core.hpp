@@ -51,6 +51,10 @@ typedef int __attribute__((may_alias)) dsim_int_a;
 template <class O, class D, bool LEAN_ = false> struct DsimCtxT {
     static constexpr bool LEAN = LEAN_;
     float* s;  // LDS image base
+    // ... of the model constants, [0, const_words) of the image.  The same pointer, except where two environments of one
+    // workgroup share ONE copy of the constants (dsim_hip.hip: DSIM_MODE_PAIR): then `s` is what makes the work-array offsets
+    // land in this environment's own work area, and differs between the lanes of the two halves of the wave.
+    const float* k;
     O o;
     D d;
     float h;   // substep length
@@ -59,8 +63,8 @@ typedef DsimCtxT<DsimOff, DsimDims> DsimCtx;
 // words of one substep's checkpoint row: the saved block (everything the adjoint reads) or, in the lean mode, only (q, qd)
 template <class Ctx> DSIM_FN int dsim_row(const Ctx& c) { return Ctx::LEAN ? c.o.xsc - c.o.q : c.o.save_words; }
 
-#define CI(name) (reinterpret_cast<const dsim_int_a*>(c.s) + c.o.name)
-#define CF(name) (static_cast<const float*>(c.s) + c.o.name)
+#define CI(name) (reinterpret_cast<const dsim_int_a*>(c.k) + c.o.name)
+#define CF(name) (c.k + c.o.name)
 #define WF(name) (c.s + c.o.name)
 
 // Small reductions out of LDS.  One wavefront per environment means nothing hides LDS latency except ILP,
@@ -147,14 +151,14 @@ struct DsimLinkInfo {
     int parent, type, cs, ds, level, nsub, c0, nc;
 };
 template <class Ctx> DSIM_FN DsimLinkInfo dsim_link_info(const Ctx& c, int i) {
-    const dsim_i4* p = reinterpret_cast<const dsim_i4*>(reinterpret_cast<const dsim_int_a*>(c.s) + c.o.linfo + 8 * i);
+    const dsim_i4* p = reinterpret_cast<const dsim_i4*>(reinterpret_cast<const dsim_int_a*>(c.k) + c.o.linfo + 8 * i);
     const dsim_i4 a = p[0], b = p[1];
     return DsimLinkInfo{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 }
 // subtree sum of a per-link array: contiguous range when the model is numbered in pre-order, CSR list otherwise
 template <class Ctx> DSIM_FN float dsim_subtree_sum(const Ctx& c, const float* data, int stride, int comp, int i, int n_known = -1) {
     if (c.d.flags & DSIM_F_RANGES) {
-        const int n = n_known >= 0 ? n_known : reinterpret_cast<const dsim_int_a*>(c.s)[c.o.linfo + 8 * i + 5];
+        const int n = n_known >= 0 ? n_known : reinterpret_cast<const dsim_int_a*>(c.k)[c.o.linfo + 8 * i + 5];
         if constexpr (DsimIsStatic<Ctx>::value)
             return dsim_range_sum_b<dsim_cap_links<decltype(c.d)>()>(data, stride, comp, i, n, 0.f);
         else
@@ -285,6 +289,13 @@ template <class Ctx, class Exec> struct DsimRowTreeFwd {
         else return false;
     }();
 };
+// Models whose one-wave kernels also exist for TWO environments per wavefront (32 lanes each; dsim_hip.hip: DSIM_MODE_PAIR):
+// specialised layouts whose links sit in one 16-lane row (the row-tree shifts stay inside a half) and whose contacts and dofs
+// are single-pass items of 32 lanes.
+template <class D> constexpr bool dsim_pair_ok() {
+    if constexpr (std::is_empty<D>::value) return D::NS == 0 && D::C <= DSIM_NL / 2 && D::nd <= DSIM_NL / 2 && D::L <= 16;
+    else return false;
+}
 template <class Ctx> struct DsimChainRegs {
     static constexpr bool value = []() {
         if constexpr (std::is_empty<decltype(Ctx::d)>::value) return decltype(Ctx::d)::D <= DSIM_CHAIN_MAX;
@@ -348,7 +359,7 @@ template <class Ctx, int NL> struct DsimScanFk {
     static constexpr bool value = []() {
         if constexpr (std::is_empty<decltype(Ctx::d)>::value) {
             using D = decltype(Ctx::d);
-            return NL == DSIM_NL && D::L < NL && D::nd <= NL && D::C <= NL && D::D >= DSIM_SCAN_MIN_DEPTH &&
+            return NL <= DSIM_NL && D::L < NL && D::nd <= NL && D::C <= NL && D::D >= DSIM_SCAN_MIN_DEPTH &&
                    D::D <= (1 << DSIM_SCAN_ROUNDS_MAX);
         } else {
             return false;
@@ -370,7 +381,7 @@ template <class Ctx, int NL> struct DsimContactsAfterWalk {
         if constexpr (DsimScanFk<Ctx, NL>::value) return false;
         else if constexpr (DsimChainRegs<Ctx>::value) {
             using D = decltype(Ctx::d);
-            return NL == DSIM_NL && D::C > 0 && D::C <= NL && D::L <= NL && D::nd <= NL && D::NS == 0;
+            return NL <= DSIM_NL && D::C > 0 && D::C <= NL && D::L <= NL && D::nd <= NL && D::NS == 0;
         } else return false;
     }();
 };
@@ -2532,7 +2543,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_mass(const Ctx& c, Exec& 
             const float* aH = WF(aH);
             // pair weight: H[a][b] and H[b][a] are the same bilinear form (for a == b this gives the factor 2 of the quadratic form)
             if (c.d.flags & DSIM_F_RANGES) {
-                const int nsub = reinterpret_cast<const dsim_int_a*>(c.s)[c.o.linfo + 8 * la + 5];
+                const int nsub = reinterpret_cast<const dsim_int_a*>(c.k)[c.o.linfo + 8 * la + 5];
                 int b = CI(qdstart)[la + 1];
                 const int b1 = CI(qdstart)[la + nsub];
                 for (; b + 2 <= b1; b += 2) {

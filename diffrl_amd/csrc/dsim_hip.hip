@@ -73,6 +73,32 @@ template <int N, int NW> __device__ __forceinline__ void dsim_wave_gj(float* H) 
     }
 }
 
+// The same for two environments per wavefront (rows of the second one in lanes 32 ..): the pivot row travels through the LDS
+// crossbar (ds_bpermute), whose source lane may differ between the halves.
+template <int N> __device__ __forceinline__ void dsim_half_gj(float* H, int lane, int half_addr) {
+    const int r = lane < N ? lane : 0;
+    float row[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) row[j] = H[r * N + j];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int src = (k << 2) + half_addr;
+        const float piv = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(row[k])));
+        const float rp = 1.0f / piv;
+        const float cik = row[k];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float hkj = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(row[j])));
+            const float pj = (j == k ? 1.0f : hkj) * rp;
+            row[j] = (lane == k) ? pj : ((j == k ? 0.0f : row[j]) - cik * pj);
+        }
+    }
+    if (lane < N) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) H[lane * N + j] = row[j];
+    }
+}
+
 // The LDS image of one environment: [model constants | work arrays].  load(): the constants are copied from global memory
 // (16 bytes per lane and load: const_words is a multiple of 4, both sides are 16-byte aligned) and the work area starts
 // out as zeros, not as what the previous workgroup on this CU left behind: the weighted range sums (dsim_core.hpp:
@@ -82,10 +108,13 @@ template <int N, int NW> __device__ __forceinline__ void dsim_wave_gj(float* H) 
 // memory returns loads in the order they were issued: constants first (needed first), then the step's inputs.  CW is the
 // compile-time const_words of a specialised kernel (the constants wait in CW / 4 / lanes 16-byte registers) or 0 (generic
 // kernels: request() does nothing, land() copies).
-template <int NW, int CW> struct DsimImage {
+template <int NW, int CW, int EPW = 1> struct DsimImage {
     typedef float v4f __attribute__((ext_vector_type(4)));
-    static constexpr int NLW = DSIM_NL * NW, REGS = (CW / 4 + NLW - 1) / NLW;
-    float* lds;
+    static constexpr int NLW = DSIM_NL * NW / EPW, REGS = (CW / 4 + NLW - 1) / NLW;
+    // lane of this environment (EPW == 2: two environments per wavefront, 32 lanes each; `lds` then differs between the halves)
+    static __device__ __forceinline__ int lane_() { return EPW == 1 ? (int)threadIdx.x : (int)(threadIdx.x & (NLW - 1)); }
+    float* lds;    // where the constants go
+    float* work;   // image base of the work arrays (== lds, except for the second environment of a pair)
     const uint32_t* cblob;
     int const_words, image_words;   // image_words: forward kernels fwd_words, adjoint kernels total_words
     v4f regs[REGS > 0 ? REGS : 1];
@@ -94,7 +123,7 @@ template <int NW, int CW> struct DsimImage {
             const v4f* g = reinterpret_cast<const v4f*>(cblob);
 #pragma unroll
             for (int r = 0; r < REGS; ++r) {
-                const int i = (int)threadIdx.x + NLW * r;
+                const int i = lane_() + NLW * r;
                 if (i < CW / 4) regs[r] = g[i];
             }
         }
@@ -104,14 +133,15 @@ template <int NW, int CW> struct DsimImage {
         if constexpr (CW > 0) {
 #pragma unroll
             for (int r = 0; r < REGS; ++r) {
-                const int i = (int)threadIdx.x + NLW * r;
+                const int i = lane_() + NLW * r;
                 if (i < CW / 4) l[i] = regs[r];
             }
         } else {
             const v4f* g = reinterpret_cast<const v4f*>(cblob);
-            for (int i = threadIdx.x; i < const_words / 4; i += NLW) l[i] = g[i];
+            for (int i = lane_(); i < const_words / 4; i += NLW) l[i] = g[i];
         }
-        for (int i = const_words / 4 + threadIdx.x; i < image_words / 4; i += NLW) l[i] = v4f{0.f, 0.f, 0.f, 0.f};
+        v4f* w = reinterpret_cast<v4f*>(work);
+        for (int i = const_words / 4 + lane_(); i < image_words / 4; i += NLW) w[i] = v4f{0.f, 0.f, 0.f, 0.f};
     }
 };
 
@@ -130,7 +160,12 @@ template <int NW, int CW> struct DsimImage {
 // executor (helper wave and all), read back with dsim_debug_stamps.  clock64 is an SMEM read: it drains the wave's LDS queue.
 __device__ long long g_dsim_stamps[2 * 16384];
 #endif
-template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
+// EPW == 2: TWO environments per wavefront, 32 lanes each (launches far beyond one wave per SIMD, where the SIMDs are saturated
+// and every instruction of a wave whose phases use 9 .. 32 lanes is half wasted).  The phase code is the same: it sees NL = 32
+// lanes and an LDS image pointer that differs between the halves; the cross-lane primitives stay inside the half.
+template <int NW, int PF = 6, int CW = 0, bool HELPER = false, int EPW = 1> struct DevExec {
+    static_assert(EPW == 1 || (EPW == 2 && NW == 1 && !HELPER), "two environments per wavefront: one-wave mapping, no helper");
+    static constexpr int ENVS_PER_WAVE = EPW;
 #ifdef DSIM_STAMPS
     int stamp_i_ = 0, stamp_tag_ = 0;
     // main wave: entries [0, 8192), helper wave: [8192, 16384) (its tags + 50)
@@ -152,14 +187,16 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
     static_assert(!HELPER || NW == 1, "the helper wavefront belongs to the one-wave mapping");
     static constexpr bool HAS_HELPER = HELPER;
     const bool helper_ = HELPER && threadIdx.x >= DSIM_NL;
-    __device__ __forceinline__ int lane_() const { return HELPER ? (int)(threadIdx.x & (DSIM_NL - 1)) : (int)threadIdx.x; }
+    __device__ __forceinline__ int lane_() const { return (HELPER || EPW > 1) ? (int)(threadIdx.x & (NL - 1)) : (int)threadIdx.x; }
+    // first lane of this environment's half of the wave (EPW == 2), as a ds_bpermute byte address
+    const int half_addr_ = EPW > 1 ? (int)(threadIdx.x & (DSIM_NL / EPW)) << 2 : 0;
     // both waves: LDS operations of this wave done, workgroup barrier (no wait for global memory)
     __device__ __forceinline__ void group_barrier() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    static constexpr int NL = DSIM_NL * NW;
+    static constexpr int NL = DSIM_NL * NW / EPW;
     static constexpr int DSIM_PF = PF;
     // Cross-lane primitives of the wavefront (one wave per environment only): the phase code uses them for the small
     // point-to-point exchanges between lanes that would otherwise be an LDS store, a phase boundary and an LDS load.
@@ -169,11 +206,13 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
     // value of v in lane `src` (any lane): ds_bpermute_b32 -- the LDS crossbar, no LDS memory, no phase boundary.  All
     // lanes of the wave must execute it (uniform control flow); values of lanes that hold nothing meaningful are ignored.
     __device__ __forceinline__ float shfl(float v, int src) {
-        return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
+        return __int_as_float(__builtin_amdgcn_ds_bpermute((src << 2) + half_addr_, __float_as_int(v)));
     }
     // value of v in lane `src`, src uniform across the wave (a compile-time constant after unrolling): v_readlane_b32
+    // (two environments per wave: the source differs between the halves -- the crossbar again)
     __device__ __forceinline__ float bcast(float v, int src) {
-        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+        if constexpr (EPW > 1) return shfl(v, src);
+        else return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
     }
     // value of v in lane + D of the same 16-lane ROW (0 beyond the row's end, 0 from an inactive lane): a DPP row shift on the
     // operand -- VALU latency, no LDS, no SGPR.  Pinned on hardware by tools/micro/dpp_semantics.hip (row_shl:D, bound_ctrl on).
@@ -278,8 +317,8 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
             group_barrier();
             stamp();
         } else {
-            fm((int)threadIdx.x);
-            fh((int)threadIdx.x);
+            fm(lane_());
+            fh(lane_());
             sync();
         }
     }
@@ -300,8 +339,8 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
             group_barrier();
             stamp();
         } else {
-            fm((int)threadIdx.x);
-            fh((int)threadIdx.x);
+            fm(lane_());
+            fh(lane_());
             sync();
         }
     }
@@ -323,8 +362,8 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
             asm volatile("" ::: "memory");
             stamp();
         } else {
-            fm((int)threadIdx.x);
-            fh((int)threadIdx.x);
+            fm(lane_());
+            fh(lane_());
             sync();
         }
     }
@@ -344,9 +383,9 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
             asm volatile("" ::: "memory");
             stamp();
         } else {
-            fh((int)threadIdx.x);
+            fh(lane_());
             dsim_wave_sync();
-            fm((int)threadIdx.x);
+            fm(lane_());
             sync();
         }
     }
@@ -364,7 +403,7 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
     // begin(): the model constants arrive in LDS and the work area is cleared (see DsimImage).  The step functions call it
     // AFTER they have requested their own inputs from global memory (dsim_core.hpp: early loads), so that the launch
     // pays ONE memory latency for all of them instead of one per prologue phase.
-    DsimImage<NW, CW> img_;
+    DsimImage<NW, CW, EPW> img_;
     __device__ __forceinline__ void begin_request() {
         if (!helper_) img_.request();
     }
@@ -379,7 +418,8 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
     // Gauss-Jordan inverse of the N x N matrix at H (LDS, row-major), in place, by the first wavefront: lane i holds row i
     // in registers, the pivot row travels through v_readlane (dsim_core.hpp: dsim_fwd_mass has the formulas).
     template <int N> __device__ __forceinline__ void wave_gj(float* H) {
-        if (!helper_) dsim_wave_gj<N, NW>(H);
+        if constexpr (EPW > 1) dsim_half_gj<N>(H, lane_(), half_addr_);
+        else if (!helper_) dsim_wave_gj<N, NW>(H);
         sync();
     }
     // lane-private accumulators of the mass-matrix cotangent (dsim_core.hpp: DSIM_HACC_MAX registers per lane)
@@ -448,6 +488,18 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false> struct DevExec {
     }
 };
 
+// Launch modes of the step kernels: 0 one environment per workgroup of NW waves, 1 ... plus its helper wavefront, 2 TWO
+// environments per wavefront (DevExec EPW == 2): environment 2 b + h in half h of workgroup b's only wave, LDS images back to back
+// Minimum resident waves per SIMD the forward pair kernels are compiled for (0: no constraint).  Ant's env-step pair kernel
+// needs 173 VGPRs, five over the 168 of three waves per SIMD: compiled for three it spills those to scratch and the Ant 8192
+// rollout drops from 18.4 M to 17.4 M env-steps/s (profiles/r04_pair_ab.txt), so two waves per SIMD (16 environments per CU,
+// plain mapping: 12) it is.
+#ifndef DSIM_PAIR_WAVES
+#define DSIM_PAIR_WAVES 0
+#endif
+#define DSIM_MODE_PLAIN 0
+#define DSIM_MODE_HELPER 1
+#define DSIM_MODE_PAIR 2
 template <class O, class D> struct KCommonT {
     O o;
     D d;
@@ -469,95 +521,125 @@ template <class D, int NW> constexpr bool dsim_has_helper() {
     else return false;
 #endif
 }
-// f(lean, help) with the two launch-time choices as compile-time constants.  `help` is false for models without helper
+// models that get two-environments-per-wave kernels: specialised one-wave models whose phases fit 32 lanes
+template <class D, int NW> constexpr bool dsim_has_pair() {
+#ifdef DSIM_NO_PAIR
+    return false;
+#else
+    return NW == 1 && dsim_pair_ok<D>();
+#endif
+}
+// f(lean, mode) with the two launch-time choices as compile-time constants.  `help` is false for models without helper
 // kernels, so they instantiate nothing extra.
-template <class D, int NW, class F> int dsim_with_flags(bool lean, bool help, F&& f) {
+// FWD: a forward kernel.  Pair kernels exist for the forward direction only: the adjoint's LDS image (Ant 17 KB) caps the
+// environments per CU at the same 8 with either mapping, and a pair wave is 1.26 x as long as a plain one (measured,
+// profiles/r04_pair_ab.txt: Ant 8192 adjoint 0.287 ms plain, 0.349 ms pair; -DDSIM_PAIR_BWD builds them for A/B runs).
+template <class D, int NW, bool FWD, class F> int dsim_with_flags(bool lean, int mode, F&& f) {
+    using M0 = std::integral_constant<int, DSIM_MODE_PLAIN>;
+    using M1 = std::integral_constant<int, DSIM_MODE_HELPER>;
+    using M2 = std::integral_constant<int, DSIM_MODE_PAIR>;
     if constexpr (dsim_has_helper<D, NW>()) {
-        if (help) return lean ? f(std::true_type{}, std::true_type{}) : f(std::false_type{}, std::true_type{});
+        if (mode == DSIM_MODE_HELPER) return lean ? f(std::true_type{}, M1{}) : f(std::false_type{}, M1{});
     }
-    return lean ? f(std::true_type{}, std::false_type{}) : f(std::false_type{}, std::false_type{});
+#ifdef DSIM_PAIR_BWD
+    constexpr bool pair_dir = true;
+#else
+    constexpr bool pair_dir = FWD;
+#endif
+    if constexpr (dsim_has_pair<D, NW>() && pair_dir) {
+        if (mode == DSIM_MODE_PAIR) return lean ? f(std::true_type{}, M2{}) : f(std::false_type{}, M2{});
+    }
+    return lean ? f(std::true_type{}, M0{}) : f(std::false_type{}, M0{});
 }
 template <class O> constexpr int dsim_const_words() {
     if constexpr (std::is_empty<O>::value) return O::const_words;
     else return 0;
 }
-template <class O, int NW, bool LEAN> constexpr int dsim_pf_regs() {
+template <class O, int NW, bool LEAN, int MODE = 0> constexpr int dsim_pf_regs() {
     if constexpr (std::is_empty<O>::value) {
-        constexpr int words = LEAN ? O::xsc - O::q : O::save_words;
-        return (words / 4 + DSIM_NL * NW - 1) / (DSIM_NL * NW);
+        constexpr int words = LEAN ? O::xsc - O::q : O::save_words, lanes = DSIM_NL * NW / (MODE == 2 ? 2 : 1);
+        return (words / 4 + lanes - 1) / lanes;
     } else {
         return 6;
     }
 }
-// context of this workgroup's environment; the executor gets the image description and loads it in begin()
-template <bool LEAN, class Exec, class O, class D>
+template <int MODE> __device__ __forceinline__ int dsim_env_index() {
+    return MODE == DSIM_MODE_PAIR ? 2 * (int)blockIdx.x + (int)(threadIdx.x >> 5) : (int)blockIdx.x;
+}
+// context of this workgroup's environment; the executor gets the image description and loads it in begin().
+// A pair shares ONE copy of the model constants (Ant: 1096 of the forward image's 2332 words; each half loads it, same values
+// to the same words, so that a half without an environment -- odd n_envs -- may leave at once): [constants | work 0 | work 1].
+template <bool LEAN, int MODE, class Exec, class O, class D>
 __device__ __forceinline__ DsimCtxT<O, D, LEAN> start_env(float* lds, const KCommonT<O, D>& k, int image_words, Exec& ex) {
+    float* base = MODE == DSIM_MODE_PAIR ? lds + (threadIdx.x >> 5) * (image_words - k.o.const_words) : lds;
     ex.img_.lds = lds;
+    ex.img_.work = base;
     ex.img_.cblob = k.cblob;
     ex.img_.const_words = k.o.const_words;
     ex.img_.image_words = image_words;
     DsimCtxT<O, D, LEAN> c;
-    c.s = lds;
+    c.s = base;
+    c.k = lds;
     c.o = k.o;
     c.d = k.d;
     c.h = k.h;
     return c;
 }
 
-template <class O, class D, int NW, bool LEAN, bool HELP>
-__global__ __launch_bounds__((DSIM_NL * NW * (HELP ? 2 : 1))) void dsim_fwd_kernel(KCommonT<O, D> k, const float* __restrict__ q_in,
+template <class O, class D, int NW, bool LEAN, int MODE>
+__global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1)), (MODE == DSIM_MODE_PAIR ? DSIM_PAIR_WAVES : 0)) void dsim_fwd_kernel(KCommonT<O, D> k, const float* __restrict__ q_in,
                                                            const float* __restrict__ qd_in,
                                                            const float* __restrict__ act,
                                                            const float* __restrict__ mact, float* q_out,
                                                            float* qd_out, float* ckpt) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int e = blockIdx.x;
+    const int e = dsim_env_index<MODE>();
     if (e >= k.n_envs) return;
-    DevExec<NW, dsim_pf_regs<O, NW, LEAN>(), dsim_const_words<O>(), HELP> ex;
-    auto c = start_env<LEAN>(lds, k, k.o.fwd_words, ex);
+    DevExec<NW, dsim_pf_regs<O, NW, LEAN, MODE>(), dsim_const_words<O>(), MODE == 1, MODE == 2 ? 2 : 1> ex;
+    auto c = start_env<LEAN, MODE>(lds, k, k.o.fwd_words, ex);
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_sim_step_forward(c, ex, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, act + e * nd,
                           M ? mact + e * M : nullptr, q_out + e * nq, qd_out + e * nd,
                           ckpt ? ckpt + (size_t)e * k.ckpt_stride : nullptr, k.status, e);
 }
 
-template <class O, class D, int NW, bool LEAN, bool HELP>
-__global__ __launch_bounds__((DSIM_NL * NW * (HELP ? 2 : 1))) void dsim_bwd_kernel(KCommonT<O, D> k, const float* __restrict__ ckpt,
+template <class O, class D, int NW, bool LEAN, int MODE>
+__global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1))) void dsim_bwd_kernel(KCommonT<O, D> k, const float* __restrict__ ckpt,
                                                            const float* __restrict__ act,
                                                            const float* __restrict__ mact,
                                                            const float* __restrict__ gq_out,
                                                            const float* __restrict__ gqd_out, float* gq_in,
                                                            float* gqd_in, float* gact, float* gmact) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int e = blockIdx.x;
+    const int e = dsim_env_index<MODE>();
     if (e >= k.n_envs) return;
-    DevExec<NW, dsim_pf_regs<O, NW, LEAN>(), dsim_const_words<O>(), HELP> ex;
-    auto c = start_env<LEAN>(lds, k, k.o.total_words, ex);
+    DevExec<NW, dsim_pf_regs<O, NW, LEAN, MODE>(), dsim_const_words<O>(), MODE == 1, MODE == 2 ? 2 : 1> ex;
+    auto c = start_env<LEAN, MODE>(lds, k, k.o.total_words, ex);
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_sim_step_backward(c, ex, k.substeps, k.mm_freq, ckpt + (size_t)e * k.ckpt_stride, act + e * nd,
                            M ? mact + e * M : nullptr, gq_out + e * nq, gqd_out + e * nd, gq_in + e * nq,
                            gqd_in + e * nd, gact ? gact + e * nd : nullptr, (gmact && M) ? gmact + e * M : nullptr);
 }
 
-template <class O, class D, int NW, bool LEAN, bool HELP>
-__global__ __launch_bounds__((DSIM_NL * NW * (HELP ? 2 : 1))) void dsim_env_fwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp, DsimEpisode ep,
+template <class O, class D, int NW, bool LEAN, int MODE>
+__global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1)), (MODE == DSIM_MODE_PAIR ? DSIM_PAIR_WAVES : 0)) void dsim_env_fwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp, DsimEpisode ep,
                                                                const float* __restrict__ q_in,
                                                                const float* __restrict__ qd_in,
                                                                const float* __restrict__ actions, float* q_out,
                                                                float* qd_out, float* obs, float* rew, float* ckpt) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int e = blockIdx.x;
+    const int e = dsim_env_index<MODE>();
     if (e >= k.n_envs) return;
-    DevExec<NW, dsim_pf_regs<O, NW, LEAN>(), dsim_const_words<O>(), HELP> ex;
-    auto c = start_env<LEAN>(lds, k, k.o.fwd_words, ex);
+    DevExec<NW, dsim_pf_regs<O, NW, LEAN, MODE>(), dsim_const_words<O>(), MODE == 1, MODE == 2 ? 2 : 1> ex;
+    auto c = start_env<LEAN, MODE>(lds, k, k.o.fwd_words, ex);
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_forward(c, ex, sp, k.substeps, k.mm_freq, q_in + e * nq, qd_in + e * nd, actions + (size_t)e * sp.n_act,
                            q_out + e * nq, qd_out + e * nd, obs + (size_t)e * sp.n_obs, rew + e,
                            ckpt ? ckpt + (size_t)e * k.ckpt_stride : nullptr, ep, e, k.n_envs, k.status);
 }
 
-template <class O, class D, int NW, bool LEAN, bool HELP>
-__global__ __launch_bounds__((DSIM_NL * NW * (HELP ? 2 : 1))) void dsim_env_bwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp,
+template <class O, class D, int NW, bool LEAN, int MODE>
+__global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1))) void dsim_env_bwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp,
                                                                const float* __restrict__ ckpt,
                                                                const float* __restrict__ actions,
                                                                const float* __restrict__ gq_out,
@@ -567,10 +649,10 @@ __global__ __launch_bounds__((DSIM_NL * NW * (HELP ? 2 : 1))) void dsim_env_bwd_
                                                                const float* __restrict__ gobs_before, float* gq_in,
                                                                float* gqd_in, float* gactions) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int e = blockIdx.x;
+    const int e = dsim_env_index<MODE>();
     if (e >= k.n_envs) return;
-    DevExec<NW, dsim_pf_regs<O, NW, LEAN>(), dsim_const_words<O>(), HELP> ex;
-    auto c = start_env<LEAN>(lds, k, k.o.total_words, ex);
+    DevExec<NW, dsim_pf_regs<O, NW, LEAN, MODE>(), dsim_const_words<O>(), MODE == 1, MODE == 2 ? 2 : 1> ex;
+    auto c = start_env<LEAN, MODE>(lds, k, k.o.total_words, ex);
     const size_t nq = k.d.nq, nd = k.d.nd;
     dsim_env_fused_backward(c, ex, sp, k.substeps, k.mm_freq, ckpt + (size_t)e * k.ckpt_stride,
                             actions + (size_t)e * sp.n_act, gq_out ? gq_out + e * nq : nullptr,
@@ -590,6 +672,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_env_obs_kernel(KCommonT<O, 
     if (e >= k.n_envs) return;
     DsimCtxT<O, D> c;
     c.s = lds;
+    c.k = lds;
     c.o = k.o;
     c.d = k.d;
     c.h = k.h;
@@ -605,7 +688,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_body_xf_kernel(KCommonT<O, 
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
     DevExec<NW, 6, dsim_const_words<O>(), false> ex;
-    auto c = start_env<false>(lds, k, k.o.fwd_words, ex);
+    auto c = start_env<false, DSIM_MODE_PLAIN>(lds, k, k.o.fwd_words, ex);
     dsim_body_transforms_only(c, ex, q + (size_t)e * k.d.nq, xsc + (size_t)e * 7 * k.d.L, xsm ? xsm + (size_t)e * 7 * k.d.L : nullptr);
 }
 
@@ -722,7 +805,7 @@ __global__ __launch_bounds__(DSIM_NL * NW) void dsim_timer_kernel(KCommonT<O, D>
     const int e = blockIdx.x;
     if (e >= k.n_envs) return;
     TimingExec<NW> ex{stamps, 1, cap};
-    auto c = start_env<false>(lds, k, k.o.total_words, ex);
+    auto c = start_env<false, DSIM_MODE_PLAIN>(lds, k, k.o.total_words, ex);
     if (blockIdx.x == 0 && threadIdx.x == 0) stamps[0] = clock64();
     const size_t nq = k.d.nq, nd = k.d.nd;
     float* ck = ckpt + (size_t)e * k.ckpt_stride;
@@ -788,6 +871,18 @@ struct dsim_model {
     // number of environments in flight -- measured: Ant 8192 envs 13.4 M env-steps/s without, 8.1 M with.
     int helper_max_envs = 0;
     bool helper_ok(int n_envs) const { return n_envs <= helper_max_envs; }
+    // Two environments per wavefront (DSIM_MODE_PAIR; forward kernels of models with pair kernels only -- dsim_with_flags falls
+    // back to the plain kernels for the others): every launch beyond the helper-wave capacity.  A pair wave is a few per cent
+    // longer than a plain one (items beyond 32 lanes take two passes) and carries two environments: half the waves per launch,
+    // and a third more environments resident per CU (Ant: 16 instead of 12).  DSIM_PAIR=0 / 1 forces the choice (A/B runs).
+    int pair_min_envs = 1 << 30;
+    int mode(int n_envs, bool fwd) const {
+        if (helper_ok(n_envs)) return DSIM_MODE_HELPER;
+#ifndef DSIM_PAIR_BWD
+        if (!fwd) return DSIM_MODE_PLAIN;
+#endif
+        return n_envs >= pair_min_envs ? DSIM_MODE_PAIR : DSIM_MODE_PLAIN;
+    }
 };
 void dsim_helper_capacity(dsim_model* m);
 #ifndef DSIM_WAVES_WIDE
@@ -963,7 +1058,7 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
     if (e == hipSuccess) e = hipMalloc(&m->d_cblob, sizeof(uint32_t) * m->lay.cblob.size());
     if (e == hipSuccess)
         e = hipMemcpy(m->d_cblob, m->lay.cblob.data(), sizeof(uint32_t) * m->lay.cblob.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess && (bytes > 64 * 1024 || fbytes > 64 * 1024)) {
+    if (e == hipSuccess && (2 * bytes > 64 * 1024 || 2 * fbytes > 64 * 1024)) {   // (2 x: pair launches)
         // Opt in to > 64 KiB of dynamic LDS.  The attribute belongs to the kernel FUNCTION, not to this model: two models
         // that share a kernel variant (e.g. two user models on the generic kernels) must not lower each other's limit,
         // so it is set once to the hardware maximum (160 KiB); what a launch actually gets is its own byte count.
@@ -971,8 +1066,8 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
             using O = decltype(o);
             using D = decltype(d);
             constexpr int NW = decltype(nw)::value;
-            auto raise = [&](auto help_c) {
-                constexpr bool HELP = decltype(help_c)::value;
+            auto raise = [&](auto mode_c) {
+                constexpr int HELP = decltype(mode_c)::value;
                 const void* fns[] = {reinterpret_cast<const void*>(dsim_bwd_kernel<O, D, NW, false, HELP>),
                                      reinterpret_cast<const void*>(dsim_env_bwd_kernel<O, D, NW, false, HELP>),
                                      reinterpret_cast<const void*>(dsim_fwd_kernel<O, D, NW, false, HELP>),
@@ -984,8 +1079,16 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
                 for (const void* fn : fns)
                     if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             };
-            raise(std::false_type{});
-            if constexpr (dsim_has_helper<D, NW>()) raise(std::true_type{});
+            raise(std::integral_constant<int, DSIM_MODE_PLAIN>{});
+            if constexpr (dsim_has_helper<D, NW>()) raise(std::integral_constant<int, DSIM_MODE_HELPER>{});
+            if constexpr (dsim_has_pair<D, NW>()) {
+                const void* fns[] = {reinterpret_cast<const void*>(dsim_fwd_kernel<O, D, NW, false, DSIM_MODE_PAIR>),
+                                     reinterpret_cast<const void*>(dsim_env_fwd_kernel<O, D, NW, false, DSIM_MODE_PAIR>),
+                                     reinterpret_cast<const void*>(dsim_fwd_kernel<O, D, NW, true, DSIM_MODE_PAIR>),
+                                     reinterpret_cast<const void*>(dsim_env_fwd_kernel<O, D, NW, true, DSIM_MODE_PAIR>)};
+                for (const void* fn : fns)
+                    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            }
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsim_env_obs_kernel<O, D, NW>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1023,18 +1126,22 @@ void dsim_helper_capacity(dsim_model* m) {
                 ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 2 * DSIM_NL, (size_t)words * 4) == hipSuccess;
                 if (n < per_cu) per_cu = n;
             };
-            cap(dsim_env_bwd_kernel<O, D, NW, false, true>, m->lay.o.total_words);
-            cap(dsim_env_fwd_kernel<O, D, NW, false, true>, m->lay.o.fwd_words);
-            cap(dsim_bwd_kernel<O, D, NW, false, true>, m->lay.o.total_words);
-            cap(dsim_fwd_kernel<O, D, NW, false, true>, m->lay.o.fwd_words);
+            cap(dsim_env_bwd_kernel<O, D, NW, false, DSIM_MODE_HELPER>, m->lay.o.total_words);
+            cap(dsim_env_fwd_kernel<O, D, NW, false, DSIM_MODE_HELPER>, m->lay.o.fwd_words);
+            cap(dsim_bwd_kernel<O, D, NW, false, DSIM_MODE_HELPER>, m->lay.o.total_words);
+            cap(dsim_fwd_kernel<O, D, NW, false, DSIM_MODE_HELPER>, m->lay.o.fwd_words);
             if (m->lean) {   // (the mode is chosen right after creation; dsim_model_set_ckpt_mode re-evaluates)
-                cap(dsim_env_bwd_kernel<O, D, NW, true, true>, m->lay.o.total_words);
-                cap(dsim_env_fwd_kernel<O, D, NW, true, true>, m->lay.o.fwd_words);
-                cap(dsim_bwd_kernel<O, D, NW, true, true>, m->lay.o.total_words);
-                cap(dsim_fwd_kernel<O, D, NW, true, true>, m->lay.o.fwd_words);
+                cap(dsim_env_bwd_kernel<O, D, NW, true, DSIM_MODE_HELPER>, m->lay.o.total_words);
+                cap(dsim_env_fwd_kernel<O, D, NW, true, DSIM_MODE_HELPER>, m->lay.o.fwd_words);
+                cap(dsim_bwd_kernel<O, D, NW, true, DSIM_MODE_HELPER>, m->lay.o.total_words);
+                cap(dsim_fwd_kernel<O, D, NW, true, DSIM_MODE_HELPER>, m->lay.o.fwd_words);
             }
             m->helper_max_envs = ok ? cus * per_cu : 0;
             if (const char* f = getenv("DSIM_HELPER")) m->helper_max_envs = atoi(f) ? (1 << 30) : 0;
+        }
+        if constexpr (dsim_has_pair<D, NW>()) {
+            m->pair_min_envs = 0;
+            if (const char* f = getenv("DSIM_PAIR")) m->pair_min_envs = atoi(f) ? 0 : (1 << 30);
         }
         return 0;
     });
@@ -1087,10 +1194,11 @@ int dsim_step_forward(const dsim_model* m, int n_envs, const float* q_in, const 
     return dispatch(m, [&](auto o, auto d, auto nw) {
         constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        dsim_with_flags<decltype(d), NW>(m->lean, m->helper_ok(n_envs), [&](auto lean_c, auto help_c) {
-            constexpr bool LEAN = decltype(lean_c)::value, HELP = decltype(help_c)::value;
-            hipLaunchKernelGGL((dsim_fwd_kernel<decltype(o), decltype(d), NW, LEAN, HELP>), dim3(n_envs), dim3(DSIM_NL * NW * (HELP ? 2 : 1)),
-                           (size_t)m->lay.o.fwd_words * 4, st, k, q_in, qd_in, act, muscle_act, q_out, qd_out, ckpt);
+        dsim_with_flags<decltype(d), NW, true>(m->lean, m->mode(n_envs, true), [&](auto lean_c, auto mode_c) {
+            constexpr bool LEAN = decltype(lean_c)::value;
+            constexpr int MODE = decltype(mode_c)::value, EPB = MODE == DSIM_MODE_PAIR ? 2 : 1;
+            hipLaunchKernelGGL((dsim_fwd_kernel<decltype(o), decltype(d), NW, LEAN, MODE>), dim3((n_envs + EPB - 1) / EPB),
+                           dim3(DSIM_NL * NW * (MODE == DSIM_MODE_HELPER ? 2 : 1)), ((size_t)m->lay.o.fwd_words * EPB - (size_t)m->lay.o.const_words * (EPB - 1)) * 4, st, k, q_in, qd_in, act, muscle_act, q_out, qd_out, ckpt);
             return 0;
         });
         return launched("launch dsim_fwd_kernel");
@@ -1109,10 +1217,11 @@ int dsim_step_backward(const dsim_model* m, int n_envs, const float* ckpt, const
     return dispatch(m, [&](auto o, auto d, auto nw) {
         constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        dsim_with_flags<decltype(d), NW>(m->lean, m->helper_ok(n_envs), [&](auto lean_c, auto help_c) {
-            constexpr bool LEAN = decltype(lean_c)::value, HELP = decltype(help_c)::value;
-            hipLaunchKernelGGL((dsim_bwd_kernel<decltype(o), decltype(d), NW, LEAN, HELP>), dim3(n_envs), dim3(DSIM_NL * NW * (HELP ? 2 : 1)),
-                           (size_t)m->lay.o.total_words * 4, st, k, ckpt, act, muscle_act, gq_out, gqd_out, gq_in, gqd_in,
+        dsim_with_flags<decltype(d), NW, false>(m->lean, m->mode(n_envs, false), [&](auto lean_c, auto mode_c) {
+            constexpr bool LEAN = decltype(lean_c)::value;
+            constexpr int MODE = decltype(mode_c)::value, EPB = MODE == DSIM_MODE_PAIR ? 2 : 1;
+            hipLaunchKernelGGL((dsim_bwd_kernel<decltype(o), decltype(d), NW, LEAN, MODE>), dim3((n_envs + EPB - 1) / EPB),
+                           dim3(DSIM_NL * NW * (MODE == DSIM_MODE_HELPER ? 2 : 1)), ((size_t)m->lay.o.total_words * EPB - (size_t)m->lay.o.const_words * (EPB - 1)) * 4, st, k, ckpt, act, muscle_act, gq_out, gqd_out, gq_in, gqd_in,
                            gact, gmuscle_act);
             return 0;
         });
@@ -1155,10 +1264,11 @@ int dsim_env_step_forward(const dsim_model* m, const dsim_env_spec* env, int n_e
     return dispatch(m, [&](auto o, auto d, auto nw) {
         constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        dsim_with_flags<decltype(d), NW>(m->lean, m->helper_ok(n_envs), [&](auto lean_c, auto help_c) {
-            constexpr bool LEAN = decltype(lean_c)::value, HELP = decltype(help_c)::value;
-            hipLaunchKernelGGL((dsim_env_fwd_kernel<decltype(o), decltype(d), NW, LEAN, HELP>), dim3(n_envs), dim3(DSIM_NL * NW * (HELP ? 2 : 1)),
-                           (size_t)m->lay.o.fwd_words * 4, st, k, sp, ep, q_in, qd_in, actions, q_out, qd_out, obs, rew,
+        dsim_with_flags<decltype(d), NW, true>(m->lean, m->mode(n_envs, true), [&](auto lean_c, auto mode_c) {
+            constexpr bool LEAN = decltype(lean_c)::value;
+            constexpr int MODE = decltype(mode_c)::value, EPB = MODE == DSIM_MODE_PAIR ? 2 : 1;
+            hipLaunchKernelGGL((dsim_env_fwd_kernel<decltype(o), decltype(d), NW, LEAN, MODE>), dim3((n_envs + EPB - 1) / EPB),
+                           dim3(DSIM_NL * NW * (MODE == DSIM_MODE_HELPER ? 2 : 1)), ((size_t)m->lay.o.fwd_words * EPB - (size_t)m->lay.o.const_words * (EPB - 1)) * 4, st, k, sp, ep, q_in, qd_in, actions, q_out, qd_out, obs, rew,
                            ckpt);
             return 0;
         });
@@ -1180,10 +1290,11 @@ int dsim_env_step_backward(const dsim_model* m, const dsim_env_spec* env, int n_
     return dispatch(m, [&](auto o, auto d, auto nw) {
         constexpr int NW = decltype(nw)::value;
         auto k = make_k(m, o, d, n_envs, dt, substeps, mm_freq);
-        dsim_with_flags<decltype(d), NW>(m->lean, m->helper_ok(n_envs), [&](auto lean_c, auto help_c) {
-            constexpr bool LEAN = decltype(lean_c)::value, HELP = decltype(help_c)::value;
-            hipLaunchKernelGGL((dsim_env_bwd_kernel<decltype(o), decltype(d), NW, LEAN, HELP>), dim3(n_envs), dim3(DSIM_NL * NW * (HELP ? 2 : 1)),
-                           (size_t)m->lay.o.total_words * 4, st, k, sp, ckpt, actions, gq_out, gqd_out, gobs, grew,
+        dsim_with_flags<decltype(d), NW, false>(m->lean, m->mode(n_envs, false), [&](auto lean_c, auto mode_c) {
+            constexpr bool LEAN = decltype(lean_c)::value;
+            constexpr int MODE = decltype(mode_c)::value, EPB = MODE == DSIM_MODE_PAIR ? 2 : 1;
+            hipLaunchKernelGGL((dsim_env_bwd_kernel<decltype(o), decltype(d), NW, LEAN, MODE>), dim3((n_envs + EPB - 1) / EPB),
+                           dim3(DSIM_NL * NW * (MODE == DSIM_MODE_HELPER ? 2 : 1)), ((size_t)m->lay.o.total_words * EPB - (size_t)m->lay.o.const_words * (EPB - 1)) * 4, st, k, sp, ckpt, actions, gq_out, gqd_out, gobs, grew,
                            gobs_before_reset, gq_in, gqd_in, gactions);
             return 0;
         });

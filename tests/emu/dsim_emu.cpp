@@ -21,8 +21,10 @@
 // kernels use them: a lane that reaches a collective deposits its value and yields; once every lane still running has
 // arrived, each continues with the value of its source lane.  Four wavefronts: plain lane-serial execution, no
 // cross-lane primitives (the kernels have none across wavefronts either; WAVE_OPS is false).
-template <int NW> struct HostExecT {
-    static constexpr int NL = DSIM_NL * NW;
+// LANES == 32: the lane count the phase code sees when TWO environments share a wavefront (dsim_hip.hip: DSIM_MODE_PAIR,
+// DevExec EPW == 2) -- every variant choice that depends on Exec::NL is then the pair kernels'.
+template <int NW, int LANES = DSIM_NL> struct HostExecT {
+    static constexpr int NL = LANES * NW;
     static constexpr bool WAVE_OPS = NW == 1;
     static constexpr size_t STACK = 512 * 1024;
     ucontext_t main_ctx_, lane_ctx_[NL];
@@ -74,7 +76,7 @@ template <int NW> struct HostExecT {
     }
     // a phase of the environment's FIRST wavefront alone (device: DevExec::run_wave0), with its cross-lane primitives
     static constexpr bool WAVE0_OPS = true;
-    template <class F> void run_wave0(F&& f) { run_coro(f, DSIM_NL); }
+    template <class F> void run_wave0(F&& f) { run_coro(f, LANES); }
     // collectives (only meaningful inside run(), NW == 1).  Every lane that is still running must call the same sequence.
     void arrive() {
         const int lane = cur_;
@@ -182,11 +184,13 @@ extern "C" void dsim_emu_set_ckpt_lean(int on) { g_lean = on; }
 static int emu_row(const DsimLayout& lay) { return g_lean ? lay.o.xsc - lay.o.q : lay.o.save_words; }
 static int g_waves = 1;
 extern "C" void dsim_emu_set_waves(int w) { g_waves = w > 1 ? 4 : 1; }
+static int g_half = 0;   // 32 lanes per environment (specialised one-wave variants only: the pair kernels)
+extern "C" void dsim_emu_set_half_wave(int on) { g_half = on; }
 
 static void make_ctx(const DsimLayout& lay, std::vector<float>& lds, DsimCtx& c, float h) {
     lds.assign(lay.o.total_words, 0.f);
     memcpy(lds.data(), lay.cblob.data(), sizeof(uint32_t) * lay.o.const_words);
-    c.s = lds.data();
+    c.s = lds.data(); c.k = c.s;
     c.o = lay.o;
     c.d = lay.d;
     c.h = h;
@@ -288,6 +292,13 @@ template <class F, class O, class D> static int emu_waves(F&& f, O o, D d) {
         static HostExecT<4> ex4;
         return g_lean ? f(o, d, ex4, std::true_type{}) : f(o, d, ex4, std::false_type{});
     }
+    if constexpr (dsim_pair_ok<D>()) {
+        if (g_half) {
+            static HostExecT<1, 32> exh;
+            return g_lean ? f(o, d, exh, std::true_type{}) : f(o, d, exh, std::false_type{});
+        }
+    }
+    if (g_half) return -3;   // no pair kernels for this model
     static HostExecT<1> ex1;
     return g_lean ? f(o, d, ex1, std::true_type{}) : f(o, d, ex1, std::false_type{});
 }
@@ -333,7 +344,7 @@ extern "C" int dsim_emu_env_forward(const dsim_model_desc* m, const dsim_env_spe
             std::vector<float> lds(lay.o.total_words, 0.f);
             memcpy(lds.data(), lay.cblob.data(), sizeof(uint32_t) * lay.o.const_words);
             DsimCtxT<decltype(o), decltype(d), decltype(lean)::value> c;
-            c.s = lds.data(); c.o = o; c.d = d; c.h = dt / float(substeps);
+            c.s = lds.data(); c.k = c.s; c.o = o; c.d = d; c.h = dt / float(substeps);
             dsim_env_fused_forward(c, ex, sp, substeps, mm_freq, q_in + (size_t)e * nq, qd_in + (size_t)e * nd,
                                    actions + (size_t)e * sp.n_act, q_out + (size_t)e * nq, qd_out + (size_t)e * nd,
                                    obs + (size_t)e * sp.n_obs, rew + e, ckpt ? ckpt + (size_t)e * stride : nullptr, ep, e,
@@ -357,7 +368,7 @@ extern "C" int dsim_emu_env_backward(const dsim_model_desc* m, const dsim_env_sp
             std::vector<float> lds(lay.o.total_words, 0.f);
             memcpy(lds.data(), lay.cblob.data(), sizeof(uint32_t) * lay.o.const_words);
             DsimCtxT<decltype(o), decltype(d), decltype(lean)::value> c;
-            c.s = lds.data(); c.o = o; c.d = d; c.h = dt / float(substeps);
+            c.s = lds.data(); c.k = c.s; c.o = o; c.d = d; c.h = dt / float(substeps);
             dsim_env_fused_backward(c, ex, sp, substeps, mm_freq, ckpt + (size_t)e * stride,
                                     actions + (size_t)e * sp.n_act, gq_out ? gq_out + (size_t)e * nq : nullptr,
                                     gqd_out ? gqd_out + (size_t)e * nd : nullptr,

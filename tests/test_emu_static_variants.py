@@ -124,3 +124,45 @@ def test_lean_checkpoint_mode_gives_identical_gradients(env):
     for x, y in zip(out[1][0] + out[1][1], out[0][0] + out[0][1]):
         np.testing.assert_allclose(x, y, rtol=0, atol=0)
     assert words[1] < 0.2 * words[0]
+
+
+@pytest.mark.parametrize("env", ["cartpole", "ant", "hopper", "cheetah"])
+def test_pair_kernels_lane_count_is_bit_identical(env, static_mode):
+    """Two environments per wavefront (dsim_hip.hip: DSIM_MODE_PAIR): the phase code then sees 32 lanes per environment, and
+    every variant choice that depends on Exec::NL is made anew.  The forward -- the direction that ships pair kernels -- must
+    give the bits of the 64-lane kernels (state, observations, reward, checkpoint); the adjoint phases, instantiated for A/B
+    builds only, may re-order sums."""
+    t = template_from_golden(env)
+    g = golden(env + "_rollout")
+    spec, keep = env_spec_for(env, t)
+    S, mm, dt = SUBSTEPS[env], int(g["mm_freq"]), 1.0 / 60.0
+    n = min(2, g["q0"].shape[0])
+    q, qd, a = g["q0"][:n], g["qd0"][:n], g["actions"][0][:n]
+    rng = np.random.default_rng(0)
+    cot = [rng.normal(size=x.shape).astype(np.float32) for x in (q, qd)]
+    gobs, grew = rng.normal(size=(n, spec.n_obs)).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    out = {}
+    try:
+        for half in (0, 1):
+            emu().dsim_emu_set_half_wave(half)
+            f = emu_env_forward(t, spec, q, qd, a, dt, S, mm)
+            b = emu_env_backward(t, spec, f[4], a, dt, S, mm, cot[0], cot[1], gobs, grew)
+            out[half] = (f, b)
+    finally:
+        emu().dsim_emu_set_half_wave(0)
+    for x, y in zip(out[1][0], out[0][0]):
+        np.testing.assert_array_equal(x, y)
+    for x, y in zip(out[1][1], out[0][1]):
+        assert np.abs(x - y).max() <= 2e-5 * max(np.abs(y).max(), 1e-6)
+
+
+def test_models_beyond_32_lanes_have_no_pair_kernels(static_mode):
+    t = template_from_golden("humanoid")
+    g = golden("humanoid_rollout")
+    spec, keep = env_spec_for("humanoid", t)
+    emu().dsim_emu_set_half_wave(1)
+    try:
+        with pytest.raises(AssertionError):
+            emu_env_forward(t, spec, g["q0"][:1], g["qd0"][:1], g["actions"][0][:1], 1 / 60, 48, 48)
+    finally:
+        emu().dsim_emu_set_half_wave(0)

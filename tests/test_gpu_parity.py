@@ -237,6 +237,53 @@ def test_helper_wave_kernels_match_single_wave(env, dev, monkeypatch):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("env", ["ant", "hopper", "cheetah", "cartpole"])
+def test_pair_kernels_match_one_environment_per_wave(env, dev, monkeypatch):
+    """Launches beyond the helper-wave capacity run the FORWARD of the models that fit 32 lanes with two environments per
+    wavefront (dsim_hip.hip: DSIM_MODE_PAIR; DSIM_PAIR=0 / 1 forces the choice).  Bit-identical per environment to the
+    one-environment kernels -- state, observations, rewards, and the gradients the (always one-environment) adjoint computes
+    from the checkpoint the pair kernel wrote -- with an odd number of environments (the last wave carries one)."""
+    from diffrl_amd import envs as E
+    from diffrl_amd.engine import Engine
+    t = template_from_golden(env)
+    g = golden(env + "_step")
+    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
+    monkeypatch.setenv("DSIM_HELPER", "0")
+    n = 67
+    reps = n // g["q_in"].shape[0] + 1
+    tile = lambda a: np.ascontiguousarray(np.tile(a, (reps, 1))[:n])
+    rng = np.random.default_rng(5)
+    q, qd, act = tile(g["q_in"]), tile(g["qd_in"]), tile(g["act_in"])
+    act = (act + 0.1 * rng.normal(size=act.shape)).astype(np.float32)     # (every environment its own trajectory)
+    gq, gqd = rng.normal(size=q.shape).astype(np.float32), rng.normal(size=qd.shape).astype(np.float32)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DSIM_PAIR", mode)
+        eng = Engine(t, dev)
+        out[mode] = _run(eng, dev, q, qd, act, None, dt, S, mm, gq, gqd)
+    for k in ("q", "qd", "gq", "gqd", "gact"):
+        assert np.isfinite(out["1"][k]).all() and np.array_equal(out["1"][k], out["0"][k]), k
+    r = out["1"]
+    assert relerr(r["q"][:g["q_in"].shape[0]], out["0"]["q"][:g["q_in"].shape[0]]) == 0
+    cls = {"ant": E.AntEnv, "hopper": E.HopperEnv, "cheetah": E.CheetahEnv, "cartpole": E.CartPoleSwingUpEnv}[env]
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DSIM_PAIR", mode)
+        e = cls(num_envs=65, device="cuda:0", no_grad=False, stochastic_init=True, seed=7)
+        e.reset()
+        e.initialize_trajectory()
+        torch.manual_seed(3)
+        a = torch.randn((4, 65, e.num_actions), device=dev).tanh().requires_grad_(True)
+        tot = 0.0
+        for s in range(4):
+            obs, rew, done, info = e.step(a[s])
+            tot = tot - rew.sum() + 0.01 * obs.sum()
+        tot.backward()
+        res[mode] = (obs.detach().cpu().numpy(), rew.detach().cpu().numpy(), a.grad.cpu().numpy())
+    for x, y in zip(res["1"], res["0"]):
+        assert np.isfinite(x).all() and np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("env", ["ant", "humanoid", "snu"])
 def test_lean_checkpoint_mode(env, dev):
     """DSIM_CKPT_LEAN (include/dsim.h): rows of (q, qd) only, the adjoint launch recomputes the forward phases -- identical

@@ -42,3 +42,14 @@ def test_helper_kernels_fit_two_waves_per_simd(kernels):
     # dsim_model_create then finds fewer resident workgroups and the launches fall back to the single-wave kernels
     over = [(short(k["name"]), k["vgpr_count"]) for k in helpers if k["vgpr_count"] + k.get("agpr_count", 0) > 256 and ", lean" not in short(k["name"])]
     assert not over, over
+
+
+def test_pair_forward_kernels_exist_for_the_32_lane_models(kernels):
+    """two environments per wavefront (dsim_hip.hip: DSIM_MODE_PAIR): forward kernels of Ant / Hopper / HalfCheetah / CartPole,
+    none for the adjoint (its LDS image caps the environments per CU either way) and none for the bigger models"""
+    from kernel_meta import short
+    pair = [short(k["name"]) for k in kernels if ", pair" in short(k["name"])]
+    for model in ("Ant", "Hopper", "Cheetah", "Cartpole"):
+        for kn in ("dsim_fwd_kernel", "dsim_env_fwd_kernel"):
+            assert any(p.startswith("%s<%s," % (kn, model)) for p in pair), (kn, model, pair)
+    assert not any("bwd" in p or "Humanoid" in p or "Snu" in p for p in pair), pair

@@ -32,11 +32,11 @@ def kernels(lib):
 
 
 def short(name):
-    m = re.search(r"(dsim_\w+_kernel)I\d+DsimOff(\w*?)\d+DsimDims\w*?Li(\d)(?:ELb(\d))?(?:ELb(\d))?", name)
+    m = re.search(r"(dsim_\w+_kernel)I\d+DsimOff(\w*?)\d+DsimDims\w*?Li(\d)(?:ELb(\d))?(?:EL[bi](\d))?", name)
     if not m:
         return name[:50]
     return "%s<%s, waves %s%s%s>" % (m.group(1), m.group(2) or "generic", m.group(3), ", lean" if m.group(4) == "1" else "",
-                                     ", helper" if m.group(5) == "1" else "")
+                                     {"1": ", helper", "2": ", pair"}.get(m.group(5), ""))
 
 
 if __name__ == "__main__":
