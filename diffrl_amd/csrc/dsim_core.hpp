@@ -2063,6 +2063,7 @@ DSIM_FN void dsim_body_transforms_only(const Ctx& c, Exec& ex, const float* g_q,
 // `lane + 64 m` never leaves its lane) and writes them to LDS once, at the refresh substep, for the mass-matrix adjoint.
 // The LDS read-modify-write it replaces was a chain of dependent round trips in every substep.
 #define DSIM_HACC_MAX 12
+#define DSIM_HPF_MAX 8    // registers per lane of the inverse requested ahead of the adjoint's first substep (Exec::hpf)
 template <class Ctx> struct DsimHaccRegs {
     static constexpr bool value = DsimIsStatic<Ctx>::value;
 };
@@ -3744,6 +3745,45 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
         });
         return;
     }
+    // The inverse of the LAST group of substeps (the first the adjoint needs) is requested here and stored to LDS at the first
+    // substep: its memory latency (measured: 2.4 k cycles of the Ant adjoint launch when loaded on the spot) passes under the
+    // observation adjoint, whose serial quaternion chain on one lane needs no memory at all.
+    const int groups = (substeps + mm_freq - 1) / mm_freq;
+    constexpr int HPF = []() {
+        if constexpr (IO::PRE) {
+            constexpr int need = (decltype(c.d)::nd * decltype(c.d)::nd + Exec::NL - 1) / Exec::NL;
+            return need <= DSIM_HPF_MAX ? need : 0;
+        } else {
+            return 0;
+        }
+    }();
+    if constexpr (HPF > 0) {
+        const float* hv = dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, groups - 1);
+        ex.fire([&](int lane) {
+            float* hpf = ex.hpf(lane);
+#pragma unroll
+            for (int r = 0; r < HPF; ++r) hpf[r] = hv[(lane + Exec::NL * r) < nd * nd ? lane + Exec::NL * r : 0];
+        });
+    }
+    // hinv <- the group's inverse, aH <- 0 (from the registers above for the last group)
+    auto load_hinv = [&](int lane, const float* hv, int g) __attribute__((always_inline)) {
+        if (HPF > 0 && g == groups - 1) {
+            const float* hpf = ex.hpf(lane);
+#pragma unroll
+            for (int r = 0; r < HPF; ++r) {
+                const int k = lane + Exec::NL * r;
+                if (k < nd * nd) {
+                    WF(hinv)[k] = hpf[r];
+                    WF(aH)[k] = 0.f;
+                }
+            }
+        } else {
+            for (int k = lane; k < nd * nd; k += Exec::NL) {
+                WF(hinv)[k] = hv[k];
+                WF(aH)[k] = 0.f;
+            }
+        }
+    };
     dsim_init_static(c, ex);
     ex.run_both([&](int lane) { dsim_topo_init(c, ex, lane); });   // every wave keeps its own topology records
     ex.run([&](int lane) {
@@ -3771,7 +3811,6 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
     });
     dsim_env_load_actions(c, ex, sp, g_actions, true);
     dsim_env_observe_adjoint(c, ex, sp, g_gobs, g_grew, g_gobs_before, ep_flags, true);
-    const int groups = (substeps + mm_freq - 1) / mm_freq;
     for (int g = groups - 1; g >= 0; --g) {
         const int s0 = g * mm_freq, s1 = (s0 + mm_freq < substeps) ? s0 + mm_freq : substeps;
         for (int s = s1 - 1; s >= s0; --s) {
@@ -3785,10 +3824,7 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
                 ex.helper_commit(WF(q), dsim_row(c), s > 0 ? g_ckpt + (size_t)(s - 1) * dsim_row(c) : nullptr);
                 if (hv)
                     ex.run([&](int lane) {
-                        for (int k = lane; k < nd * nd; k += Exec::NL) {
-                            WF(hinv)[k] = hv[k];
-                            WF(aH)[k] = 0.f;
-                        }
+                        load_hinv(lane, hv, g);
                         dsim_hacc_zero(c, ex, lane);
                     });
             } else {
@@ -3796,10 +3832,7 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
                 ex.run([&](int lane) {
                     ex.commit(WF(q), dsim_row(c), lane);
                     if (hv) {
-                        for (int k = lane; k < nd * nd; k += Exec::NL) {
-                            WF(hinv)[k] = hv[k];
-                            WF(aH)[k] = 0.f;
-                        }
+                        load_hinv(lane, hv, g);
                         dsim_hacc_zero(c, ex, lane);
                     }
                 });

@@ -425,6 +425,8 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false, int EPW = 1> stru
     // lane-private accumulators of the mass-matrix cotangent (dsim_core.hpp: DSIM_HACC_MAX registers per lane)
     float hacc_[DSIM_HACC_MAX];
     __device__ __forceinline__ float* hacc(int) { return hacc_; }
+    float hpf_[DSIM_HPF_MAX];
+    __device__ __forceinline__ float* hpf(int) { return hpf_; }
     // per-lane topology records (dsim_core.hpp: DsimTopoRegs, dsim_topo_init)
     DsimTopoRegs topo_;
     __device__ __forceinline__ DsimTopoRegs& topo(int) { return topo_; }
@@ -786,6 +788,8 @@ template <int NW> struct TimingExec {
     }
     float hacc_[DSIM_HACC_MAX];
     __device__ __forceinline__ float* hacc(int) { return hacc_; }
+    float hpf_[DSIM_HPF_MAX];
+    __device__ __forceinline__ float* hpf(int) { return hpf_; }
     DsimTopoRegs topo_;
     __device__ __forceinline__ DsimTopoRegs& topo(int) { return topo_; }
     const float* pf_src;

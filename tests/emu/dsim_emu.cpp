@@ -170,6 +170,8 @@ template <int NW, int LANES = DSIM_NL> struct HostExecT {
     float* io(int lane) { return io_[lane]; }
     float hacc_[NL][DSIM_HACC_MAX];  // what a lane keeps in registers across phases on the GPU
     float* hacc(int lane) { return hacc_[lane]; }
+    float hpf_[NL][DSIM_HPF_MAX];
+    float* hpf(int lane) { return hpf_[lane]; }
     DsimTopoRegs topo_[NL];
     DsimTopoRegs& topo(int lane) { return topo_[lane]; }
     const float* pf_src = nullptr;
