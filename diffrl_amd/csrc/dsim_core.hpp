@@ -3730,8 +3730,11 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
             dsim_io_fetch<IO::CO, Exec::NL>(io + IO::GOBSB, g_gobs_before, sp.n_obs, lane);
             io[IO::GREW] = g_grew ? g_grew[0] : 0.f;
         });
-        if constexpr (DsimHelperCommit<Ctx, Exec>::value) ex.helper_prefetch(g_ckpt + (size_t)(substeps - 1) * dsim_row(c), dsim_row(c));
-        else ex.prefetch(g_ckpt + (size_t)(substeps - 1) * dsim_row(c), dsim_row(c));
+        if constexpr (DsimHelperCommit<Ctx, Exec>::value) {
+            ex.helper_prefetch(g_ckpt + (size_t)(substeps - 1) * dsim_row(c), dsim_row(c));
+        } else {
+            ex.prefetch(g_ckpt + (size_t)(substeps - 1) * dsim_row(c), dsim_row(c));
+        }
     }
     ex.begin();
     if (ep_flags == DSIM_EP_INVALID) {
@@ -3750,7 +3753,9 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
     // observation adjoint, whose serial quaternion chain on one lane needs no memory at all.
     const int groups = (substeps + mm_freq - 1) / mm_freq;
     constexpr int HPF = []() {
-        if constexpr (IO::PRE) {
+        if constexpr (DsimHelperCommit<Ctx, Exec>::value) {
+            return 0;   // (the helper wavefront brings it: helper_prefetch_aux above)
+        } else if constexpr (IO::PRE) {
             constexpr int need = (decltype(c.d)::nd * decltype(c.d)::nd + Exec::NL - 1) / Exec::NL;
             return need <= DSIM_HPF_MAX ? need : 0;
         } else {
@@ -3765,27 +3770,20 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
             for (int r = 0; r < HPF; ++r) hpf[r] = hv[(lane + Exec::NL * r) < nd * nd ? lane + Exec::NL * r : 0];
         });
     }
-    // hinv <- the group's inverse, aH <- 0 (from the registers above for the last group)
-    auto load_hinv = [&](int lane, const float* hv, int g) __attribute__((always_inline)) {
-        if (HPF > 0 && g == groups - 1) {
-            const float* hpf = ex.hpf(lane);
-#pragma unroll
-            for (int r = 0; r < HPF; ++r) {
-                const int k = lane + Exec::NL * r;
-                if (k < nd * nd) {
-                    WF(hinv)[k] = hpf[r];
-                    WF(aH)[k] = 0.f;
-                }
-            }
-        } else {
-            for (int k = lane; k < nd * nd; k += Exec::NL) {
-                WF(hinv)[k] = hv[k];
-                WF(aH)[k] = 0.f;
-            }
+    // hinv <- a group's inverse, aH <- 0
+    auto load_hinv = [&](int lane, const float* hv) __attribute__((always_inline)) {
+        for (int k = lane; k < nd * nd; k += Exec::NL) {
+            WF(hinv)[k] = hv[k];
+            WF(aH)[k] = 0.f;
         }
     };
     dsim_init_static(c, ex);
     ex.run_both([&](int lane) { dsim_topo_init(c, ex, lane); });   // every wave keeps its own topology records
+    // (helper wavefront) the inverse of the last group of substeps, the first the adjoint needs: requested now -- behind the
+    // topology records, whose set-up needs the registers -- and stored by the helper at the first substep; the main wave's
+    // observation adjoint in between covers the latency
+    if constexpr (DsimHelperCommit<Ctx, Exec>::value)
+        ex.helper_prefetch_aux(dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, groups - 1), dsim_hinv_words_d(nd));
     ex.run([&](int lane) {
         const float* io = ex.io(lane);
         dsim_io_each<IO::CQ, Exec::NL>(nq, lane, [&](int k, int u) {
@@ -3811,20 +3809,28 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
     });
     dsim_env_load_actions(c, ex, sp, g_actions, true);
     dsim_env_observe_adjoint(c, ex, sp, g_gobs, g_grew, g_gobs_before, ep_flags, true);
+    // The first inverse goes to LDS HERE, in front of the loops: a use inside them would keep the registers it waits in alive
+    // through every substep (measured: Humanoid's helper kernel 255 -> 271 VGPRs).
+    // (Kernels without a helper keep theirs in the loop: a phase of its own costs the four-wave SNUHumanoid kernel 2 %.)
+    constexpr bool first_hinv_ahead = DsimHelperCommit<Ctx, Exec>::value;
+    if constexpr (DsimHelperCommit<Ctx, Exec>::value) {
+        ex.group_sync();   // the main wave is done with the end state in q / qd (observation adjoint)
+        ex.helper_commit_aux(WF(hinv), WF(aH), dsim_hinv_words_d(nd));   // (published by the barrier of the first helper_commit)
+        ex.fire([&](int lane) { dsim_hacc_zero(c, ex, lane); });
+    }
     for (int g = groups - 1; g >= 0; --g) {
         const int s0 = g * mm_freq, s1 = (s0 + mm_freq < substeps) ? s0 + mm_freq : substeps;
         for (int s = s1 - 1; s >= s0; --s) {
             // forward intermediates of substep s (and, entering a group, the inverse its substeps used) from HBM.
             // The row was requested one substep earlier (ex.prefetch keeps it in flight in registers while the
             // previous adjoint substep computes), so this phase only moves registers to LDS.
-            const float* hv = (s == s1 - 1) ? dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, g) : nullptr;
+            const float* hv = (s == s1 - 1 && !(first_hinv_ahead && g == groups - 1)) ? dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, g) : nullptr;
             if constexpr (DsimHelperCommit<Ctx, Exec>::value) {
                 static_assert(IO::PRE, "helper-side commit belongs to the specialised kernels");
-                if (s == substeps - 1) ex.group_sync();   // the main wave is done with the end state in q / qd (observation adjoint)
                 ex.helper_commit(WF(q), dsim_row(c), s > 0 ? g_ckpt + (size_t)(s - 1) * dsim_row(c) : nullptr);
                 if (hv)
                     ex.run([&](int lane) {
-                        load_hinv(lane, hv, g);
+                        load_hinv(lane, hv);
                         dsim_hacc_zero(c, ex, lane);
                     });
             } else {
@@ -3832,7 +3838,19 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
                 ex.run([&](int lane) {
                     ex.commit(WF(q), dsim_row(c), lane);
                     if (hv) {
-                        load_hinv(lane, hv, g);
+                        if (HPF > 0 && g == groups - 1) {
+                            const float* hpf = ex.hpf(lane);
+#pragma unroll
+                            for (int r = 0; r < HPF; ++r) {
+                                const int k = lane + Exec::NL * r;
+                                if (k < nd * nd) {
+                                    WF(hinv)[k] = hpf[r];
+                                    WF(aH)[k] = 0.f;
+                                }
+                            }
+                        } else {
+                            load_hinv(lane, hv);
+                        }
                         dsim_hacc_zero(c, ex, lane);
                     }
                 });

@@ -476,6 +476,37 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false, int EPW = 1> stru
             stamp();
         }
     }
+    // A second block in flight on the helper: the inverse of the mass matrix that the adjoint's first substep needs (fused env
+    // adjoint).  Requested at kernel start next to the first row, stored (and its cotangent zeroed) in front of the barrier of the
+    // first helper_commit -- the main wave never touches it (Humanoid: 729 words, 12 per lane, that the main wave has no
+    // registers to keep in flight across its prologue).  `words`: a multiple of 4, at most 4 * 64 * DSIM_APF.
+    static constexpr int DSIM_APF = 4;
+    v4f apf[DSIM_APF];
+    __device__ __forceinline__ void helper_prefetch_aux(const float* src, int words) {
+        if constexpr (HELPER) {
+            if (!helper_) return;
+            const v4f* s4 = reinterpret_cast<const v4f*>(src);
+#pragma unroll
+            for (int r = 0; r < DSIM_APF; ++r) {
+                const int k = lane_() + NL * r;
+                if (4 * k < words) apf[r] = s4[k];
+            }
+        }
+    }
+    __device__ __forceinline__ void helper_commit_aux(float* dst, float* zeroed, int words) {
+        if constexpr (HELPER) {
+            if (!helper_) return;
+            v4f *d4 = reinterpret_cast<v4f*>(dst), *z4 = reinterpret_cast<v4f*>(zeroed);
+#pragma unroll
+            for (int r = 0; r < DSIM_APF; ++r) {
+                const int k = lane_() + NL * r;
+                if (4 * k < words) {
+                    d4[k] = apf[r];
+                    z4[k] = v4f{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    }
     __device__ __forceinline__ void commit(float* dst, int words, int lane) {
         if (words > 4 * NL * DSIM_PF) {
             for (int k = lane; k < words; k += NL) dst[k] = pf_src[k];
@@ -761,6 +792,8 @@ template <int NW> struct TimingExec {
     __device__ __forceinline__ void group_sync() {}
     __device__ __forceinline__ void helper_prefetch(const float*, int) {}
     __device__ __forceinline__ void helper_commit(float*, int, const float*) {}
+    __device__ __forceinline__ void helper_prefetch_aux(const float*, int) {}
+    __device__ __forceinline__ void helper_commit_aux(float*, float*, int) {}
     __device__ __forceinline__ void mid() { __syncthreads(); }
     __device__ __forceinline__ void stamp() {}
     DsimImage<NW, 0> img_;
@@ -1346,6 +1379,11 @@ int dsim_model_device(const dsim_model* m) { return m ? m->device : -1; }
 #ifdef DSIM_STAMPS
 int dsim_debug_stamps(long long* out, int n) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dsim_stamps), sizeof(long long) * (size_t)(n < 2 * 16384 ? n : 2 * 16384));
+    if (e == hipSuccess) {   // (cleared for the next launch: a shorter launch would otherwise end in the previous one's stamps)
+        void* sym = nullptr;
+        e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g_dsim_stamps));
+        if (e == hipSuccess) e = hipMemset(sym, 0, sizeof(long long) * 2 * 16384);
+    }
     return e == hipSuccess ? DSIM_OK : hip_fail(e, "dsim_debug_stamps");
 }
 #endif

@@ -117,6 +117,8 @@ template <int NW, int LANES = DSIM_NL> struct HostExecT {
     void group_sync() {}                                       // (no helper wavefront here: DsimHelperCommit is off)
     void helper_prefetch(const float*, int) {}
     void helper_commit(float*, int, const float*) {}
+    void helper_prefetch_aux(const float*, int) {}
+    void helper_commit_aux(float*, float*, int) {}
     template <int D, bool FIRST = true> void add_from_above(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
         const float y0 = from_above<D>(a0), y1 = from_above<D>(a1), y2 = from_above<D>(a2), y3 = from_above<D>(a3),
                     y4 = from_above<D>(a4), y5 = from_above<D>(a5);

@@ -43,7 +43,9 @@ names = {0: "prologue", 1: "fwd_kin", 2: "fwd_ext", 3: "fwd_dyn/tau", 4: "fwd_ma
          9: "bwd_mass", 10: "bwd_bodies"}
 L.dsim_debug_stamps.argtypes = [C.c_void_p, C.c_int]
 for backward in (0, 1):
-    for _ in range(3):
+    for it in range(3):
+        if it == 2:   # (read-and-clear: the measured launch starts from an empty buffer)
+            capi.check(L.dsim_debug_stamps(np.zeros(2 * CAP, np.int64).ctypes.data_as(C.c_void_p), 2 * CAP))
         if backward:
             capi.check(L.dsim_env_step_backward(h, C.byref(spec), N, p(ck), p(a), C.c_float(dt), S, mm, p(gq), p(gqd), p(go), p(gr),
                                                 None, p(gqi), p(gqdi), p(ga), None))
