@@ -269,6 +269,7 @@ def test_pair_kernels_match_one_environment_per_wave(env, dev, monkeypatch):
     res = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("DSIM_PAIR", mode)
+        torch.manual_seed(12)
         e = cls(num_envs=65, device="cuda:0", no_grad=False, stochastic_init=True, seed=7)
         e.reset()
         e.initialize_trajectory()
@@ -280,6 +281,30 @@ def test_pair_kernels_match_one_environment_per_wave(env, dev, monkeypatch):
             tot = tot - rew.sum() + 0.01 * obs.sum()
         tot.backward()
         res[mode] = (obs.detach().cpu().numpy(), rew.detach().cpu().numpy(), a.grad.cpu().numpy())
+    for x, y in zip(res["1"], res["0"]):
+        assert np.isfinite(x).all() and np.array_equal(x, y)
+    # episodes that end inside the window (3 steps): restarts from the noisy start-state pool, obs_before_reset, done flags -- the
+    # two environments of a wave take different branches of the bookkeeping
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DSIM_PAIR", mode)
+        torch.manual_seed(12)    # (the host-side reset() draws its start states from torch's global generator, like the reference)
+        e = cls(num_envs=65, device="cuda:0", no_grad=False, stochastic_init=True, seed=11, episode_length=3)
+        e.reset()
+        e.progress_buf[::2] += 1     # (half of the environments one step ahead: the halves of a wave restart at different steps)
+        e.initialize_trajectory()
+        torch.manual_seed(4)
+        a = torch.randn((7, 65, e.num_actions), device=dev).tanh().requires_grad_(True)
+        tot, dones, before = 0.0, [], []
+        for s in range(7):
+            obs, rew, done, info = e.step(a[s])
+            tot = tot - rew.sum() + 0.01 * obs.sum() + 0.02 * info["obs_before_reset"].sum()
+            dones.append(done.detach().cpu().numpy().copy())
+            before.append(info["obs_before_reset"].detach().cpu().numpy())
+        tot.backward()
+        res[mode] = (obs.detach().cpu().numpy(), rew.detach().cpu().numpy(), np.stack(dones), np.stack(before), a.grad.cpu().numpy(),
+                     e.progress_buf.cpu().numpy())
+    assert res["1"][2].any() and not res["1"][2].all()
     for x, y in zip(res["1"], res["0"]):
         assert np.isfinite(x).all() and np.array_equal(x, y)
 
