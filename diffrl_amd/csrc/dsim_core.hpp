@@ -2078,11 +2078,131 @@ template <class Ctx, class Exec> DSIM_FN void dsim_hacc_zero(const Ctx& c, Exec&
     }
 }
 
+// Joint-space adjoint of the models whose links other than the free root have one hinge / prismatic dof each (DsimDims::JW_OK,
+// JW_FREE_ROOT: Ant; Humanoid, Hopper and HalfCheetah qualify structurally and measured no gain), up to DSIM_JW_ND_MAX dofs: integrate^T, adj tau = H^-1 adj qdd and the per-dof cotangents of
+// tau as ONE phase on the dof lanes.  A hinge dof's share of integrate^T is two loads and two multiply-adds, done by its own dof
+// lane; the free root's quaternion update^T runs on lane 0 as before and its six results reach the root's dof lanes by
+// v_readlane; adj qdd then travels by v_readlane into the rows of H^-1 each dof lane holds in registers (the mirror of the
+// forward's qdd = H^-1 tau), and adj tau stays in the register the per-dof block needs it in.  Two phase boundaries and the LDS
+// round trips of adj qdd and adj tau leave the critical path; same operations in the same order as the three phases.
+#ifndef DSIM_JW_ND_MAX
+#define DSIM_JW_ND_MAX 16
+#endif
+template <class Ctx, class Exec> struct DsimJointWave {
+    static constexpr bool value = []() {
+#ifdef DSIM_NO_JOINT_WAVE   // (A/B builds)
+        return false;
+#else
+        if constexpr (std::is_empty<decltype(Ctx::d)>::value && Exec::WAVE_OPS) {
+            using D = decltype(Ctx::d);
+            // measured (tools/ab_min.py, adjoint launch at 1024 environments): Ant -3.9 %; Humanoid (27 dofs: 27 rows of registers and
+            // broadcasts) +0.3 %, Hopper / HalfCheetah (no root chain to hide the per-dof work behind) +0.5 .. 1 % -- so: free root, <= 16 dofs
+            return D::JW_OK != 0 && D::JW_FREE_ROOT != 0 && D::nd <= DSIM_JW_ND_MAX && D::nd <= Exec::NL && D::L <= Exec::NL;
+        } else {
+            return false;
+        }
+#endif
+    }();
+};
+template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_wave(const Ctx& c, Exec& ex) {
+    using D = decltype(c.d);
+    constexpr int nd = D::nd;
+    ex.run([&](int lane) {
+        constexpr int MASK = dsim_tmask_static<Ctx>();
+        const float h = c.h;
+        const DsimTopoRegs& tp = ex.topo(lane);
+        const bool is_dof = lane < nd;
+        // ---- loads: dof role
+        int type = tp.dof_type;
+        DSIM_OPAQUE(type);
+        const int i = tp.dof_link, cs = tp.dof_cs, d = is_dof ? lane : 0;
+        const bool hinge = type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE;
+        const int qi = hinge ? cs : 0;
+        float hrow[nd];
+#pragma unroll
+        for (int j = 0; j < nd; ++j) hrow[j] = WF(hinv)[d * nd + j];
+        const sv6 ft = ldsv(WF(ftot) + 6 * i);
+        const float q = WF(q)[qi];
+        const float tke = CF(tke)[i], tkd = CF(tkd)[i], lke = CF(lke)[i], lkd = CF(lkd)[i];
+        const float lower = CF(lower)[qi], upper = CF(upper)[qi];
+        const float g_q = WF(aq)[qi], g_qd_in = WF(aqd)[d], g_act = WF(aact)[d];
+        // ---- integrate^T: the free root on lane 0 (its six new adj qd values in r6), a hinge on its dof lane
+        float r6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (D::JW_FREE_ROOT != 0) {
+            int ltype = tp.own_type;
+            DSIM_OPAQUE(ltype);
+            if (lane < D::L && ltype == DSIM_JOINT_FREE) {
+                const int lcs = tp.own_cs, lds_ = tp.own_ds;
+                const float *qq = WF(q) + lcs, *qd = WF(qd) + lds_, *qdd = WF(qdd) + lds_;
+                float *aq = WF(aq) + lcs;
+                const float* aqd = WF(aqd) + lds_;
+                const v3 p = ld3(qq), g_pn = ld3(aq);
+                const q4 r = ldq(qq + 3), g_rn = ldq(aq + 3);
+                const v3 w = ld3(qd) + ld3(qdd) * h;
+                const v3 gqd_w = ld3(aqd), gqd_v = ld3(aqd + 3);
+                const q4 rt = r + qmul_v(w, r) * 0.5f * h;   // W = (w, 0); the integrator's own expression, rounding included
+                q4 g_rt = mkq(0.f, 0.f, 0.f, 0.f);
+                float il = 0.f;
+                if constexpr (DsimSavedIl<Ctx, Exec>::value) {
+                    il = WF(qil)[0];   // from the forward launch, through the checkpoint
+                } else {
+                    const float l = sqrtf(qdot(rt, rt));
+                    if (l > 0.0f) il = 1.0f / l;
+                }
+                if (il > 0.0f) {
+                    const q4 rn = rt * il;
+                    g_rt = (g_rn + rn * (-qdot(rn, g_rn))) * il;
+                }
+                const q4 g_r = g_rt + qmul_v(mk3(-w.x, -w.y, -w.z), g_rt) * (0.5f * h);   // conj(W) (x) g_rt
+                const q4 g_W = qmul_adj_a(r, g_rt) * (0.5f * h);
+                v3 g_w = qvec(g_W) + gqd_w;
+                const v3 g_dp = g_pn * h;
+                const v3 g_v = g_dp + gqd_v;
+                g_w += cross(p, g_dp);
+                st3(aq, g_pn - cross(w, g_dp));
+                stq(aq + 3, g_r);
+                r6[0] = g_w.x; r6[1] = g_w.y; r6[2] = g_w.z;
+                r6[3] = g_v.x; r6[4] = g_v.y; r6[5] = g_v.z;
+            }
+        }
+        float g = g_qd_in + h * g_q;   // hinge: adj qd after integrate^T
+        if constexpr (D::JW_FREE_ROOT != 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float rk = ex.bcast(r6[k], 0);
+                if (lane == k) g = rk;
+            }
+        }
+        const float aqdd = h * g;
+        // ---- adj tau = H^-1 adj qdd (hinv is symmetric): adj qdd_j travels by v_readlane
+        float at = 0.f;
+#pragma unroll
+        for (int j = 0; j < nd; ++j) at += hrow[j] * ex.bcast(aqdd, j);
+        // ---- per-dof cotangents of tau
+        if (is_dof) {
+            WF(atau)[lane] = at;
+            stsv(WF(aS) + 6 * lane, ft * (-at));
+            if (hinge) {
+                float dq = -tke;
+                if (q < lower) dq = -tke - lke;
+                if (q > upper) dq = -tke - lke;
+                WF(aq)[qi] = g_q + dq * at;
+                WF(aqd)[lane] = g + (-tkd - lkd) * at;
+                WF(aact)[lane] = g_act + at;
+            } else {
+                WF(aqd)[lane] = g;   // (free root: tau has no joint-space terms)
+            }
+        }
+    });
+}
+
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c, Exec& ex, bool update_mass) {
     ex.mark(7);
     const int nd = c.d.nd;
+    constexpr bool joint_wave = DsimJointWave<Ctx, Exec>::value;
+    if constexpr (joint_wave) dsim_bwd_joint_wave(c, ex);
     // integrate^T per link: loads, arithmetic, stores (aq / aqd alias aqn / aqdn: every lane replaces its own link's words)
-    ex.run([&](int lane) {
+    if constexpr (!joint_wave) ex.run([&](int lane) {
         constexpr int MASK = dsim_tmask_static<Ctx>();
         constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
         const float h = c.h;
@@ -2161,7 +2281,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
             }
         }
     });
-    ex.run([&](int lane) {
+    if constexpr (!joint_wave) ex.run([&](int lane) {
         for (int i = lane; i < nd; i += Exec::NL) {
             WF(atau)[i] = dsim_dot_n(WF(hinv) + i * nd, WF(aqdd), nd);  // hinv is symmetric
         }
@@ -2327,7 +2447,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
         // cotangent of body_f_s[j]: f_tot of every ancestor-or-self i of j contains f[j] and tau_d = -S_d . f_tot[link(d)], so
         // af[j] = -sum over the dofs d of all ancestors-or-self of j of S_d atau_d (same phase: reads only S and atau;
         // items are dealt from the top lane down so that they do not pile onto the lanes of the per-dof loop above)
-        tau_adjoint_per_dof(lane);
+        if constexpr (!joint_wave) tau_adjoint_per_dof(lane);
     }, af_block);
 
 }

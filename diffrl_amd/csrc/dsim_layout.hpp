@@ -57,6 +57,9 @@ struct DsimDims {
     // bounds of the mass-matrix adjoint's two lists per dof (dsim_core.hpp: dsim_bwd_mass): most dofs in the STRICT subtree of a
     // link, longest list of dofs of the ancestors-or-self of a link
     int SDMAX, ADMAX;
+    // fused joint-space adjoint (dsim_core.hpp: dsim_bwd_joint_wave): every link but the root is a hinge / prismatic joint, the root
+    // is one too or a free joint (JW_FREE_ROOT)
+    int JW_OK, JW_FREE_ROOT;
 };
 #define DSIM_TM(t) (1 << (t))
 #define DSIM_RT_ROW 0
@@ -455,6 +458,16 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     }
     dd.L = L; dd.nq = nq; dd.nd = nd; dd.C = C; dd.M = M; dd.W = W; dd.NS = NS; dd.D = D;
     dd.flags = ranges ? DSIM_F_RANGES : 0;
+    {
+        bool jw = L >= 1;
+        for (int i = 0; i < L; ++i) {
+            const int t = m.joint_type[i], n = m.joint_qd_start[i + 1] - m.joint_qd_start[i];
+            const bool hinge = (t == DSIM_JOINT_PRISMATIC || t == DSIM_JOINT_REVOLUTE) && n == 1;
+            jw = jw && (hinge || (i == 0 && t == DSIM_JOINT_FREE && n == 6));
+        }
+        dd.JW_OK = jw ? 1 : 0;
+        dd.JW_FREE_ROOT = (jw && m.joint_type[0] == DSIM_JOINT_FREE) ? 1 : 0;
+    }
     for (int i = 0; i < L; ++i) {
         int sd = 0;
         for (int j : sub[i])

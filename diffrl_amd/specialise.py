@@ -38,7 +38,7 @@ TRUNK_MAX, TRUNK_CH = 6, 4
 # DsimDims behind pmask, struct order: (name, length); length 0 = scalar (csrc/dsim_layout.hpp)
 EXTRA = [("NT", 0), ("NLT", 0), ("LCAP", 0), ("CCAP", 0), ("trunk", TRUNK_MAX), ("tr_par", TRUNK_MAX), ("tr_nch", TRUNK_MAX),
          ("tr_ch", TRUNK_MAX * TRUNK_CH), ("tr_cb0", TRUNK_MAX), ("tr_ncb", TRUNK_MAX), ("tr_d0", TRUNK_MAX), ("tr_nd", TRUNK_MAX),
-         ("MK", 0), ("pident", 0), ("RT_N", 0), ("CBMAX", 0), ("rt_lvl", 16), ("rt_d", 16), ("rt_kind", 16), ("DSH_OK", 0), ("DSH", 0), ("ND_ROOT", 0), ("SDMAX", 0), ("ADMAX", 0)]
+         ("MK", 0), ("pident", 0), ("RT_N", 0), ("CBMAX", 0), ("rt_lvl", 16), ("rt_d", 16), ("rt_kind", 16), ("DSH_OK", 0), ("DSH", 0), ("ND_ROOT", 0), ("SDMAX", 0), ("ADMAX", 0), ("JW_OK", 0), ("JW_FREE_ROOT", 0)]
 _host = None
 
 
