@@ -2097,6 +2097,7 @@ template <class Ctx, class Exec> struct DsimJointWave {
             using D = decltype(Ctx::d);
             // measured (tools/ab_min.py, adjoint launch at 1024 environments): Ant -3.9 %; Humanoid (27 dofs: 27 rows of registers and
             // broadcasts) +0.3 %, Hopper / HalfCheetah (no root chain to hide the per-dof work behind) +0.5 .. 1 % -- so: free root, <= 16 dofs
+            // (all one-wave kernels of the model, helper or not: launches of any size give the same bits)
             return D::JW_OK != 0 && D::JW_FREE_ROOT != 0 && D::nd <= DSIM_JW_ND_MAX && D::nd <= Exec::NL && D::L <= Exec::NL;
         } else {
             return false;
@@ -3875,6 +3876,11 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
     constexpr int HPF = []() {
         if constexpr (DsimHelperCommit<Ctx, Exec>::value) {
             return 0;   // (the helper wavefront brings it: helper_prefetch_aux above)
+        } else if constexpr (Exec::WAVE_OPS) {
+            // one-wave kernels without a helper run the launches beyond the helper capacity, where other waves cover the latency and
+            // registers are the residency: Ant's env adjoint must stay within 256 VGPRs (two waves per SIMD; with these four and
+            // the fused joint-space phase it was 258: 8192 environments 0.30 -> 0.49 ms)
+            return 0;
         } else if constexpr (IO::PRE) {
             constexpr int need = (decltype(c.d)::nd * decltype(c.d)::nd + Exec::NL - 1) / Exec::NL;
             return need <= DSIM_HPF_MAX ? need : 0;

@@ -53,3 +53,17 @@ def test_pair_forward_kernels_exist_for_the_32_lane_models(kernels):
         for kn in ("dsim_fwd_kernel", "dsim_env_fwd_kernel"):
             assert any(p.startswith("%s<%s," % (kn, model)) for p in pair), (kn, model, pair)
     assert not any("bwd" in p or "Humanoid" in p or "Snu" in p for p in pair), pair
+
+
+def test_saturated_regime_kernels_keep_two_waves_per_simd(kernels):
+    """The single-wave kernels of the models that also have helper-wave kernels run the launches BEYOND the helper capacity, where
+    the resident waves per SIMD are the throughput: more than 256 registers (architectural + accumulation) would halve them
+    (happened in round 4: Ant's env adjoint at 258 -> 8192 environments 0.30 -> 0.49 ms)."""
+    from kernel_meta import short
+    over = []
+    for k in kernels:
+        n = short(k["name"])
+        if any(m in n for m in ("<Ant,", "<Hopper,", "<Cheetah,")) and ", lean" not in n and k.get("max_flat_workgroup_size") == 64:
+            if k["vgpr_count"] + k.get("agpr_count", 0) > 256:
+                over.append((n, k["vgpr_count"], k.get("agpr_count", 0)))
+    assert not over, over
