@@ -3873,9 +3873,16 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
     // substep: its memory latency (measured: 2.4 k cycles of the Ant adjoint launch when loaded on the spot) passes under the
     // observation adjoint, whose serial quaternion chain on one lane needs no memory at all.
     const int groups = (substeps + mm_freq - 1) / mm_freq;
+    // (helper-wave kernels: the helper brings it, if its registers hold it -- 4 x 64 x Exec::DSIM_APF words; a bigger model's main
+    // wave loads it on the spot, as before)
+    constexpr bool helper_aux = []() {
+        if constexpr (DsimHelperCommit<Ctx, Exec>::value)
+            return ((decltype(c.d)::nd * decltype(c.d)::nd + 3) & ~3) <= 4 * DSIM_NL * Exec::DSIM_APF;
+        else return false;
+    }();
     constexpr int HPF = []() {
         if constexpr (DsimHelperCommit<Ctx, Exec>::value) {
-            return 0;   // (the helper wavefront brings it: helper_prefetch_aux above)
+            return 0;   // (the helper wavefront brings it: helper_prefetch_aux below)
         } else if constexpr (Exec::WAVE_OPS) {
             // one-wave kernels without a helper run the launches beyond the helper capacity, where other waves cover the latency and
             // registers are the residency: Ant's env adjoint must stay within 256 VGPRs (two waves per SIMD; with these four and
@@ -3908,7 +3915,7 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
     // (helper wavefront) the inverse of the last group of substeps, the first the adjoint needs: requested now -- behind the
     // topology records, whose set-up needs the registers -- and stored by the helper at the first substep; the main wave's
     // observation adjoint in between covers the latency
-    if constexpr (DsimHelperCommit<Ctx, Exec>::value)
+    if constexpr (helper_aux)
         ex.helper_prefetch_aux(dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, groups - 1), dsim_hinv_words_d(nd));
     ex.run([&](int lane) {
         const float* io = ex.io(lane);
@@ -3938,9 +3945,9 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
     // The first inverse goes to LDS HERE, in front of the loops: a use inside them would keep the registers it waits in alive
     // through every substep (measured: Humanoid's helper kernel 255 -> 271 VGPRs).
     // (Kernels without a helper keep theirs in the loop: a phase of its own costs the four-wave SNUHumanoid kernel 2 %.)
-    constexpr bool first_hinv_ahead = DsimHelperCommit<Ctx, Exec>::value;
-    if constexpr (DsimHelperCommit<Ctx, Exec>::value) {
-        ex.group_sync();   // the main wave is done with the end state in q / qd (observation adjoint)
+    constexpr bool first_hinv_ahead = helper_aux;
+    if constexpr (DsimHelperCommit<Ctx, Exec>::value) ex.group_sync();   // the main wave is done with the end state in q / qd (observation adjoint)
+    if constexpr (helper_aux) {
         ex.helper_commit_aux(WF(hinv), WF(aH), dsim_hinv_words_d(nd));   // (published by the barrier of the first helper_commit)
         ex.fire([&](int lane) { dsim_hacc_zero(c, ex, lane); });
     }
