@@ -83,6 +83,13 @@ def test_tables_match_a_direct_computation(tree):
         [k for k in range(C) if cbody[k] in sub[i]]) for i in range(L))
     assert bool(dims["flags"] & 1) == (preorder and contiguous)
     assert dims["D"] == max(len(c) for c in anc)
+    # bounds of the mass-matrix adjoint's two lists per dof (dsim_bwd_mass_bounded) and the eligibility of the fused joint-space
+    # adjoint (dsim_bwd_joint_wave): round 4
+    assert dims["SDMAX"] == max(sum(len(dofs[j]) for j in sub[i] if j != i) for i in range(L))
+    assert dims["ADMAX"] == max(sum(len(dofs[j]) for j in anc[i]) for i in range(L))
+    hinge = [kinds[i] in ("rev", "pri") and len(dofs[i]) == 1 for i in range(L)]
+    jw = all(hinge[i] or (i == 0 and kinds[0] == "free") for i in range(L))
+    assert dims["JW_OK"] == int(jw) and dims["JW_FREE_ROOT"] == int(jw and kinds[0] == "free")
 
 
 @st.composite
