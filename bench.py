@@ -143,7 +143,10 @@ def issue_view(sq, n, t_kernel=None, helper=False):
                "salu_insts_per_env_step": sq.get("SQ_INSTS_SALU", 0.0) / n}
         if waves:
             out["waves_per_env"] = waves / n
-            out["valu_issue_frac"] = (sq["SQ_ACTIVE_INST_VALU"] / min(SIMDS, waves)) / (sq["SQ_WAVE_CYCLES"] / waves)
+            # (a lone-wave view: undefined once the launch puts several rounds of waves on a SIMD -- the saturated regime is read
+            # off valu_simd_frac)
+            out["valu_issue_frac"] = ((sq["SQ_ACTIVE_INST_VALU"] / min(SIMDS, waves)) / (sq["SQ_WAVE_CYCLES"] / waves)
+                                      if waves <= 2 * SIMDS else None)
             if t_kernel:
                 cyc = t_kernel * CLOCK_HZ
                 out["valu_simd_frac"] = sq["SQ_INSTS_VALU"] / min(SIMDS, waves) * SIMD_VALU_CYCLES / cyc
