@@ -884,7 +884,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_scan(const Ctx
     constexpr bool IDENT = (D::pident & ((1 << D::D) - 1)) == ((1 << D::D) - 1);   // every X_pj rotation is the identity
     constexpr bool HAS_P = (MASK & DSIM_TM(DSIM_JOINT_PRISMATIC)) != 0, HAS_R = (MASK & DSIM_TM(DSIM_JOINT_REVOLUTE)) != 0,
                    HAS_B = (MASK & DSIM_TM(DSIM_JOINT_BALL)) != 0, HAS_F = (MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0;
-    ex.fork_join_mid_late([&](int lane) {
+    ex.fork_join_mid([&](int lane) {
         const DsimTopoRegs& tp = ex.topo(lane);
         const bool on = lane < L;
         const int i = on ? lane : 0;
@@ -945,7 +945,6 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_scan(const Ctx
             p = rotate(ra, p) + pa;
             r = qmul(ra, r);
         });
-        ex.before_stores();   // (the helper's copy of the previous substep's row has read the arrays written from here on)
         if (on) {
             st3(WF(xsc) + 7 * i, p);
             stq(WF(xsc) + 7 * i + 3, r);
@@ -1051,7 +1050,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_scan(const Ctx
 // the last link have an empty chain and store nothing), so that the hand-over is a point all lanes pass.
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_walk_mid(const Ctx& c, Exec& ex, float* g_row) {
     using D = decltype(c.d);
-    ex.fork_join_mid_late([&](int lane) {
+    ex.fork_join_mid([&](int lane) {
         const bool on = lane < D::L;
         const int i = on ? lane : 0;
         DsimFkWalk w;
@@ -1083,7 +1082,6 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_walk_mid(const
         DSIM_OPAQUE(own_type);
         const v3 pc = w.psp;
         const q4 rc = w.rsp;
-        ex.before_stores();   // (the helper's copy of the previous substep's row has read the arrays written from here on)
         if (on) {
             st3(WF(xsc) + 7 * i, pc);
             stq(WF(xsc) + 7 * i + 3, rc);

@@ -348,31 +348,6 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false, int EPW = 1> stru
         if constexpr (HELPER) group_barrier();
         else dsim_wave_sync();
     }
-    // fork_join_mid with its FIRST barrier moved into fm: fm calls before_stores() in front of its first LDS store (and mid() behind
-    // the stores fh waits for).  What the barrier orders is the helper's detached copy of the previous substep's checkpoint row
-    // (fork_mid_detached: it READS the arrays the kinematics are about to overwrite) against those stores -- not against the
-    // chain walk in front of them, which only reads q, qd and constants into registers: the copy (LDS reads + global stores,
-    // measured at 5.4 % of the Ant forward launch when the main wave waited for it at the top of the phase,
-    // profiles/r04_ablation_ant.txt) passes under the walk.
-    template <class FM, class FH> __device__ __forceinline__ void fork_join_mid_late(FM&& fm, FH&& fh) {
-        if constexpr (HELPER) {
-            if (helper_) {
-                group_barrier();   // (before_stores of the main wave)
-                group_barrier();   // (mid)
-                fh(lane_());
-            } else {
-                fm(lane_());
-            }
-            stamp();
-            group_barrier();
-            stamp();
-        } else {
-            fork_join_mid(fm, fh);
-        }
-    }
-    __device__ __forceinline__ void before_stores() {
-        if constexpr (HELPER) group_barrier();
-    }
     // ... and without the barrier at the end: fh is a DETACHED side block -- nothing it reads is written, and nothing it writes is
     // read, before the next barrier that both waves take (the checkpoint copy beside the integrator: the next substep's
     // kinematics start with one).  The main wave goes on at once.
@@ -780,8 +755,6 @@ template <int NW> struct TimingExec {
         });
     }
     template <class FM, class FH> __device__ __forceinline__ void fork_join_mid(FM&& fm, FH&& fh) { fork_join(fm, fh); }
-    template <class FM, class FH> __device__ __forceinline__ void fork_join_mid_late(FM&& fm, FH&& fh) { fork_join(fm, fh); }
-    __device__ __forceinline__ void before_stores() {}
     template <class FM, class FH> __device__ __forceinline__ void fork_mid_detached(FM&& fm, FH&& fh) { fork_join(fm, fh); }
     template <class FM, class FH> __device__ __forceinline__ void fork_side(FM&& fm, FH&& fh) {
         run([&](int lane) {

@@ -139,8 +139,6 @@ template <int NW, int LANES = DSIM_NL> struct HostExecT {
     }
     // fm hands over to fh at its mid() call (device: the helper's barrier): every lane passes mid() before any lane gets to fh
     template <class FM, class FH> void fork_join_mid(FM&& fm, FH&& fh) { fork_join(fm, fh); }
-    template <class FM, class FH> void fork_join_mid_late(FM&& fm, FH&& fh) { fork_join(fm, fh); }
-    void before_stores() {}
     template <class FM, class FH> void fork_mid_detached(FM&& fm, FH&& fh) { fork_join(fm, fh); }
     void mid() { arrive(); }
     // side block first, then the main block, whose side_done() is a point every lane passes (device: the helper's barrier)
