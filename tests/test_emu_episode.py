@@ -186,3 +186,29 @@ def test_in_kernel_restart_noise_cpu_harness():
     r2 = run(7, 3)
     assert all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(r, r2))
     assert not np.array_equal(run(8, 1)[0][0], r[0][0])
+
+
+def test_episode_bookkeeping_with_the_pair_kernels_lane_count():
+    """The forward kernels of launches beyond the helper capacity carry two environments per wavefront (dsim_hip.hip:
+    DSIM_MODE_PAIR): the phase code sees 32 lanes per environment.  Episode flags, restarts from the pool, obs_before_reset and the
+    checkpoint tail with that instantiation of the specialised Ant kernels: bit-identical to the 64-lane one."""
+    from emu_lib import emu
+    t, spec, keep, q, qd, a, progress, pool_q, pool_qd, cnt = _setup()
+    n = q.shape[0]
+    out = {}
+    emu().dsim_emu_use_static(1)
+    try:
+        for half in (0, 1):
+            emu().dsim_emu_set_half_wave(half)
+            prog, c = progress.copy(), cnt.copy()
+            done = np.full(n, -7, np.int64)
+            obs_before = np.full((n, spec.n_obs), np.nan, np.float32)
+            ep = make_episode(prog, done, obs_before, pool_q, pool_qd, c, EP_LEN, True, True)
+            res = emu_env_forward(t, spec, q, qd, a, DT, S, MM, episode=ep)
+            out[half] = tuple(res) + (prog, c, done, obs_before)
+    finally:
+        emu().dsim_emu_set_half_wave(0)
+        emu().dsim_emu_use_static(0)
+    assert out[0][7].any() and not out[0][7].all()     # some environments restarted, some did not
+    for x, y in zip(out[1], out[0]):
+        np.testing.assert_array_equal(x, y)
