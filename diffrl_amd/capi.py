@@ -35,7 +35,7 @@ class EnvSpec(C.Structure):
     """Mirror of `dsim_env_spec` (include/dsim.h)."""
     _fields_ = [
         ("kind", C.c_int32), ("rew_kind", C.c_int32), ("n_act", C.c_int32), ("n_obs", C.c_int32),
-        ("act_offset", C.c_int32), ("act_muscle", C.c_int32), ("obs_actions", C.c_int32),
+        ("act_offset", C.c_int32), ("act_muscle", C.c_int32), ("obs_actions", C.c_int32), ("sanitize_grads", C.c_int32),
         ("inv_start_rot", C.c_float * 4), ("target_x", C.c_float), ("target_z", C.c_float),
         ("termination_height", C.c_float), ("termination_tolerance", C.c_float), ("height_rew_scale", C.c_float),
         ("action_penalty", C.c_float), ("joint_vel_obs_scaling", C.c_float), ("cartpole_penalties", C.c_float * 4),
@@ -111,7 +111,7 @@ class DsimError(RuntimeError):
 
 
 _lib = None
-EXPECTED_ABI = 105   # dsim_version() of the library this binding was written against (argument lists of include/dsim.h)
+EXPECTED_ABI = 106   # dsim_version() of the library this binding was written against (argument lists of include/dsim.h)
 
 
 def lib():

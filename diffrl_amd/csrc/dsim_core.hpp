@@ -350,6 +350,29 @@ template <class Ctx, int NL> struct DsimContactRegs {  // contact `lane` / `63 -
         else return false;
     }();
 };
+// Models whose per-item phases need SEVERAL wavefronts per environment (muscles: SNUHumanoid, 4 waves): the link-level work of
+// a substep -- kinematics, inertias and body forces forward; the body level of the adjoint -- runs on the FIRST wavefront alone
+// (a tree of <= 64 links), and the per-item work (ground contacts, muscle segments, their per-chunk sums, the checkpoint copies)
+// on the OTHER wavefronts AT THE SAME TIME (Exec::fork_wave0: two different instruction streams with shared workgroup barriers
+// where one needs what the other has written, Exec::mid / mid2 / side_done).  Round 4 ran these as phases one after the other,
+// every wave waiting at a workgroup barrier while one of them worked: 65 % of all wave-cycles of the SNUHumanoid kernels were
+// barrier waits (profiles/r04_final_snu_*).  The forward kinematics of the first wavefront are the log-depth scan
+// (dsim_scan_fk_lane): the contact lanes no longer walk chains, they read published poses on the other wavefronts.
+template <class Ctx, class Exec> struct DsimWideOverlap {
+    static constexpr bool value = []() {
+#ifdef DSIM_NO_WIDE_OVERLAP   // (A/B builds)
+        return false;
+#else
+        if constexpr (std::is_empty<decltype(Ctx::d)>::value) {
+            using D = decltype(Ctx::d);
+            return Exec::NL >= 2 * DSIM_NL && D::NS > 0 && D::L < DSIM_NL && D::nd <= DSIM_NL && D::D <= (1 << DSIM_SCAN_ROUNDS_MAX) &&
+                   (D::flags & DSIM_F_RANGES) != 0;
+        } else {
+            return false;
+        }
+#endif
+    }();
+};
 // Log-depth forward kinematics (dsim_fwd_kinematics_scan) instead of the per-lane chain walk: specialised kernels with one
 // wavefront per environment, trees of DSIM_SCAN_MIN_DEPTH levels or more.  A walk costs every lane (and, SIMD-wise, the
 // whole wave) `levels` chain positions of ~130 instructions; composing the links' LOCAL transforms along the ancestor chains
@@ -441,7 +464,7 @@ template <bool ADJ = true, class Ctx, class Exec> DSIM_FN void dsim_topo_init(co
             tp.tu_d[p] = (CI(qdstart)[i + 1] > CI(qdstart)[i]) ? CI(qdstart)[i] : -1;
         }
     }
-    if constexpr (DsimScanFk<Ctx, Exec::NL>::value) {
+    if constexpr (DsimScanFk<Ctx, Exec::NL>::value || DsimWideOverlap<Ctx, Exec>::value) {
         DsimTopoRegs& tp = ex.topo(lane);
         const int i = lane < c.d.L ? lane : 0;
         const int e0 = CI(anc_start)[i], e1 = CI(anc_start)[i + 1];   // ancestors-or-self, root first
@@ -449,7 +472,7 @@ template <bool ADJ = true, class Ctx, class Exec> DSIM_FN void dsim_topo_init(co
         for (int r = 0; r < DSIM_SCAN_ROUNDS_MAX; ++r) {
             const int dist = 1 << r;
             // no such ancestor: the wave's last lane, which carries the neutral element (identity transform, zero twist)
-            tp.jmp[r] = (lane < c.d.L && e1 - e0 > dist) ? CI(anc_list)[e1 - 1 - dist] : Exec::NL - 1;
+            tp.jmp[r] = (lane < c.d.L && e1 - e0 > dist) ? CI(anc_list)[e1 - 1 - dist] : (Exec::NL < DSIM_NL ? Exec::NL : DSIM_NL) - 1;
         }
     } else if constexpr (DsimChainRegs<Ctx>::value) {
         constexpr int DEPTH = decltype(c.d)::D;
@@ -628,11 +651,12 @@ DSIM_FN sv6 dsim_contact_wrench(const DsimContactConst& k, v3 xp, q4 xq, sv6 vb)
         const v3 vt = mk3(dpdt.x, 0.f, dpdt.z);
         const float fn = cc * ke;
         const float fd = (vn < 0.0f ? vn : 0.0f) * kd * (0.0f - cc);
-        const float lt = sqrtf(dot(vt, vt));
+        // |vt| and 1 / |vt| (dsim_inv_len: the reference's sqrt and 1 / l with their own roundings -- friction switches regime at
+        // thresholds on these values; 0 at vt = 0, where the friction force is zero too)
+        const float vt2 = dot(vt, vt), ilt = dsim_inv_len(vt2), lt = vt2 * ilt;
         const float a1 = kf * lt, a2 = 0.0f - mu * cc * ke;
         const float smin = a1 < a2 ? a1 : a2;
-        v3 ft = zero3();
-        if (lt > 0.0f) ft = vt * (smin / lt);
+        const v3 ft = vt * (smin * ilt);
         const v3 ftot = mk3(ft.x, fn + fd, ft.z);
         wr = mksv(cross(p, ftot), ftot);
     }
@@ -863,6 +887,173 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_contacts_per_body(const C
     }
 }
 
+// the block of ONE lane of the log-depth kinematics (the first wavefront's lanes; see dsim_fwd_kinematics_scan below).
+// Exec::mid2(): X_sc of every link is in LDS -- a hand-over point of the several-wavefront mapping only (DsimWideOverlap: muscle
+// segments may start; a no-op elsewhere); Exec::mid(): v too (contacts may start).
+template <class Ctx, class Exec> DSIM_FN void dsim_scan_fk_lane(const Ctx& c, Exec& ex, int lane) {
+    using D = decltype(c.d);
+    constexpr int L = D::L, R = dsim_scan_rounds(D::D), MASK = D::tmask;
+    constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
+    constexpr bool IDENT = (D::pident & ((1 << D::D) - 1)) == ((1 << D::D) - 1);   // every X_pj rotation is the identity
+    constexpr bool HAS_P = (MASK & DSIM_TM(DSIM_JOINT_PRISMATIC)) != 0, HAS_R = (MASK & DSIM_TM(DSIM_JOINT_REVOLUTE)) != 0,
+                   HAS_B = (MASK & DSIM_TM(DSIM_JOINT_BALL)) != 0, HAS_F = (MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0;
+    const DsimTopoRegs& tp = ex.topo(lane);
+    const bool on = lane < L;
+    const int i = on ? lane : 0;
+    int type = tp.own_type;
+    DSIM_OPAQUE(type);
+    const int cs = tp.own_cs, ds = tp.own_ds;
+    // ---- every input of the phase in one round trip: joint constants and coordinates, body constants
+    const v3 ppj = ld3(CF(xpj) + 7 * i), axis = ld3(CF(axis) + 3 * i);
+    const q4 rpj = ldq(CF(xpj) + 7 * i + 3);
+    float qv[NQ > 0 ? NQ : 1], qdv[NDF > 0 ? NDF : 1];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) qv[k] = WF(q)[cs + k];
+#pragma unroll
+    for (int k = 0; k < NDF; ++k) qdv[k] = WF(qd)[ds + k];
+    const v3 com = ld3(CF(com) + 3 * i);
+    const float* icp = CF(ic6) + 6 * i;
+    const float ic0 = icp[0], ic1 = icp[1], ic2 = icp[2], ic3 = icp[3], ic4 = icp[4], ic5 = icp[5];
+    const float m = CF(mass)[i];
+    const v3 grav = ld3(CF(grav));
+    // ---- local transform
+    v3 p = ppj;
+    q4 r = rpj;
+    if constexpr (HAS_P) {
+        if (type == DSIM_JOINT_PRISMATIC) p = ppj + (IDENT ? axis * qv[0] : rotate(rpj, axis * qv[0]));
+    }
+    if constexpr (HAS_R) {
+        if (type == DSIM_JOINT_REVOLUTE) {
+            const q4 qa = quat_axis_angle(axis, qv[0]);
+            r = IDENT ? qa : qmul(rpj, qa);
+        }
+    }
+    if constexpr (HAS_B) {
+        if (type == DSIM_JOINT_BALL) {
+            const q4 qb = mkq(qv[0], qv[1], qv[2], qv[3]);
+            r = IDENT ? qb : qmul(rpj, qb);
+        }
+    }
+    if constexpr (HAS_F) {
+        if (type == DSIM_JOINT_FREE) {
+            const v3 pf = mk3(qv[0], qv[1], qv[2]);
+            const q4 qf = mkq(qv[3], qv[4], qv[5], qv[6]);
+            p = ppj + (IDENT ? pf : rotate(rpj, pf));
+            r = IDENT ? qf : qmul(rpj, qf);
+        }
+    }
+    // ---- poses: pointer jumping along the ancestor chains.  T_j travels from lane j by ds_bpermute (Exec::shfl): no LDS
+    // store, no store -> load ordering -- a round is seven cross-lane reads and one composition
+    // (a lane without an ancestor at that distance reads the wave's last lane, which holds the identity: rotate(1, x) + 0 = x
+    // and 1 (x) q = q exactly, so every lane composes unconditionally -- no selects)
+    if (lane >= L) {
+        p = zero3();
+        r = mkq(0.f, 0.f, 0.f, 1.f);
+    }
+    dsim_static_for<0, R>([&](auto rr) {
+        const int src = tp.jmp[decltype(rr)::value];
+        const v3 pa = mk3(ex.shfl(p.x, src), ex.shfl(p.y, src), ex.shfl(p.z, src));
+        const q4 ra = mkq(ex.shfl(r.x, src), ex.shfl(r.y, src), ex.shfl(r.z, src), ex.shfl(r.w, src));
+        p = rotate(ra, p) + pa;
+        r = qmul(ra, r);
+    });
+    if (on) {
+        st3(WF(xsc) + 7 * i, p);
+        stq(WF(xsc) + 7 * i + 3, r);
+    }
+    ex.stamp();
+    ex.mid2();   // (several wavefronts: the poses are final -- the muscle segments of the other wavefronts may start)
+    // ---- motion subspace and joint twist from the link's own pose
+    sv6 s0 = zerosv(), s1 = zerosv(), s2 = zerosv(), vj = zerosv();
+    if constexpr (HAS_B) {
+        // a ball joint's subspace is the joint frame's basis: R_sj = R_parent (x) R_pj
+        const int par = tp.own_parent, psrc = par < 0 ? lane : par;
+        const q4 rpar = mkq(ex.shfl(r.x, psrc), ex.shfl(r.y, psrc), ex.shfl(r.z, psrc), ex.shfl(r.w, psrc));
+        if (type == DSIM_JOINT_BALL) {
+            q4 rj = rpj;
+            if (par >= 0) rj = IDENT ? rpar : qmul(rpar, rpj);
+            v3 u0, u1, u2;
+            rotate_basis(rj, u0, u1, u2);
+            s0 = mksv(u0, cross(p, u0));
+            s1 = mksv(u1, cross(p, u1));
+            s2 = mksv(u2, cross(p, u2));
+            vj = s0 * qdv[0];
+            vj += s1 * qdv[1];
+            vj += s2 * qdv[2];
+        }
+    }
+    if constexpr (HAS_P) {
+        if (type == DSIM_JOINT_PRISMATIC) {
+            s0 = mksv(zero3(), rotate(r, axis));
+            vj = s0 * qdv[0];
+        }
+    }
+    if constexpr (HAS_R) {
+        if (type == DSIM_JOINT_REVOLUTE) {
+            const v3 u = rotate(r, axis);
+            s0 = mksv(u, cross(p, u));
+            vj = s0 * qdv[0];
+        }
+    }
+    if constexpr (HAS_F) {
+        if (type == DSIM_JOINT_FREE)   // S = identity (dsim_init_static)
+            vj = mksv(mk3(qdv[0], qdv[1], qdv[2]), mk3(qdv[3], qdv[4], qdv[5]));
+    }
+    // ---- twists: prefix sums of v_j along the chains
+    sv6 v = vj;
+    if (lane >= L) v = zerosv();   // (the neutral element of the sums, see the poses)
+    dsim_static_for<0, R>([&](auto rr) {
+        const int src = tp.jmp[decltype(rr)::value];
+        v += mksv(mk3(ex.shfl(v.w.x, src), ex.shfl(v.w.y, src), ex.shfl(v.w.z, src)),
+                  mk3(ex.shfl(v.v.x, src), ex.shfl(v.v.y, src), ex.shfl(v.v.z, src)));
+    });
+    if (on) stsv(WF(v) + 6 * i, v);
+    ex.stamp();
+    ex.mid();   // X_sc and v of every link are final: the contacts may start
+    // ---- bias accelerations: c_i = v_i x v_j,i (exactly zero at the root: a vector crossed with itself), prefix sums in a
+    sv6 a = zerosv();
+    if (tp.own_level > 0 && on) a = scross(v, vj);
+    dsim_static_for<0, R>([&](auto rr) {
+        const int src = tp.jmp[decltype(rr)::value];
+        a += mksv(mk3(ex.shfl(a.w.x, src), ex.shfl(a.w.y, src), ex.shfl(a.w.z, src)),
+                  mk3(ex.shfl(a.v.x, src), ex.shfl(a.v.y, src), ex.shfl(a.v.z, src)));
+    });
+    if (on) stsv(WF(a) + 6 * i, a);
+    ex.stamp();
+    // ---- COM, world inertia about the origin (Theta = R Ic R^T, A = Theta + m(c.c 1 - c c^T), h = m c) and body force
+    const v3 cm = rotate(r, com) + p;
+    v3 rx, ry, rz;
+    rotate_basis(r, rx, ry, rz);
+    const v3 b0 = rx * ic0 + ry * ic1 + rz * ic2;
+    const v3 b1 = rx * ic1 + ry * ic3 + rz * ic4;
+    const v3 b2 = rx * ic2 + ry * ic4 + rz * ic5;
+    inertia10 I;
+    I.m = m;
+    I.h = cm * m;
+    const float cc = dot(cm, cm);
+    I.axx = b0.x * rx.x + b1.x * ry.x + b2.x * rz.x + m * (cc - cm.x * cm.x);
+    I.axy = b0.x * rx.y + b1.x * ry.y + b2.x * rz.y - m * cm.x * cm.y;
+    I.axz = b0.x * rx.z + b1.x * ry.z + b2.x * rz.z - m * cm.x * cm.z;
+    I.ayy = b0.y * rx.y + b1.y * ry.y + b2.y * rz.y + m * (cc - cm.y * cm.y);
+    I.ayz = b0.y * rx.z + b1.y * ry.z + b2.y * rz.z - m * cm.y * cm.z;
+    I.azz = b0.z * rx.z + b1.z * ry.z + b2.z * rz.z + m * (cc - cm.z * cm.z);
+    const sv6 fb = inertia_mul(I, a) + scross_dual(v, inertia_mul(I, v));
+    const v3 mg = grav * m;
+    const sv6 fg = mksv(cross(cm, mg), mg);
+    if (on) {
+        st_i10(WF(i10) + 10 * i, I);
+        stsv(WF(f) + 6 * i, fb - fg);
+        float* S = WF(S) + 6 * ds;
+        if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
+            stsv(S, s0);
+        } else if (type == DSIM_JOINT_BALL) {
+            stsv(S, s0);
+            stsv(S + 6, s1);
+            stsv(S + 12, s2);
+        }
+    }
+}
+
 // Log-depth forward kinematics (DsimScanFk).  One lane per link, every lane executes every step (lanes past the last link
 // compute on link 0's inputs and store nothing): the rounds exchange their operands between lanes with ds_bpermute (Exec::shfl),
 // which needs uniform control flow, and the results go to LDS once -- poses, twists and bias accelerations as they become final:
@@ -878,171 +1069,90 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_contacts_per_body(const C
 // likewise): not bit-identical to it; tests hold both to the reference's recording of the first substep (1e-5).
 // Between poses + twists and the rest, Exec::mid() lets the helper wavefront start on the contacts (fork_join_mid).
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_scan(const Ctx& c, Exec& ex, float* g_row) {
-    using D = decltype(c.d);
-    constexpr int L = D::L, R = dsim_scan_rounds(D::D), MASK = D::tmask;
-    constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
-    constexpr bool IDENT = (D::pident & ((1 << D::D) - 1)) == ((1 << D::D) - 1);   // every X_pj rotation is the identity
-    constexpr bool HAS_P = (MASK & DSIM_TM(DSIM_JOINT_PRISMATIC)) != 0, HAS_R = (MASK & DSIM_TM(DSIM_JOINT_REVOLUTE)) != 0,
-                   HAS_B = (MASK & DSIM_TM(DSIM_JOINT_BALL)) != 0, HAS_F = (MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0;
-    ex.fork_join_mid([&](int lane) {
-        const DsimTopoRegs& tp = ex.topo(lane);
-        const bool on = lane < L;
-        const int i = on ? lane : 0;
-        int type = tp.own_type;
-        DSIM_OPAQUE(type);
-        const int cs = tp.own_cs, ds = tp.own_ds;
-        // ---- every input of the phase in one round trip: joint constants and coordinates, body constants
-        const v3 ppj = ld3(CF(xpj) + 7 * i), axis = ld3(CF(axis) + 3 * i);
-        const q4 rpj = ldq(CF(xpj) + 7 * i + 3);
-        float qv[NQ > 0 ? NQ : 1], qdv[NDF > 0 ? NDF : 1];
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) qv[k] = WF(q)[cs + k];
-#pragma unroll
-        for (int k = 0; k < NDF; ++k) qdv[k] = WF(qd)[ds + k];
-        const v3 com = ld3(CF(com) + 3 * i);
-        const float* icp = CF(ic6) + 6 * i;
-        const float ic0 = icp[0], ic1 = icp[1], ic2 = icp[2], ic3 = icp[3], ic4 = icp[4], ic5 = icp[5];
-        const float m = CF(mass)[i];
-        const v3 grav = ld3(CF(grav));
-        // ---- local transform
-        v3 p = ppj;
-        q4 r = rpj;
-        if constexpr (HAS_P) {
-            if (type == DSIM_JOINT_PRISMATIC) p = ppj + (IDENT ? axis * qv[0] : rotate(rpj, axis * qv[0]));
-        }
-        if constexpr (HAS_R) {
-            if (type == DSIM_JOINT_REVOLUTE) {
-                const q4 qa = quat_axis_angle(axis, qv[0]);
-                r = IDENT ? qa : qmul(rpj, qa);
-            }
-        }
-        if constexpr (HAS_B) {
-            if (type == DSIM_JOINT_BALL) {
-                const q4 qb = mkq(qv[0], qv[1], qv[2], qv[3]);
-                r = IDENT ? qb : qmul(rpj, qb);
-            }
-        }
-        if constexpr (HAS_F) {
-            if (type == DSIM_JOINT_FREE) {
-                const v3 pf = mk3(qv[0], qv[1], qv[2]);
-                const q4 qf = mkq(qv[3], qv[4], qv[5], qv[6]);
-                p = ppj + (IDENT ? pf : rotate(rpj, pf));
-                r = IDENT ? qf : qmul(rpj, qf);
-            }
-        }
-        // ---- poses: pointer jumping along the ancestor chains.  T_j travels from lane j by ds_bpermute (Exec::shfl): no LDS
-        // store, no store -> load ordering -- a round is seven cross-lane reads and one composition
-        // (a lane without an ancestor at that distance reads the wave's last lane, which holds the identity: rotate(1, x) + 0 = x
-        // and 1 (x) q = q exactly, so every lane composes unconditionally -- no selects)
-        if (lane >= L) {
-            p = zero3();
-            r = mkq(0.f, 0.f, 0.f, 1.f);
-        }
-        dsim_static_for<0, R>([&](auto rr) {
-            const int src = tp.jmp[decltype(rr)::value];
-            const v3 pa = mk3(ex.shfl(p.x, src), ex.shfl(p.y, src), ex.shfl(p.z, src));
-            const q4 ra = mkq(ex.shfl(r.x, src), ex.shfl(r.y, src), ex.shfl(r.z, src), ex.shfl(r.w, src));
-            p = rotate(ra, p) + pa;
-            r = qmul(ra, r);
-        });
-        if (on) {
-            st3(WF(xsc) + 7 * i, p);
-            stq(WF(xsc) + 7 * i + 3, r);
-        }
-        ex.stamp();
-        // ---- motion subspace and joint twist from the link's own pose
-        sv6 s0 = zerosv(), s1 = zerosv(), s2 = zerosv(), vj = zerosv();
-        if constexpr (HAS_B) {
-            // a ball joint's subspace is the joint frame's basis: R_sj = R_parent (x) R_pj
-            const int par = tp.own_parent, psrc = par < 0 ? lane : par;
-            const q4 rpar = mkq(ex.shfl(r.x, psrc), ex.shfl(r.y, psrc), ex.shfl(r.z, psrc), ex.shfl(r.w, psrc));
-            if (type == DSIM_JOINT_BALL) {
-                q4 rj = rpj;
-                if (par >= 0) rj = IDENT ? rpar : qmul(rpar, rpj);
-                v3 u0, u1, u2;
-                rotate_basis(rj, u0, u1, u2);
-                s0 = mksv(u0, cross(p, u0));
-                s1 = mksv(u1, cross(p, u1));
-                s2 = mksv(u2, cross(p, u2));
-                vj = s0 * qdv[0];
-                vj += s1 * qdv[1];
-                vj += s2 * qdv[2];
-            }
-        }
-        if constexpr (HAS_P) {
-            if (type == DSIM_JOINT_PRISMATIC) {
-                s0 = mksv(zero3(), rotate(r, axis));
-                vj = s0 * qdv[0];
-            }
-        }
-        if constexpr (HAS_R) {
-            if (type == DSIM_JOINT_REVOLUTE) {
-                const v3 u = rotate(r, axis);
-                s0 = mksv(u, cross(p, u));
-                vj = s0 * qdv[0];
-            }
-        }
-        if constexpr (HAS_F) {
-            if (type == DSIM_JOINT_FREE)   // S = identity (dsim_init_static)
-                vj = mksv(mk3(qdv[0], qdv[1], qdv[2]), mk3(qdv[3], qdv[4], qdv[5]));
-        }
-        // ---- twists: prefix sums of v_j along the chains
-        sv6 v = vj;
-        if (lane >= L) v = zerosv();   // (the neutral element of the sums, see the poses)
-        dsim_static_for<0, R>([&](auto rr) {
-            const int src = tp.jmp[decltype(rr)::value];
-            v += mksv(mk3(ex.shfl(v.w.x, src), ex.shfl(v.w.y, src), ex.shfl(v.w.z, src)),
-                      mk3(ex.shfl(v.v.x, src), ex.shfl(v.v.y, src), ex.shfl(v.v.z, src)));
-        });
-        if (on) stsv(WF(v) + 6 * i, v);
-        ex.stamp();
-        ex.mid();   // X_sc and v of every link are final: the contacts may start
-        // ---- bias accelerations: c_i = v_i x v_j,i (exactly zero at the root: a vector crossed with itself), prefix sums in a
-        sv6 a = zerosv();
-        if (tp.own_level > 0 && on) a = scross(v, vj);
-        dsim_static_for<0, R>([&](auto rr) {
-            const int src = tp.jmp[decltype(rr)::value];
-            a += mksv(mk3(ex.shfl(a.w.x, src), ex.shfl(a.w.y, src), ex.shfl(a.w.z, src)),
-                      mk3(ex.shfl(a.v.x, src), ex.shfl(a.v.y, src), ex.shfl(a.v.z, src)));
-        });
-        if (on) stsv(WF(a) + 6 * i, a);
-        ex.stamp();
-        // ---- COM, world inertia about the origin (Theta = R Ic R^T, A = Theta + m(c.c 1 - c c^T), h = m c) and body force
-        const v3 cm = rotate(r, com) + p;
-        v3 rx, ry, rz;
-        rotate_basis(r, rx, ry, rz);
-        const v3 b0 = rx * ic0 + ry * ic1 + rz * ic2;
-        const v3 b1 = rx * ic1 + ry * ic3 + rz * ic4;
-        const v3 b2 = rx * ic2 + ry * ic4 + rz * ic5;
-        inertia10 I;
-        I.m = m;
-        I.h = cm * m;
-        const float cc = dot(cm, cm);
-        I.axx = b0.x * rx.x + b1.x * ry.x + b2.x * rz.x + m * (cc - cm.x * cm.x);
-        I.axy = b0.x * rx.y + b1.x * ry.y + b2.x * rz.y - m * cm.x * cm.y;
-        I.axz = b0.x * rx.z + b1.x * ry.z + b2.x * rz.z - m * cm.x * cm.z;
-        I.ayy = b0.y * rx.y + b1.y * ry.y + b2.y * rz.y + m * (cc - cm.y * cm.y);
-        I.ayz = b0.y * rx.z + b1.y * ry.z + b2.y * rz.z - m * cm.y * cm.z;
-        I.azz = b0.z * rx.z + b1.z * ry.z + b2.z * rz.z + m * (cc - cm.z * cm.z);
-        const sv6 fb = inertia_mul(I, a) + scross_dual(v, inertia_mul(I, v));
-        const v3 mg = grav * m;
-        const sv6 fg = mksv(cross(cm, mg), mg);
-        if (on) {
-            st_i10(WF(i10) + 10 * i, I);
-            stsv(WF(f) + 6 * i, fb - fg);
-            float* S = WF(S) + 6 * ds;
-            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
-                stsv(S, s0);
-            } else if (type == DSIM_JOINT_BALL) {
-                stsv(S, s0);
-                stsv(S + 6, s1);
-                stsv(S + 12, s2);
-            }
-        }
-    }, [&](int lane) {
+    ex.fork_join_mid([&](int lane) { dsim_scan_fk_lane(c, ex, lane); }, [&](int lane) {
         dsim_fwd_contacts(c, ex, lane);
         dsim_fwd_contacts_per_body(c, ex, lane);
         if (g_row) dsim_ckpt_store_row<Ctx, Exec::NL, 1>(c, lane, g_row);   // head of the checkpoint row: (q, qd) entering the substep
+    });
+}
+
+template <class Ctx> DSIM_FN void dsim_muscle_chunk_sums(const Ctx& c, int lane, int nl);
+// ground contacts and muscle segments of the environment on the NLR lanes `lane` of the wavefronts behind the first one, from the
+// published poses and twists (forward: wrenches; DsimWideOverlap).  Contacts are dealt from the top lane down, segments from
+// lane 0 up, so that a lane's second item is of the other kind where the lists allow it.
+// packed record of muscle segment s (dsim_layout.hpp: seg_rec): offsets of its two links' poses, of its waypoints, its muscle, and
+// of its two rows in `mus` -- two 16-byte LDS reads
+struct DsimSegRec {
+    int x0, x1, wp, m, r0, r1;
+};
+template <class Ctx> DSIM_FN DsimSegRec dsim_seg_rec(const Ctx& c, int s) {
+    const dsim_i4* p = reinterpret_cast<const dsim_i4*>(reinterpret_cast<const dsim_int_a*>(c.k) + c.o.seg_rec + 8 * s);
+    const dsim_i4 a = p[0], b = p[1];
+    return DsimSegRec{a.x, a.y, a.z, a.w, b.x, b.y};
+}
+// the segment's inputs (second LDS round trip), then arithmetic and stores: kept apart so that a lane with two segments can
+// request both before it evaluates either
+struct DsimSegIn {
+    v3 p0, p1, m0, m1;
+    q4 r0, r1;
+    float act;
+};
+template <class Ctx> DSIM_FN DsimSegIn dsim_seg_load(const Ctx& c, const DsimSegRec& g) {
+    DsimSegIn in;
+    in.p0 = ld3(WF(xsc) + g.x0); in.r0 = ldq(WF(xsc) + g.x0 + 3);
+    in.p1 = ld3(WF(xsc) + g.x1); in.r1 = ldq(WF(xsc) + g.x1 + 3);
+    in.m0 = ld3(CF(mpoints) + g.wp); in.m1 = ld3(CF(mpoints) + g.wp + 3);
+    in.act = WF(mact)[g.m];
+    return in;
+}
+template <class Ctx> DSIM_FN void dsim_fwd_muscle_segment_eval(const Ctx& c, const DsimSegRec& g, const DsimSegIn& in) {
+    const v3 pos0 = in.p0 + rotate(in.r0, in.m0), pos1 = in.p1 + rotate(in.r1, in.m1);
+    const v3 d = pos1 - pos0;
+    const v3 f = d * (in.act * dsim_inv_len_item(dot(d, d)));   // normalize(d) * activation (zero for d = 0)
+    // wrenches on the two links, signs applied, into the rows of their bodies (rows are sorted by body, so that the
+    // per-body gather is a contiguous range sum without index loads)
+    float* o0 = WF(mus) + g.r0;
+    float* o1 = WF(mus) + g.r1;
+    st3(o0, -cross(pos0, f));
+    st3(o0 + 3, -f);
+    st3(o1, cross(pos1, f));
+    st3(o1 + 3, f);
+}
+template <class Ctx> DSIM_FN void dsim_fwd_muscle_segment(const Ctx& c, int s) {
+    const DsimSegRec g = dsim_seg_rec(c, s);
+    dsim_fwd_muscle_segment_eval(c, g, dsim_seg_load(c, g));
+}
+// segments lane, lane + nl, ... of the NS segments: in pairs, both records and both input sets requested before either is
+// evaluated (198 segments on 192 lanes: the few lanes with two would otherwise run two dependent chains one after the other,
+// and every lane of their wavefront with them)
+template <class Ctx> DSIM_FN void dsim_fwd_muscle_segments(const Ctx& c, int lane, int nl) {
+    for (int s = lane; s < c.d.NS; s += 2 * nl) {
+        const int s2 = s + nl;
+        const bool two = s2 < c.d.NS;
+        const DsimSegRec ga = dsim_seg_rec(c, s), gb = dsim_seg_rec(c, two ? s2 : s);
+        const DsimSegIn ia = dsim_seg_load(c, ga), ib = dsim_seg_load(c, gb);
+        dsim_fwd_muscle_segment_eval(c, ga, ia);
+        if (two) dsim_fwd_muscle_segment_eval(c, gb, ib);
+    }
+}
+// Kinematics of a model with several wavefronts per environment (DsimWideOverlap): the first wavefront runs the log-depth
+// kinematics of the links; the others copy the head of the checkpoint row while they wait for the poses, evaluate the muscle
+// segments from the published poses (mid2) while the first wavefront goes on with motion subspaces and twists, then (mid: twists
+// published, muscle rows complete) sum the muscle rows per chunk and evaluate the ground contacts while the first wavefront does
+// bias accelerations, inertias and body forces.  The phase ends with a workgroup barrier; the per-body gather (dsim_fwd_external)
+// follows.
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_wide(const Ctx& c, Exec& ex, float* g_row) {
+    constexpr int NLR = Exec::NL - DSIM_NL;
+    ex.fork_wave0([&](int lane) { dsim_scan_fk_lane(c, ex, lane); }, [&](int lane) {
+        if (g_row) dsim_ckpt_store_row<Ctx, NLR, 1>(c, lane, g_row);   // head of the checkpoint row: (q, qd) entering the substep
+        ex.mid2();   // poses
+        dsim_fwd_muscle_segments(c, lane, NLR);
+        ex.mid();    // twists (and: every muscle row is written)
+        dsim_muscle_chunk_sums(c, lane, NLR);
+        for (int k = NLR - 1 - lane; k < c.d.C; k += NLR) {
+            const int b = CI(cbody)[k];
+            stsv(WF(cw) + 6 * k, dsim_contact_wrench(dsim_contact_load(c, k), ld3(WF(xsc) + 7 * b), ldq(WF(xsc) + 7 * b + 3), ldsv(WF(v) + 6 * b)));
+        }
     });
 }
 
@@ -1133,6 +1243,10 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_walk_mid(const
 // wavefront where there is one, the rest beside the integrator (dsim_fwd_dynamics_wave)
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, Exec& ex, float* g_row = nullptr) {
     ex.mark(1);
+    if constexpr (DsimWideOverlap<Ctx, Exec>::value) {
+        dsim_fwd_kinematics_wide(c, ex, g_row);
+        return;
+    }
     if constexpr (DsimScanFk<Ctx, Exec::NL>::value) {
         dsim_fwd_kinematics_scan(c, ex, g_row);
         return;
@@ -1265,47 +1379,47 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
 template <class Ctx> DSIM_FN void dsim_muscle_chunk_sums(const Ctx& c, int lane, int nl) {
     for (int it = lane; it < 6 * c.d.MK; it += nl) {
         const int e = it / 6, k = it - 6 * e;
-        WF(mpart)[it] = dsim_range_sum(WF(mus), 6, k, CI(mc_row)[e], CI(mc_cnt)[e], 0.f);
+        // (specialised kernels: all rows of the chunk in one round trip, rows past its end selected away)
+        if constexpr (DsimIsStatic<Ctx>::value) WF(mpart)[it] = dsim_range_sum_b<DSIM_MUSCLE_CHUNK>(WF(mus), 6, k, CI(mc_row)[e], CI(mc_cnt)[e], 0.f);
+        else WF(mpart)[it] = dsim_range_sum(WF(mus), 6, k, CI(mc_row)[e], CI(mc_cnt)[e], 0.f);
     }
+}
+// sum of the chunk sums of body i, component k (<= 8 chunks per body in one round trip where the layout is compile-time)
+template <class Ctx> DSIM_FN float dsim_body_chunk_sum(const Ctx& c, int i, int k, float acc) {
+    const int b0 = CI(mb_start)[i], n = CI(mb_start)[i + 1] - b0;
+    if constexpr (DsimIsStatic<Ctx>::value) return dsim_range_sum_b<8>(WF(mpart), 6, k, b0, n, acc);
+    else return dsim_range_sum(WF(mpart), 6, k, b0, n, acc);
+}
+// cotangent of muscle activation m: sum over its active segments (consecutive words behind the wrench rows)
+template <class Ctx> DSIM_FN float dsim_muscle_act_sum(const Ctx& c, int m) {
+    const int s0 = CI(ms_start)[m], n = CI(ms_start)[m + 1] - s0;
+    if constexpr (DsimIsStatic<Ctx>::value) return dsim_range_sum_b<4>(WF(mus) + 12 * c.d.NS, 1, 0, s0, n, 0.f);
+    else return dsim_range_sum(WF(mus) + 12 * c.d.NS, 1, 0, s0, n, 0.f);
 }
 // ground contacts (sim.py:1137-1206) and muscle segments (sim.py:1209-1242): per-item wrenches
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Exec& ex) {
     ex.mark(2);
+    constexpr bool wide = DsimWideOverlap<Ctx, Exec>::value;   // contacts, segments and chunk sums ran beside the kinematics
     constexpr bool in_kin = DsimContactsInKin<Ctx, Exec::NL>::value || DsimScanFk<Ctx, Exec::NL>::value ||
-                            DsimContactsAfterWalk<Ctx, Exec::NL>::value;  // contacts were done by the kinematics phase
+                            DsimContactsAfterWalk<Ctx, Exec::NL>::value || wide;  // contacts were done by the kinematics phase
     if ((c.d.C == 0 || in_kin) && c.d.NS == 0) return;
-    ex.run([&](int lane) {
-        if constexpr (!in_kin) {
-            dsim_fwd_contacts(c, ex, lane);
-            dsim_fwd_contacts_per_body(c, ex, lane);
-        }
-        for (int s = lane; s < c.d.NS; s += Exec::NL) {
-            const int w = CI(seg_wp)[s];
-            const int l0 = CI(mlinks)[w], l1 = CI(mlinks)[w + 1];
-            const v3 pos0 = ld3(WF(xsc) + 7 * l0) + rotate(ldq(WF(xsc) + 7 * l0 + 3), ld3(CF(mpoints) + 3 * w));
-            const v3 pos1 = ld3(WF(xsc) + 7 * l1) + rotate(ldq(WF(xsc) + 7 * l1 + 3), ld3(CF(mpoints) + 3 * w + 3));
-            const v3 d = pos1 - pos0;
-            const float l = sqrtf(dot(d, d));
-            v3 f = zero3();
-            if (l > 0.0f) f = d * (WF(mact)[CI(seg_m)[s]] / l);
-            // wrenches on the two links, signs applied, into the rows of their bodies (rows are sorted by body, so that the
-            // per-body gather below is a contiguous range sum without index loads)
-            float* o0 = WF(mus) + 6 * CI(seg_slot)[2 * s];
-            float* o1 = WF(mus) + 6 * CI(seg_slot)[2 * s + 1];
-            st3(o0, -cross(pos0, f));
-            st3(o0 + 3, -f);
-            st3(o1, cross(pos1, f));
-            st3(o1 + 3, f);
-        }
-    });
+    if constexpr (!wide) {
+        ex.run([&](int lane) {
+            if constexpr (!in_kin) {
+                dsim_fwd_contacts(c, ex, lane);
+                dsim_fwd_contacts_per_body(c, ex, lane);
+            }
+            dsim_fwd_muscle_segments(c, lane, Exec::NL);
+        });
+    }
     if (c.d.NS > 0) {
         // per-body gather of the muscle wrench rows in two steps (dsim_layout.hpp: mc_row): chunk sums, one lane and one LDS
         // round trip per chunk and component, then per body the sums of its chunks + its contact wrenches
-        ex.run([&](int lane) { dsim_muscle_chunk_sums(c, lane, Exec::NL); });
+        if constexpr (!wide) ex.run([&](int lane) { dsim_muscle_chunk_sums(c, lane, Exec::NL); });
         ex.run([&](int lane) {
             for (int it = lane; it < 6 * c.d.L; it += Exec::NL) {
                 const int i = it / 6, k = it - 6 * i;
-                float acc = dsim_range_sum(WF(mpart), 6, k, CI(mb_start)[i], CI(mb_start)[i + 1] - CI(mb_start)[i], WF(f)[it]);
+                float acc = dsim_body_chunk_sum(c, i, k, WF(f)[it]);
                 acc = dsim_body_contact_sum(c, i, WF(cw), 6, k, acc);   // + the body's own contact wrenches
                 WF(f)[it] = acc;
             }
@@ -1466,11 +1580,16 @@ template <class Ctx, class Exec> DSIM_FN void dsim_rowtree_sum(const Ctx&, Exec&
     using D = decltype(Ctx::d);
     dsim_static_for<0, D::RT_N>([&](auto ss) {
         constexpr int s_ = decltype(ss)::value, dist = D::rt_d[s_], kind = D::rt_kind[s_];
+        // The DPP steps are inline asm, which the compiler's hazard recognizer cannot see into: the s_nop in front of a step's six
+        // v_fmac_f32_dpp covers "operands written by the instructions right before".  That is the case for the first step of a
+        // sum and for a step that follows a FAR step (compiler-generated v_readlane + v_fma writing the same six registers); a
+        // step behind another asm block reads what that block wrote five instructions earlier.
+        constexpr bool GUARD = s_ == 0 || D::rt_kind[s_ > 0 ? s_ - 1 : 0] == DSIM_RT_FAR;
         // x_k += x_k[source lane] * w: a row shift, the whole-wave shift by one lane, or one far edge by v_readlane
         if constexpr (kind == DSIM_RT_ROW)
-            ex.template add_from_above<dist, s_ == 0>(x.w.x, x.w.y, x.w.z, x.v.x, x.v.y, x.v.z, tp.rt_w[s_]);
+            ex.template add_from_above<dist, GUARD>(x.w.x, x.w.y, x.w.z, x.v.x, x.v.y, x.v.z, tp.rt_w[s_]);
         else if constexpr (kind == DSIM_RT_WAVE1)
-            ex.template add_from_next<s_ == 0>(x.w.x, x.w.y, x.w.z, x.v.x, x.v.y, x.v.z, tp.rt_w[s_]);
+            ex.template add_from_next<GUARD>(x.w.x, x.w.y, x.w.z, x.v.x, x.v.y, x.v.z, tp.rt_w[s_]);
         else
             ex.template add_from_lane<dist>(x.w.x, x.w.y, x.w.z, x.v.x, x.v.y, x.v.z, tp.rt_w[s_]);
     });
@@ -1630,69 +1749,70 @@ template <class Ctx> DSIM_FN constexpr int dsim_tmask_static() {
 }
 
 // semi-implicit Euler (sim.py:1505-1636); in place on q, qd.  Loads first, then arithmetic, then stores.
-template <class Ctx, class Exec> DSIM_FN void dsim_fwd_integrate(const Ctx& c, Exec& ex) {
-    ex.mark(6);
-    ex.run([&](int lane) {
-        constexpr int MASK = dsim_tmask_static<Ctx>();
-        constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
-        const float h = c.h;
-        for (int i = lane; i < c.d.L; i += Exec::NL) {
-            int type, cs, ds;
-            if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
-                const DsimTopoRegs& tp = ex.topo(lane);
-                type = tp.own_type; cs = tp.own_cs; ds = tp.own_ds;
-                DSIM_OPAQUE(type);
-            } else {
-                type = CI(jtype)[i]; cs = CI(qstart)[i]; ds = CI(qdstart)[i];
-            }
-            float *q = WF(q), *qd = WF(qd);
-            const float* qdd = WF(qdd);
-            float qv[NQ > 0 ? NQ : 1], qdv[NDF > 0 ? NDF : 1], av[NDF > 0 ? NDF : 1];
+template <class Ctx, class Exec> DSIM_FN void dsim_integrate_lane(const Ctx& c, Exec& ex, int lane) {
+    constexpr int MASK = dsim_tmask_static<Ctx>();
+    constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
+    const float h = c.h;
+    for (int i = lane; i < c.d.L; i += Exec::NL) {
+        int type, cs, ds;
+        if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
+            const DsimTopoRegs& tp = ex.topo(lane);
+            type = tp.own_type; cs = tp.own_cs; ds = tp.own_ds;
+            DSIM_OPAQUE(type);
+        } else {
+            type = CI(jtype)[i]; cs = CI(qstart)[i]; ds = CI(qdstart)[i];
+        }
+        float *q = WF(q), *qd = WF(qd);
+        const float* qdd = WF(qdd);
+        float qv[NQ > 0 ? NQ : 1], qdv[NDF > 0 ? NDF : 1], av[NDF > 0 ? NDF : 1];
 #pragma unroll
-            for (int k = 0; k < NQ; ++k) qv[k] = q[cs + k];
+        for (int k = 0; k < NQ; ++k) qv[k] = q[cs + k];
 #pragma unroll
-            for (int k = 0; k < NDF; ++k) {
-                qdv[k] = qd[ds + k];
-                av[k] = qdd[ds + k];
-            }
-            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
-                const float qdn = qdv[0] + av[0] * h;
-                qd[ds] = qdn;
-                q[cs] = qv[0] + qdn * h;
-            }
-            if constexpr ((MASK & (DSIM_TM(DSIM_JOINT_BALL) | DSIM_TM(DSIM_JOINT_FREE))) != 0) {
-                if (type == DSIM_JOINT_BALL || type == DSIM_JOINT_FREE) {
-                    const bool fr = type == DSIM_JOINT_FREE;
-                    const v3 w = mk3(qdv[0], qdv[1], qdv[2]) + mk3(av[0], av[1], av[2]) * h;
-                    q4 r;
-                    v3 pn = zero3(), vn = zero3();
-                    if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
-                        if (fr) {
-                            vn = mk3(qdv[3], qdv[4], qdv[5]) + mk3(av[3], av[4], av[5]) * h;
-                            const v3 p = mk3(qv[0], qv[1], qv[2]);
-                            pn = p + (vn + cross(w, p)) * h;
-                            r = mkq(qv[3], qv[4], qv[5], qv[6]);
-                        } else {
-                            r = mkq(qv[0], qv[1], qv[2], qv[3]);
-                        }
+        for (int k = 0; k < NDF; ++k) {
+            qdv[k] = qd[ds + k];
+            av[k] = qdd[ds + k];
+        }
+        if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
+            const float qdn = qdv[0] + av[0] * h;
+            qd[ds] = qdn;
+            q[cs] = qv[0] + qdn * h;
+        }
+        if constexpr ((MASK & (DSIM_TM(DSIM_JOINT_BALL) | DSIM_TM(DSIM_JOINT_FREE))) != 0) {
+            if (type == DSIM_JOINT_BALL || type == DSIM_JOINT_FREE) {
+                const bool fr = type == DSIM_JOINT_FREE;
+                const v3 w = mk3(qdv[0], qdv[1], qdv[2]) + mk3(av[0], av[1], av[2]) * h;
+                q4 r;
+                v3 pn = zero3(), vn = zero3();
+                if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
+                    if (fr) {
+                        vn = mk3(qdv[3], qdv[4], qdv[5]) + mk3(av[3], av[4], av[5]) * h;
+                        const v3 p = mk3(qv[0], qv[1], qv[2]);
+                        pn = p + (vn + cross(w, p)) * h;
+                        r = mkq(qv[3], qv[4], qv[5], qv[6]);
                     } else {
                         r = mkq(qv[0], qv[1], qv[2], qv[3]);
                     }
-                    const q4 dr = qmul_v(w, r) * 0.5f;
-                    const q4 rt = r + dr * h;
-                    const float l = sqrtf(qdot(rt, rt));
-                    q4 rn = mkq(0.f, 0.f, 0.f, 1.f);
-                    if (l > 0.0f) rn = rt * (1.0f / l);
-                    if (fr) {
-                        st3(q + cs, pn);
-                        st3(qd + ds + 3, vn);
-                    }
-                    stq(q + cs + (fr ? 3 : 0), rn);
-                    st3(qd + ds, w);
+                } else {
+                    r = mkq(qv[0], qv[1], qv[2], qv[3]);
                 }
+                const q4 dr = qmul_v(w, r) * 0.5f;
+                const q4 rt = r + dr * h;
+                const float il = dsim_inv_len(qdot(rt, rt));
+                q4 rn = mkq(0.f, 0.f, 0.f, 1.f);
+                if (il > 0.0f) rn = rt * il;
+                if (fr) {
+                    st3(q + cs, pn);
+                    st3(qd + ds + 3, vn);
+                }
+                stq(q + cs + (fr ? 3 : 0), rn);
+                st3(qd + ds, w);
             }
         }
-    });
+    }
+}
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_integrate(const Ctx& c, Exec& ex) {
+    ex.mark(6);
+    ex.run([&](int lane) { dsim_integrate_lane(c, ex, lane); });
 }
 
 // ---- forward dynamics of a substep in ONE phase (small models, one wavefront per environment) -----------------------------
@@ -1872,12 +1992,8 @@ DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float*
                 }
                 const q4 dr = qmul_v(w, r) * 0.5f;
                 const q4 rt = r + dr * h;
-                const float l = sqrtf(qdot(rt, rt));
-                float il = 0.f;
-                if (l > 0.0f) {
-                    il = 1.0f / l;
-                    rn = rt * il;
-                }
+                const float il = dsim_inv_len(qdot(rt, rt));
+                if (il > 0.0f) rn = rt * il;
                 if constexpr (DsimSavedIl<Ctx, Exec>::value) {
                     if (is_link && fr) WF(qil)[0] = il;
                 }
@@ -1965,7 +2081,8 @@ template <class Ctx, class Exec> DSIM_FN void dsim_check_unit_quats(const Ctx& c
 // one substep on the LDS-resident state; g_row / g_hinv: where to stream the saved block / the fresh inverse (or null)
 template <class Ctx, class Exec>
 DSIM_FN void dsim_fwd_substep(const Ctx& c, Exec& ex, bool update_mass, float* g_row = nullptr, float* g_hinv = nullptr) {
-    dsim_fwd_kinematics(c, ex, DsimWaveDyn<Ctx, Exec>::value ? g_row : nullptr);
+    constexpr bool wide = DsimWideOverlap<Ctx, Exec>::value;
+    dsim_fwd_kinematics(c, ex, (DsimWaveDyn<Ctx, Exec>::value || wide) ? g_row : nullptr);
     dsim_fwd_external(c, ex);
     if constexpr (DsimWaveDyn<Ctx, Exec>::value) {
         if (update_mass) dsim_fwd_mass(c, ex);   // H depends on the kinematics only
@@ -1976,6 +2093,20 @@ DSIM_FN void dsim_fwd_substep(const Ctx& c, Exec& ex, bool update_mass, float* g
     dsim_fwd_tau(c, ex);
     if (update_mass) dsim_fwd_mass(c, ex);
     dsim_fwd_solve(c, ex);
+    if constexpr (wide) {
+        // The first wavefront integrates (link lanes); the others copy the rest of the checkpoint row meanwhile -- X_sc .. qdd,
+        // which the integrator does not touch; the head (q, qd) went out beside the kinematics -- and, on a refresh, the inverse.
+        ex.mark(6);
+        constexpr int NLR = Exec::NL - DSIM_NL;
+        ex.fork_wave0([&](int lane) { dsim_integrate_lane(c, ex, lane); }, [&](int lane) {
+            if (g_row) {
+                dsim_ckpt_store_row<Ctx, NLR, 2>(c, lane, g_row);
+                if (update_mass && g_hinv)
+                    for (int k = lane; k < c.d.nd * c.d.nd; k += NLR) g_hinv[k] = WF(hinv)[k];
+            }
+        });
+        return;
+    }
     if (g_row) {
         // Checkpoint row = the saved block.  Global stores to this environment's private row that nobody in this launch
         // reads back: no wait -- they drain while the step goes on (16 bytes per lane and instruction: the saved block
@@ -2147,8 +2278,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_wave(const Ctx& c, 
                 if constexpr (DsimSavedIl<Ctx, Exec>::value) {
                     il = WF(qil)[0];   // from the forward launch, through the checkpoint
                 } else {
-                    const float l = sqrtf(qdot(rt, rt));
-                    if (l > 0.0f) il = 1.0f / l;
+                    il = dsim_inv_len(qdot(rt, rt));
                 }
                 if (il > 0.0f) {
                     const q4 rn = rt * il;
@@ -2253,8 +2383,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
                     if constexpr (DsimSavedIl<Ctx, Exec>::value) {
                         il = WF(qil)[0];   // from the forward launch, through the checkpoint: no square root, no division here
                     } else {
-                        const float l = sqrtf(qdot(rt, rt));
-                        if (l > 0.0f) il = 1.0f / l;
+                        il = dsim_inv_len(qdot(rt, rt));
                     }
                     if (il > 0.0f) {
                         const q4 rn = rt * il;
@@ -2458,11 +2587,15 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_joint_space(const Ctx& c,
 // wrenches of different points / different sources simply add (dsim_bwd_bodies).  Per contact: [wrench 6, cotangent of
 // the body's twist 6]; per muscle segment: [wrench on link 0, wrench on link 1, cotangent of the activation].
 // Runs inside the first body-level phase (both only need af); items are dealt from the top lane of the wavefront down.
-template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external_items(const Ctx& c, Exec& ex, int real_lane) {
-    const int lane = Exec::NL - 1 - real_lane;
-    for (int k = lane; k < c.d.C; k += Exec::NL) {
+// NLX: lanes the items are dealt to (Exec::NL: all lanes of the environment, from the top lane down; fewer -- the wavefronts behind
+// the first one, DsimWideOverlap: contacts from the top lane down, segments from lane 0 up, so that a lane's second item is of
+// the other kind where the lists allow it)
+template <int NLX, class Ctx, class Exec> DSIM_FN void dsim_bwd_external_items_n(const Ctx& c, Exec& ex, int real_lane) {
+    constexpr bool ALL = NLX == Exec::NL;
+    const int lane = NLX - 1 - real_lane;
+    for (int k = lane; k < c.d.C; k += NLX) {
         int b;
-        if constexpr (DsimContactRegs<Ctx, Exec::NL>::value) b = ex.topo(real_lane).cbody_b;
+        if constexpr (ALL && DsimContactRegs<Ctx, Exec::NL>::value) b = ex.topo(real_lane).cbody_b;
         else b = CI(cbody)[k];
         const v3 xp = ld3(WF(xsc) + 7 * b);
         const q4 xq = ldq(WF(xsc) + 7 * b + 3);
@@ -2484,12 +2617,11 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external_items(const Ctx&
             const float fn = cc * ke;
             const float vmin = vn < 0.0f ? vn : 0.0f;
             const float fd = vmin * kd * (0.0f - cc);
-            const float lt = sqrtf(dot(vt, vt));
+            const float vt2 = dot(vt, vt), ilt = dsim_inv_len(vt2), lt = vt2 * ilt;   // (as in dsim_contact_wrench)
             const float a1 = kf * lt, a2 = 0.0f - mu * cc * ke;
             const bool first = a1 < a2;
             const float smin = first ? a1 : a2;
-            v3 nhat = zero3();
-            if (lt > 0.0f) nhat = vt * (1.0f / lt);
+            const v3 nhat = vt * ilt;
             const v3 ft = nhat * smin;
             const v3 F = mk3(ft.x, fn + fd, ft.z);
             v3 a_p = cross(F, A.w);
@@ -2501,8 +2633,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external_items(const Ctx&
             float a_lt = 0.f, a_c = 0.f, a_vn = 0.f;
             if (first) a_lt += kf * a_s;
             else a_c += -mu * ke * a_s;
-            v3 a_vt = zero3();
-            if (lt > 0.0f) a_vt = (a_nhat - nhat * dot(nhat, a_nhat)) * (1.0f / lt) + nhat * a_lt;
+            const v3 a_vt = (a_nhat - nhat * dot(nhat, a_nhat)) * ilt + nhat * a_lt;   // (zero at vt = 0: normalize / length have zero gradients there)
             if (vn < 0.0f) a_vn += kd * (0.0f - cc) * a_fnfd;
             a_c += -vmin * kd * a_fnfd;
             a_c += ke * a_fnfd;
@@ -2520,34 +2651,32 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external_items(const Ctx&
         stsv(o, wr);
         stsv(o + 6, tw);
     }
-    for (int s = lane; s < c.d.NS; s += Exec::NL) {
-        const int w = CI(seg_wp)[s];
-        const int l0 = CI(mlinks)[w], l1 = CI(mlinks)[w + 1];
-        const v3 pos0 = ld3(WF(xsc) + 7 * l0) + rotate(ldq(WF(xsc) + 7 * l0 + 3), ld3(CF(mpoints) + 3 * w));
-        const v3 pos1 = ld3(WF(xsc) + 7 * l1) + rotate(ldq(WF(xsc) + 7 * l1 + 3), ld3(CF(mpoints) + 3 * w + 3));
-        const float act = WF(mact)[CI(seg_m)[s]];
-        const sv6 A0 = ldsv(WF(af) + 6 * l0), A1 = ldsv(WF(af) + 6 * l1);
+    for (int s = ALL ? lane : real_lane; s < c.d.NS; s += NLX) {
+        const DsimSegRec sg = dsim_seg_rec(c, s);
+        const DsimSegIn in = dsim_seg_load(c, sg);
+        // (af rows are [L][6], X_sc rows [L][7]: 6 * link = offset - offset / 7)
+        const sv6 A0 = ldsv(WF(af) + (sg.x0 - sg.x0 / 7)), A1 = ldsv(WF(af) + (sg.x1 - sg.x1 / 7));
+        const v3 pos0 = in.p0 + rotate(in.r0, in.m0), pos1 = in.p1 + rotate(in.r1, in.m1);
+        const float act = in.act;
         const v3 d = pos1 - pos0;
-        const float l = sqrtf(dot(d, d));
-        v3 f = zero3();
-        if (l > 0.0f) f = d * (act / l);
+        const float il = dsim_inv_len_item(dot(d, d));
+        const v3 n = d * il, f = n * act;   // (n = 0 for d = 0: every term below is zero then)
         const v3 a_f = cross(A1.w, pos1) + A1.v - cross(A0.w, pos0) - A0.v;
         v3 a_p0 = -cross(f, A0.w);
         v3 a_p1 = cross(f, A1.w);
-        float a_act = 0.f;
-        if (l > 0.0f) {
-            const v3 n = d * (1.0f / l);
-            a_act = dot(n, a_f);
-            const v3 a_n = a_f * act;
-            const v3 a_d = (a_n - n * dot(n, a_n)) * (1.0f / l);
-            a_p1 += a_d;
-            a_p0 -= a_d;
-        }
+        const float a_act = dot(n, a_f);
+        const v3 a_n = a_f * act;
+        const v3 a_d = (a_n - n * dot(n, a_n)) * il;
+        a_p1 += a_d;
+        a_p0 -= a_d;
         // the forward wrench rows are dead by now: same buffer, same body-sorted rows + one activation cotangent per segment
-        stsv(WF(mus) + 6 * CI(seg_slot)[2 * s], mksv(cross(pos0, a_p0), a_p0));
-        stsv(WF(mus) + 6 * CI(seg_slot)[2 * s + 1], mksv(cross(pos1, a_p1), a_p1));
+        stsv(WF(mus) + sg.r0, mksv(cross(pos0, a_p0), a_p0));
+        stsv(WF(mus) + sg.r1, mksv(cross(pos1, a_p1), a_p1));
         WF(mus)[12 * c.d.NS + s] = a_act;
     }
+}
+template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external_items(const Ctx& c, Exec& ex, int real_lane) {
+    dsim_bwd_external_items_n<Exec::NL>(c, ex, real_lane);
 }
 
 // mass matrix^T (update substeps): aH -> aS (added), ai10m.
@@ -2816,9 +2945,8 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
     ex.run([&](int lane) {
         for (int m = lane; m < c.d.M; m += Exec::NL) {
             // a muscle's active segments are consecutive rows of `mus`: batched range sum, not a serial chain of loads
-            const int s0 = CI(ms_start)[m], s1 = CI(ms_start)[m + 1];
             const float g = WF(amact)[m];
-            WF(amact)[m] = g + dsim_range_sum(WF(mus) + 12 * c.d.NS, 1, 0, s0, s1 - s0, 0.f);
+            WF(amact)[m] = g + dsim_muscle_act_sum(c, m);
         }
         if constexpr (DsimTrunk<Ctx, Exec>::value) dsim_trunk_sum<true>(c, ex, lane, WF(aa), nullptr, 0, 0, WF(aatot));
         for (int it = lane; it < (DsimTrunk<Ctx, Exec>::value ? 0 : 6 * c.d.L); it += Exec::NL) {
@@ -2844,7 +2972,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
                 // r < 6: pose wrench of the body = its muscle rows (chunk sums) + its contacts; r >= 6: the twist cotangent of
                 // its contacts
                 float acc = 0.f;
-                if (r < 6) acc = dsim_range_sum(WF(mpart), 6, r, CI(mb_start)[i], CI(mb_start)[i + 1] - CI(mb_start)[i], 0.f);
+                if (r < 6) acc = dsim_body_chunk_sum(c, i, r, 0.f);
                 WF(agx)[it] = dsim_body_contact_sum(c, i, WF(acx), 12, r, acc);
             }
         });
@@ -3011,12 +3139,22 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies(const Ctx& c, Exec
 // its joint coordinates.  The one thing that comes from other lanes' ITEMS is the contact terms: the side block (the helper
 // wavefront where there is one) evaluates contacts^T per contact and reduces them per body (agx: pose wrench 6, twist cotangent
 // 6); the link lanes pick their body's row up at Exec::side_done(), after the first third of their work.
-template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx& c, Exec& ex, bool update_mass) {
+// What the wavefronts behind the first one do at the END of an adjoint substep's body level when the two run side by side
+// (DsimWideOverlap): bring in the checkpoint row of the NEXT adjoint substep -- requested one substep earlier, Exec::prefetch_rest --
+// and, where that substep starts a mass-matrix group, the inverse the group's forward substeps used; then request the row after it.
+// Nothing the first wavefront still does in this substep reads the saved block or the inverse from LDS.
+struct DsimNextRow {
+    bool any = false;             // there is a next substep (its row waits in the prefetch registers)
+    const float* hv = nullptr;    // ... and it enters a new group: that group's inverse (global memory)
+    const float* after = nullptr; // the row to request afterwards (null: none left)
+};
+template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx& c, Exec& ex, bool update_mass, const DsimNextRow& nx = DsimNextRow{}) {
     ex.mark(10);
     using D = decltype(c.d);
     constexpr int L = D::L, MASK = D::tmask;
     constexpr bool HAS_FREE = (MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0, HAS_BALL = (MASK & DSIM_TM(DSIM_JOINT_BALL)) != 0;
     constexpr bool MUSCLES = D::NS > 0;   // per-item / per-body phases on all wavefronts, the body level on the first one
+    constexpr bool WIDE = MUSCLES && DsimWideOverlap<Ctx, Exec>::value;   // ... at the same time
     auto fm = [&](int lane) __attribute__((always_inline)) {
         const DsimTopoRegs& tp = ex.topo(lane);
         const bool on = lane < L;
@@ -3092,6 +3230,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
             a_v = zerosv();
             W = zerosv();
         }
+        if constexpr (WIDE) ex.mid();   // (the other wavefronts: per-item cotangents done, their chunk sums may start)
         // ---- aatot = subtree sum of aa; joint motion^T
         dsim_rowtree_sum(c, ex, tp, A);
         sv6 vj = zerosv();
@@ -3112,8 +3251,14 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
         a_vj.w = cross(A.w, v.w) + cross(A.v, v.v);
         a_vj.v = cross(A.v, v.w);
         ex.stamp();
-        // ---- the contact (and muscle) terms of the own body, reduced per body by the side block / the phases before this one
-        ex.side_done();
+        // ---- the contact (and muscle) terms of the own body, reduced per body by the side block / the phases before this one /
+        // the other wavefronts
+        if constexpr (WIDE) {
+            ex.mid2();          // (chunk sums done, the per-body gather may start)
+            ex.side_done_w();   // the per-body rows are there
+        } else {
+            ex.side_done();
+        }
         const sv6 cpose = ldsv(WF(agx) + 12 * i), ctw = ldsv(WF(agx) + 12 * i + 6);
         ex.loads_landed();
         // ---- avtot = subtree sum of (a_v + contact twist cotangents); cotangents of qd and of S; S is attached to the joint frame
@@ -3175,15 +3320,51 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
             }
         }
     };
-    if constexpr (MUSCLES) {
+    if constexpr (WIDE) {
+        // first wavefront: the body level; the others, at the same time: per item contacts^T, muscles^T | per muscle the activation
+        // cotangent, chunk sums of the muscle rows | per body: muscle + contact pose wrenches (6), contact twist cotangents (6) |
+        // the next substep's checkpoint row
+        constexpr int NLR = Exec::NL - DSIM_NL;
+        ex.fork_wave0([&](int lane) {
+            fm(lane);
+            if (nx.hv) dsim_hacc_zero(c, ex, lane);
+        }, [&](int lane) {
+            dsim_bwd_external_items_n<NLR>(c, ex, lane);
+            ex.mid();
+            dsim_muscle_chunk_sums(c, lane, NLR);
+            ex.mid2();
+            for (int it = lane; it < 12 * c.d.L; it += NLR) {
+                const int i = it / 12, r = it - 12 * i;
+                float acc = 0.f;
+                if (r < 6) acc = dsim_body_chunk_sum(c, i, r, 0.f);
+                WF(agx)[it] = dsim_body_contact_sum(c, i, WF(acx), 12, r, acc);
+            }
+            ex.side_done_w();
+            // nothing the first wavefront still needs: the activation cotangents (one sum per muscle) and the next row
+            for (int m = lane; m < c.d.M; m += NLR) {
+                const float gm = WF(amact)[m];
+                WF(amact)[m] = gm + dsim_muscle_act_sum(c, m);
+            }
+            if (nx.any) {
+                ex.commit_rest(WF(q), dsim_row(c), lane);
+                if (nx.hv) {
+                    for (int k = lane; k < c.d.nd * c.d.nd; k += NLR) {
+                        WF(hinv)[k] = nx.hv[k];
+                        WF(aH)[k] = 0.f;
+                    }
+                    dsim_hacc_zero(c, ex, lane + DSIM_NL);
+                }
+                if (nx.after) ex.prefetch_rest(nx.after, dsim_row(c));
+            }
+        });
+    } else if constexpr (MUSCLES) {
         // per item (all wavefronts): contacts^T, muscles^T; per muscle: the activation cotangent; chunk sums of the muscle rows;
         // per body: muscle pose wrenches + contact pose wrenches (6), contact twist cotangents (6) -- the phases of dsim_bwd_bodies
         ex.run([&](int lane) { dsim_bwd_external_items(c, ex, lane); });
         ex.run([&](int lane) {
             for (int m = lane; m < c.d.M; m += Exec::NL) {
-                const int s0 = CI(ms_start)[m], s1 = CI(ms_start)[m + 1];
                 const float gm = WF(amact)[m];
-                WF(amact)[m] = gm + dsim_range_sum(WF(mus) + 12 * c.d.NS, 1, 0, s0, s1 - s0, 0.f);
+                WF(amact)[m] = gm + dsim_muscle_act_sum(c, m);
             }
             dsim_muscle_chunk_sums(c, lane, Exec::NL);
         });
@@ -3191,7 +3372,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
             for (int it = lane; it < 12 * c.d.L; it += Exec::NL) {
                 const int i = it / 12, r = it - 12 * i;
                 float acc = 0.f;
-                if (r < 6) acc = dsim_range_sum(WF(mpart), 6, r, CI(mb_start)[i], CI(mb_start)[i + 1] - CI(mb_start)[i], 0.f);
+                if (r < 6) acc = dsim_body_chunk_sum(c, i, r, 0.f);
                 WF(agx)[it] = dsim_body_contact_sum(c, i, WF(acx), 12, r, acc);
             }
         });
@@ -3231,12 +3412,20 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_recompute_forward(const C
     dsim_fwd_solve(c, ex);
 }
 
-template <class Ctx, class Exec> DSIM_FN void dsim_bwd_substep(const Ctx& c, Exec& ex, bool update_mass) {
+// nx: DsimWideOverlap only (the body level brings the next substep's checkpoint row in, see DsimNextRow)
+template <class Ctx, class Exec> DSIM_FN void dsim_bwd_substep(const Ctx& c, Exec& ex, bool update_mass, const DsimNextRow& nx = DsimNextRow{}) {
     dsim_bwd_joint_space(c, ex, update_mass);
     if (update_mass) dsim_bwd_mass(c, ex);
-    if constexpr (DsimRowTree<Ctx, Exec>::value) dsim_bwd_bodies_rowtree(c, ex, update_mass);
+    if constexpr (DsimRowTree<Ctx, Exec>::value) dsim_bwd_bodies_rowtree(c, ex, update_mass, nx);
     else dsim_bwd_bodies(c, ex, update_mass);
 }
+// the body level of the adjoint substeps commits the checkpoint rows itself (first wavefront: body level, the others: items and rows)
+template <class Ctx, class Exec> struct DsimWideRows {
+    static constexpr bool value = []() {
+        if constexpr (DsimRowTree<Ctx, Exec>::value) return DsimWideOverlap<Ctx, Exec>::value;
+        else return false;
+    }();
+};
 
 // Reverse sweep of one env.step().  g_ckpt is this environment's [substeps][nq+nd] checkpoint.
 template <class Ctx, class Exec>
@@ -3283,6 +3472,20 @@ DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
                         }
                         dsim_hacc_zero(c, ex, lane);
                     });
+            } else if constexpr (DsimWideRows<Ctx, Exec>::value) {
+                // only the launch's first row is committed here; every later one by the body level of the substep before it
+                if (s == substeps - 1) {
+                    ex.prefetch(g_ckpt + (size_t)s * dsim_row(c), dsim_row(c));
+                    ex.run([&](int lane) {
+                        ex.commit(WF(q), dsim_row(c), lane);
+                        for (int k = lane; k < nd * nd; k += Exec::NL) {
+                            WF(hinv)[k] = hv[k];
+                            WF(aH)[k] = 0.f;
+                        }
+                        dsim_hacc_zero(c, ex, lane);
+                    });
+                    if (s > 0) ex.prefetch_rest(g_ckpt + (size_t)(s - 1) * dsim_row(c), dsim_row(c));
+                }
             } else {
                 if (s == substeps - 1) ex.prefetch(g_ckpt + (size_t)s * dsim_row(c), dsim_row(c));
                 ex.run([&](int lane) {
@@ -3299,7 +3502,13 @@ DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
             }
             if constexpr (Ctx::LEAN) dsim_bwd_recompute_forward(c, ex);
             if (s == s0) dsim_fwd_composite(c, ex);
-            dsim_bwd_substep(c, ex, s == s0);  // aq / aqd (== aqn / aqdn, same LDS words) now belong to substep s - 1
+            DsimNextRow nx;
+            if constexpr (DsimWideRows<Ctx, Exec>::value) {
+                nx.any = s > 0;
+                nx.hv = (s == s0 && g > 0) ? dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, g - 1) : nullptr;
+                nx.after = s > 1 ? g_ckpt + (size_t)(s - 2) * dsim_row(c) : nullptr;
+            }
+            dsim_bwd_substep(c, ex, s == s0, nx);  // aq / aqd (== aqn / aqdn, same LDS words) now belong to substep s - 1
         }
     }
     ex.run([&](int lane) {
@@ -3335,6 +3544,7 @@ struct DsimEnvSpec {
     int act_offset;      // joint_act[act_offset + k] = clip(a_k) * act_scale[k]            (act_muscle == 0)
     int act_muscle;      // muscle_act[k] = (clip(a_k) * 0.5 + 0.5) * act_scale[k]           (act_muscle == 1)
     int obs_actions;     // append the (clipped / remapped) actions to the observation
+    int sanitize;        // the adjoint launch returns 0 for non-finite cotangents (include/dsim.h: sanitize_grads)
     float isr[4];        // conjugate of the start rotation
     float tgt_x, tgt_z;  // targets + start_pos (x, z)
     float term_h, term_tol, h_scale, act_pen, vel_scale;
@@ -3966,7 +4176,9 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
                         load_hinv(lane, hv);
                         dsim_hacc_zero(c, ex, lane);
                     });
-            } else {
+            } else if (!DsimWideRows<Ctx, Exec>::value || s == substeps - 1) {
+                // (DsimWideRows: only the launch's first row is committed here, every later one -- with its group's inverse -- by the
+                // body level of the substep before it)
                 if (!IO::PRE && s == substeps - 1) ex.prefetch(g_ckpt + (size_t)s * dsim_row(c), dsim_row(c));
                 ex.run([&](int lane) {
                     ex.commit(WF(q), dsim_row(c), lane);
@@ -3987,16 +4199,29 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
                         dsim_hacc_zero(c, ex, lane);
                     }
                 });
-                if (s > 0) ex.prefetch(g_ckpt + (size_t)(s - 1) * dsim_row(c), dsim_row(c));
+                if (s > 0) {
+                    if constexpr (DsimWideRows<Ctx, Exec>::value) ex.prefetch_rest(g_ckpt + (size_t)(s - 1) * dsim_row(c), dsim_row(c));
+                    else ex.prefetch(g_ckpt + (size_t)(s - 1) * dsim_row(c), dsim_row(c));
+                }
             }
             if constexpr (Ctx::LEAN) dsim_bwd_recompute_forward(c, ex);
             if (s == s0) dsim_fwd_composite(c, ex);
-            dsim_bwd_substep(c, ex, s == s0);  // aq / aqd (== aqn / aqdn, same LDS words) now belong to substep s - 1
+            DsimNextRow nx;
+            if constexpr (DsimWideRows<Ctx, Exec>::value) {
+                nx.any = s > 0;
+                nx.hv = (s == s0 && g > 0) ? dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, g - 1) : nullptr;
+                nx.after = s > 1 ? g_ckpt + (size_t)(s - 2) * dsim_row(c) : nullptr;
+            }
+            dsim_bwd_substep(c, ex, s == s0, nx);  // aq / aqd (== aqn / aqdn, same LDS words) now belong to substep s - 1
         }
     }
+    // sanitize: torch.nan_to_num(grad, 0.0, 0.0, 0.0) of the reference's per-step hooks on joint_q / joint_qd / actions
+    // (envs/humanoid.py:195-206), applied where the three cotangents leave the launch
+    const bool scrub = sp.sanitize != 0;
+    auto clean = [&](float x) __attribute__((always_inline)) { return (scrub && !(fabsf(x) <= 3.4028235e38f)) ? 0.f : x; };
     ex.run([&](int lane) {
-        for (int k = lane; k < nq; k += Exec::NL) g_gq_in[k] = WF(aqn)[k];
-        for (int k = lane; k < nd; k += Exec::NL) g_gqd_in[k] = WF(aqdn)[k];
+        for (int k = lane; k < nq; k += Exec::NL) g_gq_in[k] = clean(WF(aqn)[k]);
+        for (int k = lane; k < nd; k += Exec::NL) g_gqd_in[k] = clean(WF(aqdn)[k]);
         const float* io = ex.io(lane);
         dsim_io_each<IO::CA, Exec::NL>(sp.n_act, lane, [&](int k, int u) {
             const float a = IO::PRE ? io[IO::ACT + u] : g_actions[k];
@@ -4004,7 +4229,7 @@ DSIM_FN void dsim_env_fused_backward(const Ctx& c, Exec& ex, const DsimEnvSpec& 
             float g = WF(gua)[k];
             if (sp.act_muscle) g = 0.5f * (g + sc * WF(amact)[k]);
             else g += sc * WF(aact)[sp.act_offset + k];
-            g_gactions[k] = (a >= -1.0f && a <= 1.0f) ? g : 0.f;
+            g_gactions[k] = (a >= -1.0f && a <= 1.0f) ? clean(g) : 0.f;
         });
     });
 }

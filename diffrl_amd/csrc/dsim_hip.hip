@@ -48,6 +48,24 @@ namespace {
 #endif
 __device__ __forceinline__ void dsim_wave_sync() { asm volatile(DSIM_WAVE_SYNC_ASM ::: "memory"); }
 
+// reciprocal of a pivot: v_rcp_f32 + one Newton step (< 1 ulp on the pivots of an SPD matrix; ~3 instead of the ~11 instructions
+// of the correctly rounded division on the pivot's dependent chain; -DDSIM_EXACT_DIV_SQRT builds the A/B variant with 1.0f / x)
+__device__ __forceinline__ float dsim_pivot_rcp(float x) {
+#if !defined(DSIM_EXACT_DIV_SQRT) && !defined(DSIM_EXACT_RCP)
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+#else
+    return 1.0f / x;
+#endif
+}
+// Gauss-Jordan inverse with lane i holding row i in registers.  Per pivot k the classical in-place update is
+//   row k <- p = (row k with column k := 1) / h_kk;  row i <- (row i with column k := 0) - h_ik p        (dsim_core.hpp: dsim_fwd_mass)
+// i.e. per column: broadcast h_kj, scale it, multiply-add, select the pivot row: four instructions (-DDSIM_CLASSIC_GJ builds that
+// form for A/B runs; round 5 measured the deferred form below at -1 % .. -7 % of the forward launch, Ant .. SNUHumanoid).  The pivot
+// row's scaling commutes with every LATER row operation (they are linear in the row), so lane k keeps its row UNSCALED -- column k
+// set to 1 -- remembers 1 / h_kk and scales once at the end; every other row takes f h_kj with f = h_ik / h_kk, lane k with f = 0:
+// per column one v_readlane and one multiply-add, no select.  Same elimination, different rounding (f h_kj instead of
+// h_ik (h_kj / h_kk)); the generic kernels keep the classical form, the tests hold both to the reference.
 template <int N, int NW> __device__ __forceinline__ void dsim_wave_gj(float* H) {
     const int lane = (int)threadIdx.x;
     if (NW > 1 && lane >= DSIM_NL) return;
@@ -55,10 +73,29 @@ template <int N, int NW> __device__ __forceinline__ void dsim_wave_gj(float* H) 
     float row[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) row[j] = H[r * N + j];
+#ifndef DSIM_CLASSIC_GJ
+    float scale = 1.0f;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const float piv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row[k]), k));
-        const float rp = 1.0f / piv;
+        const float rp = dsim_pivot_rcp(piv);
+        const bool own = lane == k;
+        const float f = own ? 0.0f : row[k] * rp;
+        scale = own ? rp : scale;
+        row[k] = own ? 1.0f : 0.0f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float hkj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row[j]), k));
+            row[j] = __builtin_fmaf(-f, hkj, row[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) row[j] *= scale;
+#else
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float piv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row[k]), k));
+        const float rp = dsim_pivot_rcp(piv);
         const float cik = row[k];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -67,6 +104,7 @@ template <int N, int NW> __device__ __forceinline__ void dsim_wave_gj(float* H) 
             row[j] = (lane == k) ? pj : ((j == k ? 0.0f : row[j]) - cik * pj);
         }
     }
+#endif
     if (lane < N) {
 #pragma unroll
         for (int j = 0; j < N; ++j) H[lane * N + j] = row[j];
@@ -80,11 +118,31 @@ template <int N> __device__ __forceinline__ void dsim_half_gj(float* H, int lane
     float row[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) row[j] = H[r * N + j];
+#ifndef DSIM_CLASSIC_GJ
+    float scale = 1.0f;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const int src = (k << 2) + half_addr;
         const float piv = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(row[k])));
-        const float rp = 1.0f / piv;
+        const float rp = dsim_pivot_rcp(piv);
+        const bool own = lane == k;
+        const float f = own ? 0.0f : row[k] * rp;
+        scale = own ? rp : scale;
+        row[k] = own ? 1.0f : 0.0f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float hkj = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(row[j])));
+            row[j] = __builtin_fmaf(-f, hkj, row[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) row[j] *= scale;
+#else
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int src = (k << 2) + half_addr;
+        const float piv = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(row[k])));
+        const float rp = dsim_pivot_rcp(piv);
         const float cik = row[k];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -93,6 +151,7 @@ template <int N> __device__ __forceinline__ void dsim_half_gj(float* H, int lane
             row[j] = (lane == k) ? pj : ((j == k ? 0.0f : row[j]) - cik * pj);
         }
     }
+#endif
     if (lane < N) {
 #pragma unroll
         for (int j = 0; j < N; ++j) H[lane * N + j] = row[j];
@@ -170,7 +229,8 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false, int EPW = 1> stru
     int stamp_i_ = 0, stamp_tag_ = 0;
     // main wave: entries [0, 8192), helper wave: [8192, 16384) (its tags + 50)
     __device__ __forceinline__ void stamp() {
-        const bool main_lane = threadIdx.x == 0, help_lane = HELPER && threadIdx.x == DSIM_NL;
+        // (several wavefronts per environment: the second track is the SECOND wavefront's first lane)
+        const bool main_lane = threadIdx.x == 0, help_lane = (HELPER || NW > 1) && threadIdx.x == DSIM_NL;
         if (blockIdx.x == 0 && (main_lane || help_lane) && stamp_i_ < 8192) {
             const int k = stamp_i_ + (help_lane ? 8192 : 0);
             g_dsim_stamps[k] = clock64();
@@ -345,8 +405,30 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false, int EPW = 1> stru
         }
     }
     __device__ __forceinline__ void mid() {
-        if constexpr (HELPER) group_barrier();
+        if constexpr (HELPER || NW > 1) group_barrier();
         else dsim_wave_sync();
+        if constexpr (NW > 1) stamp();
+    }
+    // Several wavefronts per environment (dsim_core.hpp: DsimWideOverlap): f0 is the block of the FIRST wavefront (link lanes, with
+    // its cross-lane primitives), fr the block of the others, which sees lanes 0 .. NL - 64 - 1 -- two different instruction
+    // streams at the same time.  Where one needs what the other has written both call the same hand-over point -- mid(), mid2(),
+    // side_done(): workgroup barriers, so every wavefront must pass each of them exactly once -- and the phase ends with the
+    // barrier of sync().  (A branch on the wavefront index is uniform per wave: s_barrier counts waves, not lanes.)
+    template <class F0, class FR> __device__ __forceinline__ void fork_wave0(F0&& f0, FR&& fr) {
+        static_assert(NW > 1, "fork_wave0 belongs to the mapping with several wavefronts per environment");
+        if (threadIdx.x < DSIM_NL) f0((int)threadIdx.x);
+        else fr((int)threadIdx.x - DSIM_NL);
+        asm volatile("" ::: "memory");
+        stamp();
+        group_barrier();
+        stamp();
+    }
+    __device__ __forceinline__ void mid2() {
+        if constexpr (NW > 1) {
+            stamp();   // (developer builds: this wave's arrival; the next stamp is behind the barrier -- the difference is waiting)
+            group_barrier();
+            stamp();
+        }
     }
     // ... and without the barrier at the end: fh is a DETACHED side block -- nothing it reads is written, and nothing it writes is
     // read, before the next barrier that both waves take (the checkpoint copy beside the integrator: the next substep's
@@ -389,9 +471,16 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false, int EPW = 1> stru
             sync();
         }
     }
+    // (several wavefronts: a no-op inside run_wave0, whose inputs were finished behind the barrier in front of it; the barrier of
+    // fork_wave0's first wavefront -- side_done_w())
     __device__ __forceinline__ void side_done() {
         if constexpr (HELPER) group_barrier();
         else if constexpr (NW == 1) dsim_wave_sync();
+    }
+    __device__ __forceinline__ void side_done_w() {
+        stamp();
+        group_barrier();
+        stamp();
     }
     // phase that only writes global memory nobody in this launch reads back: no vmcnt wait.  One wave: no barrier either
     // (its LDS reads precede, in program order, whatever the next phase stores); several waves: the LDS words it reads
@@ -507,6 +596,32 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false, int EPW = 1> stru
             }
         }
     }
+    // the same by the wavefronts BEHIND the first one alone (dsim_core.hpp: DsimWideRows; NL - 64 lanes): requested from any phase
+    // (the first wavefront returns at once), committed from fork_wave0's second block, which sees lanes 0 .. NL - 64 - 1
+    __device__ __forceinline__ void prefetch_rest(const float* row, int words) {
+        constexpr int NLR = NL - DSIM_NL;
+        pf_src = row;
+        if (threadIdx.x < DSIM_NL || words > 4 * NLR * DSIM_PF) return;
+        const v4f* r4 = reinterpret_cast<const v4f*>(row);
+#pragma unroll
+        for (int r = 0; r < DSIM_PF; ++r) {
+            const int k = (int)threadIdx.x - DSIM_NL + NLR * r;
+            if (4 * k < words) pf[r] = r4[k];
+        }
+    }
+    __device__ __forceinline__ void commit_rest(float* dst, int words, int lane) {
+        constexpr int NLR = NL - DSIM_NL;
+        if (words > 4 * NLR * DSIM_PF) {
+            for (int k = lane; k < words; k += NLR) dst[k] = pf_src[k];
+            return;
+        }
+        v4f* d4 = reinterpret_cast<v4f*>(dst);
+#pragma unroll
+        for (int r = 0; r < DSIM_PF; ++r) {
+            const int k = lane + NLR * r;
+            if (4 * k < words) d4[k] = pf[r];
+        }
+    }
     __device__ __forceinline__ void commit(float* dst, int words, int lane) {
         if (words > 4 * NL * DSIM_PF) {
             for (int k = lane; k < words; k += NL) dst[k] = pf_src[k];
@@ -530,6 +645,11 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false, int EPW = 1> stru
 #ifndef DSIM_PAIR_WAVES
 #define DSIM_PAIR_WAVES 0
 #endif
+// Kernels with several wavefronts per environment (SNUHumanoid: 4 waves, LDS for two environments per CU) need two resident waves
+// per SIMD -- 256 registers per lane, accumulation registers included: one more halves the environments in flight and doubles the
+// launch time (measured in round 5: the operator-level adjoint at 257: 0.29 -> 0.53 ms).  The bound makes the compiler keep to it.
+// (Not the lean-checkpoint kernels: their adjoint carries the forward phases too and would spill to scratch memory under it.)
+#define DSIM_WIDE_WAVES(NW) (((NW) > 1 && !LEAN) ? 2 : 0)
 #define DSIM_MODE_PLAIN 0
 #define DSIM_MODE_HELPER 1
 #define DSIM_MODE_PAIR 2
@@ -590,7 +710,8 @@ template <class O> constexpr int dsim_const_words() {
 }
 template <class O, int NW, bool LEAN, int MODE = 0> constexpr int dsim_pf_regs() {
     if constexpr (std::is_empty<O>::value) {
-        constexpr int words = LEAN ? O::xsc - O::q : O::save_words, lanes = DSIM_NL * NW / (MODE == 2 ? 2 : 1);
+        // (several wavefronts: rows may be brought in by the wavefronts behind the first one alone, DevExec::prefetch_rest)
+        constexpr int words = LEAN ? O::xsc - O::q : O::save_words, lanes = DSIM_NL * (NW > 1 ? NW - 1 : NW) / (MODE == 2 ? 2 : 1);
         return (words / 4 + lanes - 1) / lanes;
     } else {
         return 6;
@@ -620,7 +741,7 @@ __device__ __forceinline__ DsimCtxT<O, D, LEAN> start_env(float* lds, const KCom
 }
 
 template <class O, class D, int NW, bool LEAN, int MODE>
-__global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1)), (MODE == DSIM_MODE_PAIR ? DSIM_PAIR_WAVES : 0)) void dsim_fwd_kernel(KCommonT<O, D> k, const float* __restrict__ q_in,
+__global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1)), (MODE == DSIM_MODE_PAIR ? DSIM_PAIR_WAVES : DSIM_WIDE_WAVES(NW))) void dsim_fwd_kernel(KCommonT<O, D> k, const float* __restrict__ q_in,
                                                            const float* __restrict__ qd_in,
                                                            const float* __restrict__ act,
                                                            const float* __restrict__ mact, float* q_out,
@@ -637,7 +758,7 @@ __global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1)), (MODE == DSIM
 }
 
 template <class O, class D, int NW, bool LEAN, int MODE>
-__global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1))) void dsim_bwd_kernel(KCommonT<O, D> k, const float* __restrict__ ckpt,
+__global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1)), DSIM_WIDE_WAVES(NW)) void dsim_bwd_kernel(KCommonT<O, D> k, const float* __restrict__ ckpt,
                                                            const float* __restrict__ act,
                                                            const float* __restrict__ mact,
                                                            const float* __restrict__ gq_out,
@@ -655,7 +776,7 @@ __global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1))) void dsim_bwd
 }
 
 template <class O, class D, int NW, bool LEAN, int MODE>
-__global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1)), (MODE == DSIM_MODE_PAIR ? DSIM_PAIR_WAVES : 0)) void dsim_env_fwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp, DsimEpisode ep,
+__global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1)), (MODE == DSIM_MODE_PAIR ? DSIM_PAIR_WAVES : DSIM_WIDE_WAVES(NW))) void dsim_env_fwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp, DsimEpisode ep,
                                                                const float* __restrict__ q_in,
                                                                const float* __restrict__ qd_in,
                                                                const float* __restrict__ actions, float* q_out,
@@ -672,7 +793,7 @@ __global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1)), (MODE == DSIM
 }
 
 template <class O, class D, int NW, bool LEAN, int MODE>
-__global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1))) void dsim_env_bwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp,
+__global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1)), DSIM_WIDE_WAVES(NW)) void dsim_env_bwd_kernel(KCommonT<O, D> k, DsimEnvSpec sp,
                                                                const float* __restrict__ ckpt,
                                                                const float* __restrict__ actions,
                                                                const float* __restrict__ gq_out,
@@ -795,6 +916,14 @@ template <int NW> struct TimingExec {
     __device__ __forceinline__ void helper_prefetch_aux(const float*, int) {}
     __device__ __forceinline__ void helper_commit_aux(float*, float*, int) {}
     __device__ __forceinline__ void mid() { __syncthreads(); }
+    __device__ __forceinline__ void mid2() { if constexpr (NW > 1) __syncthreads(); }
+    __device__ __forceinline__ void side_done_w() { __syncthreads(); }
+    template <class F0, class FR> __device__ __forceinline__ void fork_wave0(F0&& f0, FR&& fr) {
+        run([&](int lane) {
+            if (lane < DSIM_NL) f0(lane);
+            else fr(lane - DSIM_NL);
+        });
+    }
     __device__ __forceinline__ void stamp() {}
     DsimImage<NW, 0> img_;
     __device__ __forceinline__ void begin_request() {}
@@ -829,6 +958,10 @@ template <int NW> struct TimingExec {
     __device__ __forceinline__ void prefetch(const float* row, int) { pf_src = row; }
     __device__ __forceinline__ void commit(float* dst, int words, int lane) {
         for (int k = lane; k < words; k += NL) dst[k] = pf_src[k];
+    }
+    __device__ __forceinline__ void prefetch_rest(const float* row, int) { pf_src = row; }
+    __device__ __forceinline__ void commit_rest(float* dst, int words, int lane) {
+        for (int k = lane; k < words; k += NL - DSIM_NL) dst[k] = pf_src[k];
     }
 };
 template <class O, class D, int NW>
@@ -1049,7 +1182,7 @@ int make_spec(const dsim_model* m, const dsim_env_spec* e, DsimEnvSpec& sp) {
     }
     if (e->n_obs != expect) return fail(DSIM_ERR_INVALID, "n_obs does not match the observation layout");
     sp.kind = e->kind; sp.rew_kind = e->rew_kind; sp.n_act = e->n_act; sp.n_obs = e->n_obs;
-    sp.act_offset = e->act_offset; sp.act_muscle = e->act_muscle; sp.obs_actions = e->obs_actions;
+    sp.act_offset = e->act_offset; sp.act_muscle = e->act_muscle; sp.obs_actions = e->obs_actions; sp.sanitize = e->sanitize_grads;
     for (int k = 0; k < 4; ++k) { sp.isr[k] = e->inv_start_rot[k]; sp.pen[k] = e->cartpole_penalties[k]; }
     sp.tgt_x = e->target_x; sp.tgt_z = e->target_z; sp.term_h = e->termination_height;
     sp.term_tol = e->termination_tolerance; sp.h_scale = e->height_rew_scale; sp.act_pen = e->action_penalty;
@@ -1062,7 +1195,7 @@ int make_spec(const dsim_model* m, const dsim_env_spec* e, DsimEnvSpec& sp) {
 extern "C" {
 
 const char* dsim_last_error(void) { return g_err.c_str(); }
-int dsim_version(void) { return 105; }
+int dsim_version(void) { return 106; }
 
 int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
     if (!desc || !out) return fail(DSIM_ERR_INVALID, "null argument");

@@ -18,7 +18,8 @@
 #define DSIM_TRUNK_MAX 6
 #define DSIM_TRUNK_CH 4
 #define DSIM_LIGHT_CAP 8    // register budget of the light sums: LCAP, CCAP <= this
-#define DSIM_MUSCLE_CHUNK 12
+#define DSIM_MUSCLE_CHUNK 16   // rows per chunk of the per-body muscle-row gather (SNUHumanoid: 396 rows in 30 chunks -- 180 (chunk, component) items,
+                               // one pass over the 192 lanes that sum them beside the first wavefront's link-level work)
 #define DSIM_TAIL_PAD 384
 #define DSIM_RT_MAX 16      // steps of a row-tree sum (DsimDims::RT_N)
 struct DsimDims {
@@ -88,6 +89,10 @@ struct DsimOff {
     // rows are summed by one lane each (one LDS round trip), then the chunk sums of a body -- a body with 86 rows was 11
     // dependent round trips of one lane.  mc_row / mc_cnt: first row and row count of chunk e; mb_start: body -> its chunks.
     int mc_row, mc_cnt, mb_start;
+    // packed per-segment record [NS][8] (16-byte aligned): 7 * link 0, 7 * link 1 (X_sc offsets), 3 * first waypoint (mpoints offset),
+    // muscle index, 6 * row of link 0, 6 * row of link 1 (offsets into `mus`), 0, 0 -- ONE LDS round trip (two 16-byte reads) for what
+    // seg_wp -> mlinks -> ... is three dependent ones
+    int seg_rec;
     int mlinks;
     // ---- constant block: floats
     int xpj, com, axis, ic6, mass, tke, tkd, lke, lkd, target, lower, upper, arm;
@@ -378,6 +383,20 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.mc_cnt = put_i(mc_cnt.data(), MK);
     o.mb_start = put_i(mb_start.data(), L + 1);
     o.mlinks = put_i(m.muscle_links, W);
+    {
+        while (blob.size() % 4) blob.push_back(0);
+        std::vector<int> rec(8 * (size_t)NS, 0);
+        for (int sgm = 0; sgm < NS; ++sgm) {
+            const int w = seg_wp[sgm];
+            rec[8 * sgm + 0] = 7 * m.muscle_links[w];
+            rec[8 * sgm + 1] = 7 * m.muscle_links[w + 1];
+            rec[8 * sgm + 2] = 3 * w;
+            rec[8 * sgm + 3] = seg_m[sgm];
+            rec[8 * sgm + 4] = 6 * seg_slot[2 * sgm];
+            rec[8 * sgm + 5] = 6 * seg_slot[2 * sgm + 1];
+        }
+        o.seg_rec = put_i(rec.data(), rec.size());
+    }
     o.xpj = put_f(m.joint_X_pj, 7 * L);
     std::vector<float> com(3 * L), ic6(6 * L), mass(L);
     for (int i = 0; i < L; ++i) {

@@ -91,6 +91,63 @@ DSIM_FN q4 rotate_adj_q(q4 q, v3 x, v3 r) {
     v3 av = cross(x, r) * (2.0f * q.w) + x * (2.0f * dot(qv, r)) + r * (2.0f * dot(qv, x));
     return q4{av.x, av.y, av.z, aw};
 }
+// 1 / sqrt(n2) for the normalisation of a quaternion (0 for n2 == 0: the reference's normalize() leaves a zero quaternion alone,
+// quat.h:70-83).  Device code: v_rsq_f32 + one Newton step -- as accurate as the reference's two correctly rounded operations
+// (square root, division) together (< 1 ulp), ~6 instead of ~30 dependent instructions on the one lane that integrates the free
+// root; not the same bits (-DDSIM_EXACT_DIV_SQRT builds the A/B variant; the host harness of tests/emu always takes that path).
+DSIM_FN float dsim_inv_len_exact(float n2) {
+    const float l = sqrtf(n2);
+    return l > 0.0f ? 1.0f / l : 0.0f;
+}
+DSIM_FN float dsim_inv_len_fast(float n2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float y = __builtin_amdgcn_rsqf(n2);
+    const float r = y * __builtin_fmaf(-0.5f * n2 * y, y, 1.5f);
+    return n2 > 0.0f ? r : 0.0f;
+#else
+    return dsim_inv_len_exact(n2);
+#endif
+}
+// The reference's two operations -- l = sqrt(n2), then 1 / l -- each from the hardware approximation plus one residual correction
+// (sqrt: l = n2 rsq(n2), l += (n2 - l l) rsq(n2) / 2; reciprocal: c = rcp(l), c += (1 - l c) c): the corrected values are the
+// correctly rounded ones except for rare halfway cases, so the result follows the reference's roundings instead of replacing two
+// roundings by a differently rounded 1 / sqrt -- which matters where it is applied 512 times in a row to the same quantity.
+DSIM_FN float dsim_inv_len_two_step(float n2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float y = __builtin_amdgcn_rsqf(n2);
+    float l = n2 * y;
+    l = __builtin_fmaf(__builtin_fmaf(-l, l, n2), 0.5f * y, l);
+    float c = __builtin_amdgcn_rcpf(l);
+    c = __builtin_fmaf(__builtin_fmaf(-l, c, 1.0f), c, c);
+    return n2 > 0.0f ? c : 0.0f;
+#else
+    return dsim_inv_len_exact(n2);
+#endif
+}
+// ... of a quaternion in the integrator (one lane, on the critical path of every substep) and of a contact's tangential velocity.
+// Round 5 measured the plain v_rsq_f32 + Newton form at these two sites against the reference's recordings: in the integrator
+// 15 instead of 3 of the 512 sampled Ant environments left the 1e-3 band, in the contact friction 14 instead of 8 of the 128
+// sampled Humanoid environments (tools/ant_grad_probe.py; the pivots' v_rcp_f32 + Newton and the muscle segments' one-step
+// form changed nothing) -- these are the values friction regimes and contact thresholds hang on, and the quantity the integrator
+// renormalises 512 times per rollout.  They keep the reference's two roundings (dsim_inv_len_two_step: same counts as the
+// correctly rounded operations; -DDSIM_INTEG_RSQ builds the one-step form).
+DSIM_FN float dsim_inv_len(float n2) {
+#if defined(DSIM_EXACT_DIV_SQRT) || defined(DSIM_EXACT_RSQ_INTEG)
+    return dsim_inv_len_exact(n2);
+#elif defined(DSIM_INTEG_RSQ)
+    return dsim_inv_len_fast(n2);
+#else
+    return dsim_inv_len_two_step(n2);
+#endif
+}
+// ... of a muscle segment (per-item lanes; a smooth function of the poses, no thresholds)
+DSIM_FN float dsim_inv_len_item(float n2) {
+#if defined(DSIM_EXACT_DIV_SQRT) || defined(DSIM_EXACT_RSQ_ITEM)
+    return dsim_inv_len_exact(n2);
+#else
+    return dsim_inv_len_fast(n2);
+#endif
+}
 // sin/cos of a joint half-angle.  Joint angles live inside their limits (|q| <= ~pi), so |x| <= pi/2 is the
 // hot case: odd/even Taylor polynomials to x^11 / x^12 (truncation error < 6e-8 at pi/2, i.e. below fp32
 // resolution) -- ~14 FMAs instead of two library calls with full range reduction; anything larger falls

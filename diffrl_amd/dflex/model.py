@@ -295,14 +295,14 @@ class State:
         self._joint_act = None
         self._act_like = act_like
         self._xf_model = model   # whoever produces the state passes the Model (Model.state, the integrator, DFlexEnv.step)
-        self._xf_ckpt = None     # (checkpoint, substeps) of the step that produced this state, when gradients were on
+        self._xf_q = None        # joint_q entering the last substep of the step that produced this state, when gradients were on
         self._xf = None
 
     # Derived tensors of the reference's State (model.py:338-392) that leave LDS only on request: body_X_sc / body_X_sm
     # ([n_envs * n_links, 7], no grad_fn -- the reference's are plain outputs of eval_rigid_fk too).  One small launch on first
     # access (dsim_body_transforms), cached per state object.  After forward() the reference's tensors belong to the joint
     # coordinates that ENTERED the last substep (eval_rigid_fk runs before the integrator, sim.py:2316-2601); the integrator
-    # remembers the step's checkpoint (`_xf_ckpt`) when gradients are on, whose last row starts with exactly those coordinates,
+    # copies them out of the step's checkpoint (`_xf_q`, n_q floats per environment) when gradients are on,
     # so the values match; in no-grad mode there is no checkpoint and the transforms are those of this state's own joint_q
     # (one substep ahead of the reference's: h later).  A state that did not come out of a step (Model.state(), reset) has no
     # such lag in the reference either... it has zeros there; here: the transforms of its joint_q.
@@ -311,7 +311,7 @@ class State:
             if self._xf_model is None:
                 raise RuntimeError("this State was not produced by a Model / integrator: no engine to derive body transforms with")
             eng = self._xf_model.engine()
-            q = eng.last_substep_q(*self._xf_ckpt) if self._xf_ckpt is not None else self.joint_q
+            q = self._xf_q if self._xf_q is not None else self.joint_q
             self._xf = eng.body_transforms(q)
         return self._xf
 

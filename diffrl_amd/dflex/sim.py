@@ -28,7 +28,7 @@ class SemiImplicitIntegrator:
         else:
             out.joint_q, out.joint_qd = SimStep.apply(eng, float(dt), int(substeps), int(mass_matrix_freq),
                                                       state_in.joint_q, state_in.joint_qd, state_in.joint_act, mact)
-        out._xf_ckpt = eng.last_ckpt   # None in no-grad mode (State.body_X_sc then derives from out.joint_q)
+        out._xf_q = eng.last_q_in if not config.no_grad else None   # None in no-grad mode (State.body_X_sc then derives from out.joint_q)
         if config.verify_fp and not (torch.isfinite(out.joint_q).all() and torch.isfinite(out.joint_qd).all()):
             raise FloatingPointError("non-finite state after SemiImplicitIntegrator.forward")
         return out

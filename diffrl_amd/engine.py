@@ -42,7 +42,10 @@ class Engine:
         assert int(self._lib.dsim_model_device(h)) == self.device.index
         self.variant = int(self._lib.dsim_model_variant(h))  # 0 = generic kernels, > 0 = specialised for this model
         self.n_q, self.n_qd, self.n_muscles = template.n_q, template.n_qd, template.n_muscles
-        self.last_ckpt = None
+        # joint_q ENTERING the last substep of the most recent forward() with gradients on ([n_envs, n_q], a copy: n_q floats per
+        # environment -- never a reference to the checkpoint itself, which is hundreds of MB for the humanoid and must die with
+        # its autograd node): what State.body_X_sc derives the reference's lagging transforms from (dflex/sim.py)
+        self.last_q_in = None
 
     def __del__(self):
         try:
@@ -89,7 +92,9 @@ class Engine:
         if t.numel() % max(cols, 1) != 0:
             raise capi.DsimError("%s has %d elements, not a multiple of %d" % (name, t.numel(), cols))
 
-    def forward(self, q, qd, act, mact, dt, substeps, mm_freq, need_ckpt):
+    def forward(self, q, qd, act, mact, dt, substeps, mm_freq, need_ckpt, keep_q_in=False):
+        """keep_q_in: also copy joint_q entering the last substep out of the checkpoint (-> self.last_q_in; one small copy kernel,
+        asked for by the operator boundary only: SimStep / SemiImplicitIntegrator.forward)"""
         self._check(q, self.n_q, "joint_q")
         self._check(qd, self.n_qd, "joint_qd")
         self._check(act, self.n_qd, "joint_act")
@@ -105,12 +110,14 @@ class Engine:
         ckpt = None
         if need_ckpt:
             ckpt = self._alloc_ckpt(n, substeps, mm_freq)
-        self.last_ckpt = (ckpt, substeps) if ckpt is not None else None   # (State.body_X_sc reads its last row's q on request)
+        self.last_q_in = None
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             capi.check(self._lib.dsim_step_forward(self._h, n, _ptr(q), _ptr(qd), _ptr(act),
                                                    _ptr(mact) if self.n_muscles else None, C.c_float(dt), substeps,
                                                    mm_freq, _ptr(q_out), _ptr(qd_out), _ptr(ckpt), st))
+        if ckpt is not None and keep_q_in:
+            self.last_q_in = self.last_substep_q(ckpt, substeps)
         return q_out, qd_out, ckpt
 
     def _check_ckpt(self, ckpt, substeps, mm_freq):
@@ -153,7 +160,6 @@ class Engine:
         obs = torch.empty((n, spec.n_obs), dtype=torch.float32, device=self.device)
         rew = torch.empty(n, dtype=torch.float32, device=self.device)
         ckpt = self._alloc_ckpt(n, substeps, mm_freq) if need_ckpt else None
-        self.last_ckpt = (ckpt, substeps) if ckpt is not None else None
         ep, extra = None, ()
         if episode is not None:
             ep, extra = episode.bind(self, n, spec.n_obs)
@@ -271,7 +277,8 @@ class SimStep(torch.autograd.Function):
         mact = mact.contiguous() if mact is not None else None
         need = any(t is not None and t.requires_grad for t in (q, qd, act, mact))
         q_out, qd_out, ckpt = engine.forward(q.detach(), qd.detach(), act.detach(),
-                                             mact.detach() if mact is not None else None, dt, substeps, mm_freq, need)
+                                             mact.detach() if mact is not None else None, dt, substeps, mm_freq, need,
+                                             keep_q_in=True)
         ctx.engine, ctx.dt, ctx.substeps, ctx.mm_freq = engine, dt, substeps, mm_freq
         ctx.has_mact = mact is not None
         ctx.shapes = (q.shape, qd.shape, act.shape, mact.shape if mact is not None else None)

@@ -120,6 +120,10 @@ class DFlexEnv:
     def _spec(self):
         if getattr(self, "_spec_cache", None) is None:
             self._spec_cache = self.fused_spec()
+            if self._spec_cache is not None:
+                # the reference's nan_to_num hooks on joint_q / joint_qd / actions (humanoid.py:195-206): done by the adjoint
+                # launch's own output stores (include/dsim.h: sanitize_grads), not by three torch kernels per step
+                self._spec_cache.sanitize_grads = int(bool(self.sanitize_grads))
         return self._spec_cache
 
     def stored_actions(self, actions):
@@ -158,6 +162,27 @@ class DFlexEnv:
         self.state, self.actions = saved_state, saved_actions
         return q.contiguous(), qd.contiguous()
 
+    def _start_state_key(self):
+        """what the cached start states / noise amplitudes are built from (host-side only: identity + in-place version counter
+        of the tensors, no device work, no host sync; the key's tensors are kept referenced, an id() alone could be recycled)"""
+        def stamp(v):
+            return (id(v), v._version) if torch.is_tensor(v) else v
+        attrs = tuple(getattr(self, a, None) for a in ("start_pos", "start_rotation", "start_joint_q", "start_joint_target", "start_height"))
+        self._pool_key_refs = attrs
+        return (bool(getattr(self, "stochastic_init", False)),) + tuple(stamp(v) for v in attrs)
+
+    def _check_pinned_pool(self, key=None):
+        """raises if a GraphedRollout was captured on this environment and the start-state settings changed since: the captured
+        launches hold the device pointers of the pool / noise tensors AND the launch arguments derived from them (noise on or
+        off, the rotation amplitude), a replay cannot follow such a change.  A key comparison, nothing else: no EpisodeIO is
+        built, no start state drawn (GraphedRollout.replay calls this on every replay)."""
+        if not getattr(self, "_pool_pinned", False) or getattr(self, "_pool", None) is None:
+            return
+        if (key if key is not None else self._start_state_key()) != getattr(self, "_pool_key", None):
+            raise RuntimeError("%s: stochastic_init or a start-state attribute changed after a GraphedRollout was captured on "
+                               "this environment; build a new GraphedRollout (the captured launches keep the old start "
+                               "states)" % type(self).__name__)
+
     def _episode_io(self):
         """EpisodeIO of the fused step: progress_buf, the deterministic start state of every environment and -- with
         stochastic resets -- the noise amplitudes the kernel perturbs it with (a fresh counter-based draw per restart:
@@ -168,18 +193,10 @@ class DFlexEnv:
         # step while the torch reset() path honours it
         # (identity + in-place version counter of the tensors: no device work, no host sync -- this runs on every step)
         # (the key keeps a reference to each tensor: an id() alone could be recycled by a NEW tensor after the old one died)
-        def stamp(v):
-            return (id(v), v._version) if torch.is_tensor(v) else v
-        attrs = tuple(getattr(self, a, None) for a in ("start_pos", "start_rotation", "start_joint_q", "start_joint_target", "start_height"))
-        self._pool_key_refs = attrs
-        key = (bool(getattr(self, "stochastic_init", False)),) + tuple(stamp(v) for v in attrs)
+        key = self._start_state_key()
         stale = getattr(self, "_pool", None) is not None and getattr(self, "_pool_key", None) != key
-        if stale and getattr(self, "_pool_pinned", False):
-            # a captured GraphedRollout holds the device pointers of the pool / noise tensors AND the launch arguments that
-            # were derived from them (noise on or off, the rotation amplitude): a replay cannot follow such a change
-            raise RuntimeError("%s: stochastic_init or a start-state attribute changed after a GraphedRollout was captured on "
-                               "this environment; build a new GraphedRollout (the captured launches keep the old start "
-                               "states)" % type(self).__name__)
+        if stale:
+            self._check_pinned_pool(key)
         if getattr(self, "_pool", None) is None or stale:
             self._pool_key = key
             q0, qd0 = self._deterministic_start_state()
@@ -215,12 +232,7 @@ class DFlexEnv:
 
     def _step_fused(self, actions, spec):
         actions = actions.view((self.num_envs, self.num_actions))
-        if self.sanitize_grads:
-            def scrub(grad):
-                return torch.nan_to_num(grad, 0.0, 0.0, 0.0)
-            for t in (self.state.joint_q, self.state.joint_qd, actions):
-                if t.requires_grad:
-                    t.register_hook(scrub)
+        # (sanitize_grads: scrubbed inside the adjoint launch, see _spec; the unfused path below keeps the torch hooks)
         eng = self.model.engine()
         epi = self._episode_io()
         if self.no_grad:

@@ -46,8 +46,10 @@ class GraphedRollout:
         # Finished environments restart inside the captured step kernels: the start state is perturbed with counter-based
         # random numbers keyed by the per-environment restart counter, which lives in device memory and advances with every
         # replay -- nothing has to be drawn on the host (the reference's reset_state() indexed writes are not capturable).
-        env._episode_io()
-        if not carry_state:
+        # (an environment captured on its unfused torch path has no in-kernel restarts and no pool: nothing to build or pin)
+        if getattr(env, "fused", False):
+            env._episode_io()
+        if not carry_state and getattr(env, "_reset_count", None) is not None:
             # the in-kernel restart noise is keyed by the per-environment restart counter, which every replay advances: a
             # replay that restarts from the construction state must restart the counters too, or replays with
             # stochastic_init would draw different start states ("deterministic benchmark")
@@ -97,7 +99,7 @@ class GraphedRollout:
 
     def replay(self):
         """re-executes the captured rollout (forward + backward); returns the static loss tensor"""
-        self.env._episode_io()   # raises if the start-state settings changed since the capture (host-side check, no GPU work)
+        self.env._check_pinned_pool()   # raises if the start-state settings changed since the capture (a key comparison only)
         self.graph.replay()
         if self._frames_per_replay:
             self.env.num_frames += self._frames_per_replay

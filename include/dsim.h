@@ -208,6 +208,10 @@ typedef struct dsim_env_spec {
     int32_t act_offset;   /* joint_act[act_offset + k] = clip(a_k,-1,1) * act_scale[k]        (act_muscle == 0) */
     int32_t act_muscle;   /* muscle_act[k] = (clip(a_k,-1,1) * 0.5 + 0.5) * act_scale[k]      (act_muscle == 1) */
     int32_t obs_actions;  /* observation ends with the stored actions */
+    int32_t sanitize_grads; /* dsim_env_step_backward writes 0 for every non-finite cotangent it would return (gq_in, gqd_in,
+                             * gactions): the nan_to_num(grad, 0, 0, 0) hooks that the reference's humanoid environments register on
+                             * state.joint_q / joint_qd / actions in every step (envs/humanoid.py:195-206, snu_humanoid.py:253-264),
+                             * done in the adjoint launch's own output stores instead of three extra torch kernels per step (ABI 106) */
     float inv_start_rot[4];
     float target_x, target_z;      /* targets + start_pos */
     float termination_height, termination_tolerance, height_rew_scale, action_penalty, joint_vel_obs_scaling;

@@ -46,6 +46,9 @@ def pytest_terminal_summary(terminalreporter):
     tr.section("probed tolerances (stated: 1e-3)")
     if not probe_ledger.ENTRIES:
         tr.write_line("none: every gradient comparison of this run passed at the stated 1e-3")
+    for tid, (n, what) in probe_ledger.SAMPLED.items():
+        used = sum(1 for r in probe_ledger.ENTRIES if r["test"] == tid)
+        tr.write_line("%s %s: %d of %d compared cases probed (%.2f %%)" % (tid, what, used, n, 100.0 * used / max(n, 1)))
     for r in probe_ledger.ENTRIES:
         tr.write_line("%s [%s] %s: error %.2e, reference-order sensitivity %.2e, accepted up to %.2e (case %d of budget %d)"
                       % (r["test"], r["level"], r["what"], r["error"], r["sensitivity"], r["tolerance"], r["used"], r["budget"]))

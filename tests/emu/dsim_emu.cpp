@@ -93,8 +93,8 @@ template <int NW, int LANES = DSIM_NL> struct HostExecT {
     // DPP row shift of the device executor: lane + D of the same 16-lane row, 0 beyond the row's end
     template <int D> float from_above(float v) {
         const int lane = cur_, src = lane + D;
-        const float r = shfl(v, src < NL ? src : lane);
-        return (src < NL && (src >> 4) == (lane >> 4)) ? r : 0.f;
+        const float r = shfl(v, src < LANES ? src : lane);
+        return (src < LANES && (src >> 4) == (lane >> 4)) ? r : 0.f;
     }
     template <int D> float from_below(float v) {
         const int lane = cur_, src = lane - D;
@@ -103,7 +103,7 @@ template <int NW, int LANES = DSIM_NL> struct HostExecT {
     }
     template <bool FIRST = true> void add_from_next(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5, float w) {
         const int lane = cur_;
-        auto nx = [&](float v) { const float r = shfl(v, lane + 1 < NL ? lane + 1 : lane); return lane + 1 < NL ? r : 0.f; };
+        auto nx = [&](float v) { const float r = shfl(v, lane + 1 < LANES ? lane + 1 : lane); return lane + 1 < LANES ? r : 0.f; };
         const float y0 = nx(a0), y1 = nx(a1), y2 = nx(a2), y3 = nx(a3), y4 = nx(a4), y5 = nx(a5);
         a0 = __builtin_fmaf(y0, w, a0); a1 = __builtin_fmaf(y1, w, a1); a2 = __builtin_fmaf(y2, w, a2);
         a3 = __builtin_fmaf(y3, w, a3); a4 = __builtin_fmaf(y4, w, a4); a5 = __builtin_fmaf(y5, w, a5);
@@ -140,7 +140,40 @@ template <int NW, int LANES = DSIM_NL> struct HostExecT {
     // fm hands over to fh at its mid() call (device: the helper's barrier): every lane passes mid() before any lane gets to fh
     template <class FM, class FH> void fork_join_mid(FM&& fm, FH&& fh) { fork_join(fm, fh); }
     template <class FM, class FH> void fork_mid_detached(FM&& fm, FH&& fh) { fork_join(fm, fh); }
-    void mid() { arrive(); }
+    // Several wavefronts (device: DevExec::fork_wave0): the first wavefront's lanes and the others' run as coroutines of one group;
+    // mid() / mid2() / side_done_w() are WORKGROUP BARRIERS there -- no lane passes one before every lane of the group has reached
+    // it -- while the first wavefront's cross-lane primitives (shfl, lds_fence) stay lock-step points of its own lanes only (the
+    // other lanes' blocks use none).
+    int bar_n_ = 0, bar_cnt_ = 0, bar_gen_ = 0;
+    void wbar() {
+        const int gen = bar_gen_;
+        if (++bar_cnt_ == bar_n_) {
+            bar_cnt_ = 0;
+            ++bar_gen_;
+        }
+        do arrive();
+        while (bar_gen_ == gen);
+    }
+    template <class F0, class FR> void fork_wave0(F0&& f0, FR&& fr) {
+        static_assert(NW > 1, "fork_wave0 belongs to the mapping with several wavefronts per environment");
+        bar_n_ = NL;
+        bar_cnt_ = 0;
+        in_coro_ = true;
+        run_coro([&](int lane) {
+            if (lane < LANES) f0(lane);
+            else fr(lane - LANES);
+        }, NL);
+        in_coro_ = false;
+        bar_n_ = 0;
+    }
+    void mid() {
+        if (bar_n_) wbar();
+        else arrive();
+    }
+    void mid2() {
+        if (bar_n_) wbar();
+    }
+    void side_done_w() { wbar(); }
     // side block first, then the main block, whose side_done() is a point every lane passes (device: the helper's barrier)
     template <class FM, class FH> void fork_side(FM&& fm, FH&& fh) {
         run([&](int lane) {
@@ -151,19 +184,24 @@ template <int NW, int LANES = DSIM_NL> struct HostExecT {
     }
     void side_done() { arrive(); }
     void stamp() {}
-    // host form of the register / v_readlane Gauss-Jordan of the kernels (dsim_hip.hip: dsim_wave_gj): same formulas
+    // host form of the register / v_readlane Gauss-Jordan of the kernels (dsim_hip.hip: dsim_wave_gj, deferred scaling of the
+    // pivot rows): same formulas in the same order (the device's pivot reciprocal is v_rcp_f32 + a Newton step, here 1 / x)
     template <int N> void wave_gj(float* H) {
+        float scale[N];
+        for (int i = 0; i < N; ++i) scale[i] = 1.0f;
         for (int k = 0; k < N; ++k) {
-            float p[N], col[N];
             const float rp = 1.0f / H[k * N + k];
-            for (int j = 0; j < N; ++j) {
-                p[j] = (j == k ? 1.0f : H[k * N + j]) * rp;
-                col[j] = H[j * N + k];
-            }
+            float f[N];
+            for (int i = 0; i < N; ++i) f[i] = (i == k) ? 0.0f : H[i * N + k] * rp;
+            scale[k] = rp;
+            for (int i = 0; i < N; ++i) H[i * N + k] = (i == k) ? 1.0f : 0.0f;
+            float hk[N];
+            for (int j = 0; j < N; ++j) hk[j] = H[k * N + j];
             for (int i = 0; i < N; ++i)
-                for (int j = 0; j < N; ++j)
-                    H[i * N + j] = (i == k) ? p[j] : ((j == k ? 0.0f : H[i * N + j]) - col[i] * p[j]);
+                for (int j = 0; j < N; ++j) H[i * N + j] = __builtin_fmaf(-f[i], hk[j], H[i * N + j]);
         }
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) H[i * N + j] *= scale[i];
     }
     void mark(int) {}
     void begin_request() {}
@@ -180,6 +218,17 @@ template <int NW, int LANES = DSIM_NL> struct HostExecT {
     void prefetch(const float* row, int) { pf_src = row; }
     void commit(float* dst, int words, int lane) {
         for (int k = lane; k < words; k += NL) dst[k] = pf_src[k];
+    }
+    // (per lane: on the device the row waits in each lane's own registers; here a lane of fork_wave0's second block requests the
+    // row after the next while the lanes behind it have not committed theirs yet)
+    const float* pf_rest_[NL] = {};
+    bool in_coro_ = false;
+    void prefetch_rest(const float* row, int) {
+        if (in_coro_) pf_rest_[cur_] = row;
+        else for (int l = 0; l < NL; ++l) pf_rest_[l] = row;
+    }
+    void commit_rest(float* dst, int words, int lane) {
+        for (int k = lane; k < words; k += NL - LANES) dst[k] = pf_rest_[lane + LANES][k];
     }
 };
 typedef HostExecT<1> HostExec;
@@ -277,7 +326,7 @@ extern "C" int dsim_emu_step_backward(const dsim_model_desc* m, int n_envs, cons
 static DsimEnvSpec to_spec(const dsim_env_spec* e) {
     DsimEnvSpec sp;
     sp.kind = e->kind; sp.rew_kind = e->rew_kind; sp.n_act = e->n_act; sp.n_obs = e->n_obs;
-    sp.act_offset = e->act_offset; sp.act_muscle = e->act_muscle; sp.obs_actions = e->obs_actions;
+    sp.act_offset = e->act_offset; sp.act_muscle = e->act_muscle; sp.obs_actions = e->obs_actions; sp.sanitize = e->sanitize_grads;
     for (int k = 0; k < 4; ++k) { sp.isr[k] = e->inv_start_rot[k]; sp.pen[k] = e->cartpole_penalties[k]; }
     sp.tgt_x = e->target_x; sp.tgt_z = e->target_z; sp.term_h = e->termination_height;
     sp.term_tol = e->termination_tolerance; sp.h_scale = e->height_rew_scale; sp.act_pen = e->action_penalty;

@@ -71,3 +71,36 @@ def test_fused_obs_cotangent_matches_finite_difference():
         e[0, k] = 5e-3
         fd[k] = (f(a + e) - f(a - e)) / 1e-2
     assert np.abs(ga[0] - fd).max() < 2e-2 * max(1.0, np.abs(fd).max())
+
+
+def test_sanitize_grads_scrubs_the_returned_cotangents_only_when_asked():
+    """dsim_env_spec.sanitize_grads (include/dsim.h): the adjoint launch writes 0 for every non-finite cotangent it returns --
+    torch.nan_to_num(grad, 0, 0, 0) of the reference's per-step hooks on joint_q / joint_qd / actions (envs/humanoid.py:195-206).
+    A NaN / inf fed into one environment's observation cotangent comes out as zeros there with the flag, as non-finite values
+    without it; the other environment is untouched either way (bit-identical)."""
+    from emu_lib import emu_env_backward, emu_env_forward, env_spec_for
+    from oracle_lib import golden, template_from_golden
+    t = template_from_golden("humanoid")
+    g = golden("humanoid_rollout")
+    spec, keep = env_spec_for("humanoid", t)
+    n = 2
+    q, qd, a = g["q0"][:n], g["qd0"][:n], g["actions"][0][:n]
+    f = emu_env_forward(t, spec, q, qd, a, 1 / 60, 48, 48)
+    rng = np.random.default_rng(5)
+    gq, gqd = rng.normal(size=q.shape).astype(np.float32), rng.normal(size=qd.shape).astype(np.float32)
+    gobs, grew = rng.normal(size=(n, spec.n_obs)).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    clean = emu_env_backward(t, spec, f[4], a, 1 / 60, 48, 48, gq, gqd, gobs, grew)
+    bad = gobs.copy()
+    bad[0, 3] = np.nan
+    bad[0, 20] = np.inf
+    out = {}
+    for flag in (0, 1):
+        spec.sanitize_grads = flag
+        out[flag] = emu_env_backward(t, spec, f[4], a, 1 / 60, 48, 48, gq, gqd, bad, grew)
+    spec.sanitize_grads = 0
+    assert not all(np.isfinite(x[0]).all() for x in out[0]), "without the flag the non-finite cotangent must come through"
+    for x, y, c in zip(out[1], out[0], clean):
+        assert np.isfinite(x).all()
+        np.testing.assert_array_equal(x[1], c[1])                       # the healthy environment: untouched
+        np.testing.assert_array_equal(x[0][np.isfinite(y[0])], y[0][np.isfinite(y[0])])   # finite entries pass through unchanged
+        assert (x[0][~np.isfinite(y[0])] == 0.0).all()                   # non-finite ones become exactly 0

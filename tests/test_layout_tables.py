@@ -194,7 +194,8 @@ def _chain(parents, j):
 
 
 def test_muscle_chunk_tables_cover_the_body_rows():
-    """mc_row / mc_cnt / mb_start (dsim_layout.hpp): the chunks of a body tile its muscle wrench rows, at most 12 rows each"""
+    """mc_row / mc_cnt / mb_start (dsim_layout.hpp): the chunks of a body tile its muscle wrench rows, at most DSIM_MUSCLE_CHUNK = 16
+    rows each; seg_rec: the packed per-segment records agree with the tables they replace on the item phases"""
     from emu_lib import layout
     from oracle_lib import template_from_golden
     t = template_from_golden("snu")
@@ -211,4 +212,17 @@ def test_muscle_chunk_tables_cover_the_body_rows():
     for i in range(L):
         rows = [r for e in range(mb[i], mb[i + 1]) for r in range(row[e], row[e] + cnt[e])]
         assert rows == list(range(ml[i], ml[i + 1]))
-        assert all(0 < cnt[e] <= 12 for e in range(mb[i], mb[i + 1]))
+        assert all(0 < cnt[e] <= 16 for e in range(mb[i], mb[i + 1]))
+    assert 6 * K <= 192, "one pass of the (chunk, component) items over the three wavefronts behind the first one"
+    NS = d["NS"]
+    wp, sm = I[off2["seg_wp"]:off2["seg_wp"] + NS], I[off2["seg_m"]:off2["seg_m"] + NS]
+    slot = I[off2["seg_slot"]:off2["seg_slot"] + 2 * NS]
+    links = I[off2["mlinks"]:off2["mlinks"] + d["W"]]
+    rec = I[off2["seg_rec"]:off2["seg_rec"] + 8 * NS].reshape(NS, 8)
+    assert off2["seg_rec"] % 4 == 0
+    np.testing.assert_array_equal(rec[:, 0], 7 * links[wp])
+    np.testing.assert_array_equal(rec[:, 1], 7 * links[wp + 1])
+    np.testing.assert_array_equal(rec[:, 2], 3 * wp)
+    np.testing.assert_array_equal(rec[:, 3], sm)
+    np.testing.assert_array_equal(rec[:, 4], 6 * slot[0::2])
+    np.testing.assert_array_equal(rec[:, 5], 6 * slot[1::2])

@@ -16,9 +16,15 @@ EP_SUBSTEPS = {"ant": 16, "humanoid": 48, "snu": 48, "hopper": 16, "cheetah": 16
 EP_RULES = {"ant": (True, False), "humanoid": (True, True), "snu": (True, True), "hopper": (True, False),
             "cheetah": (False, False), "cartpole": (False, False)}
 TERM_H = {"ant": 0.27, "humanoid": 0.74, "snu": 0.46, "hopper": -0.45}
-# sampled environments of the full-size recordings that may need a probed tolerance (measured at the shipped kernels:
-# Humanoid 1024 x 32: 10 of 128, SNUHumanoid 512 x 32: 1 of 32)
-FULLSIZE_PROBE_BUDGET = {"humanoid": 12, "snu": 3}
+# sampled environments of the full-size recordings that may need a probed tolerance (measured at the shipped kernels, round 5:
+# Humanoid 1024 x 32: 8 of 128 (round 4: 10), SNUHumanoid 512 x 32: 2 of 32 (round 4: 1))
+FULLSIZE_PROBE_BUDGET = {"humanoid": 10, "snu": 3}
+# Ant 1024 x 32 (BASELINE.json configs[1]), gradients of every 2nd environment (512 sampled; round 5 -- every 8th before, where all
+# 128 passed at 1e-3): measured at the shipped kernels 3 of 512 above 1e-3 (4.9e-3, 3.7e-3, 2.7e-3 -- the same three with every
+# division and square root correctly rounded; 15-17 with a one-step v_rsq_f32 in the integrator, which is why it is not used there:
+# csrc/dsim_math.hpp, dsim_inv_len)
+ANT_PROBE_BUDGET = 5
+ANT_SUBSET_PROBE_BUDGET = 1
 
 
 def _emu_episode_rollout(g, env):
@@ -199,6 +205,69 @@ def test_gpu_h32_rollout_vs_reference(env):
     assert relerr(e.state.joint_q.detach().view(n, -1).cpu().numpy(), g["q_final"]) < 1e-3
 
 
+PROBE_LADDER = ((1e-7, 0), (1e-6, 0), (3e-6, 0), (1e-6, 1), (3e-6, 1), (1e-6, 2), (3e-6, 2), (1e-6, 3), (3e-6, 3),
+                (1e-6, 4), (3e-6, 4), (1e-6, 5), (3e-6, 5), (1e-5, 0), (1e-5, 1), (1e-5, 2))
+
+
+def _per_env_gradient_check(tag, a, r, sel, budget, oracle_grad):
+    """Action gradients a against the recording r, both [H, n_sampled, n_act]; sel: global environment indices of the sampled
+    ones.  Stated tolerance 1e-3 (BASELINE.md section 4, H = 32) PER ENVIRONMENT.  An environment above it must be one whose
+    REFERENCE-order gradient is itself that sensitive: contacts switch on / off and friction switches regime at thresholds, so
+    the gradient of a rollout is piecewise -- a state that differs in the 6th digit (what the fp32 re-association of this
+    implementation amounts to: 10-parameter inertias, composite-body mass matrix, explicit inverse, v_rsq / v_rcp with a Newton
+    step) can sit on the other side of such a threshold for one substep, and the gradient then takes the OTHER branch's value.
+    Probe: oracle_grad(env_indices, scale) recomputes the gradient of those environments with the scalar oracle (reference
+    operation order, same termination rules, same loss) from start states perturbed by 1e-7 .. 1e-5 (relative); the
+    reference-order gradient must move by at least a third of this implementation's error for every such environment.
+    Every use goes through tests/probe_ledger.py: recorded, capped, counted against `budget`.  Returns the well-conditioned mask."""
+    per_env = np.abs(a - r).max(axis=(0, 2)) / (np.abs(r).max(axis=(0, 2)) + 1e-30)
+    well = per_env < 1e-3
+    hard = np.where(~well)[0]
+    import probe_ledger
+    probe_ledger.note_sampled(len(per_env), tag)
+    print("%s: %d of %d sampled environments above 1e-3 (%.1f %%; max %.2e, median %.2e)"
+          % (tag, len(hard), len(per_env), 100.0 * len(hard) / len(per_env), per_env.max(), np.median(per_env)))
+    # the budget is checked BEFORE any probing: an adjoint defect puts every environment above 1e-3, and that must fail
+    # at once instead of asking the oracle n x 16 times whether each of them is "sensitive"
+    assert len(hard) <= budget, ("%s: %d of %d sampled environments above 1e-3, the budget of branch-boundary environments is %d"
+                                 % (tag, len(hard), len(per_env), budget))
+    if len(hard):
+        sens = np.zeros(len(hard))
+        todo = np.arange(len(hard))
+        # (a branch flip is a discrete event that a random perturbation hits or misses: the list is walked until every
+        # environment above 1e-3 has shown it, smallest perturbations first; all of them are far inside the 1e-3 trajectory
+        # tolerance of the start state)
+        for mag, seed in PROBE_LADDER:
+            if not len(todo):
+                break
+            hs = sel[hard[todo]]
+            gp = oracle_grad(hs, mag, seed)
+            rr = r[:, hard[todo]]
+            sens[todo] = np.maximum(sens[todo], np.abs(gp - rr).max(axis=(0, 2)) / (np.abs(rr).max(axis=(0, 2)) + 1e-30))
+            todo = todo[per_env[hard[todo]] >= np.maximum(3.0 * sens[todo], 1e-3)]
+        assert not len(todo), "environments whose error exceeds 3x the reference-order sensitivity: %s" % sel[hard[todo]]
+        # every one of them goes through the ledger: recorded, capped and counted against the budget of this recording -- the
+        # counts measured at the shipped kernels plus a margin (a re-association of the arithmetic may move an environment across
+        # a branch boundary; a regression of the adjoint moves ALL of them)
+        for k, (x, y) in enumerate(zip(per_env[hard], sens)):
+            assert x < probe_ledger.accept("rollout", x, y, budget, "%s env %d" % (tag, sel[hard[k]])), (tag, sel[hard[k]], x, y)
+    aw, rw = a[:, well], r[:, well]
+    assert (aw * rw).sum() / (np.linalg.norm(aw) * np.linalg.norm(rw)) > 0.9999
+    # ... and over ALL sampled environments, the branch-boundary ones included (measured: 0.9998 / 0.99999)
+    assert (a * r).sum() / (np.linalg.norm(a) * np.linalg.norm(r)) > 0.999
+    return well
+
+
+def _ant_oracle_grad(g, acts):
+    """probe of the Ant 1024 x 32 recording: the reference-order gradient of environments `hs` from perturbed start states"""
+    def f(hs, mag, seed):
+        from oracle_env import rollout_grad
+        rng = np.random.default_rng(seed)
+        q0p = (g["q0"][hs].astype(np.float64) * (1.0 + mag * rng.normal(size=g["q0"][hs].shape))).astype(np.float32)
+        return rollout_grad("ant", template_from_golden("ant"), q0p, g["qd0"][hs], acts[:, hs])[2].astype(np.float64)
+    return f
+
+
 def _ant_1024x32_actions(g):
     """the action tensor of tests/golden/ant_1024x32.npz, regenerated from its seed exactly as oracle/gen_golden.py drew it
     (CPU generator: 20 pre-roll draws, then the [H, N, 8] block)"""
@@ -216,7 +285,8 @@ def test_emu_baseline_config_subset_vs_reference():
     """first 64 of the 1024 environments of BASELINE.json configs[1] (Ant 1024 x H=32) on the host harness"""
     from emu_lib import emu_env_backward, emu_env_forward, env_spec_for
     g = golden("ant_1024x32")
-    acts = _ant_1024x32_actions(g).numpy()[:, :64]
+    acts_all = _ant_1024x32_actions(g).numpy()
+    acts = acts_all[:, :64]
     t = template_from_golden("ant")
     spec, keep = env_spec_for("ant", t)
     q, qd, tape = g["q0"][:64], g["qd0"][:64], []
@@ -228,15 +298,16 @@ def test_emu_baseline_config_subset_vs_reference():
     gq, gqd, ga = np.zeros_like(q), np.zeros_like(qd), np.zeros_like(acts)
     for s in reversed(range(32)):
         gq, gqd, ga[s] = emu_env_backward(t, spec, tape[s], acts[s], DT, 16, 16, gq, gqd, None, -np.ones(64, np.float32))
-    a, r = ga[:, ::8].astype(np.float64), g["grad_actions_every8"][:, :8].astype(np.float64)
-    assert (a * r).sum() / (np.linalg.norm(a) * np.linalg.norm(r)) > 0.9999
-    assert relerr(a, r) < 1e-3
+    st = int(g["stride"])
+    a, r = ga[:, ::st].astype(np.float64), g["grad_actions_strided"][:, :64 // st].astype(np.float64)
+    _per_env_gradient_check("ant_1024x32 (first 64, host harness)", a, r, np.arange(64)[::st], ANT_SUBSET_PROBE_BUDGET, _ant_oracle_grad(g, acts_all))
 
 
 @pytest.mark.gpu
 def test_gpu_baseline_config_vs_reference():
     """BASELINE.json configs[1] literally -- Ant, 1024 environments, H = 32, forward + adjoint -- against the recording of
-    the reference's CPU path: rewards of all environments and steps, final states, action gradients of every 8th one"""
+    the reference's CPU path: rewards of all environments and steps, final states, action gradients of every 2nd one (round 5:
+    every 8th before), each held to 1e-3 or to its probed reference-order sensitivity (_per_env_gradient_check)"""
     from diffrl_amd import envs
     g = golden("ant_1024x32")
     n, H = g["q0"].shape[0], 32
@@ -258,10 +329,10 @@ def test_gpu_baseline_config_vs_reference():
     assert np.abs(R - g["rew"]).max() < 1e-3 * max(1.0, np.abs(g["rew"]).max())
     assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
     assert relerr(e.state.joint_q.detach().view(n, -1).cpu().numpy(), g["q_final"]) < 1e-3
-    a = acts.grad[:, ::8].cpu().numpy().astype(np.float64)
-    r = g["grad_actions_every8"].astype(np.float64)
-    assert (a * r).sum() / (np.linalg.norm(a) * np.linalg.norm(r)) > 0.9999
-    assert relerr(a, r) < 1e-3
+    st = int(g["stride"])
+    a = acts.grad[:, ::st].cpu().numpy().astype(np.float64)
+    r = g["grad_actions_strided"].astype(np.float64)
+    _per_env_gradient_check("ant_1024x32", a, r, np.arange(n)[::st], ANT_PROBE_BUDGET, _ant_oracle_grad(g, acts.detach().cpu().numpy()))
 
 
 def _fullsize_inputs(g, n_act, n_obs):
@@ -331,56 +402,15 @@ def test_gpu_fullsize_humanoids_vs_reference(tag):
     sel = np.arange(n)[::st][ok[::st]]                       # global indices of the environments with recorded gradients
     a = acts.grad[:, ::st].cpu().numpy().astype(np.float64)[:, ok[::st]]
     r = g["grad_actions_strided"].astype(np.float64)[:, ok[::st]]
-    per_env = np.abs(a - r).max(axis=(0, 2)) / (np.abs(r).max(axis=(0, 2)) + 1e-30)
-    # Stated tolerance 1e-3 (BASELINE.md section 4, H = 32) per environment.  An environment above it must be one whose
-    # REFERENCE-order gradient is itself that sensitive: contacts switch on / off and friction switches regime at
-    # thresholds, so the gradient of a rollout is piecewise -- a state that differs in the 6th digit (what the fp32
-    # re-association of this implementation amounts to: 10-parameter inertias, composite-body mass matrix, explicit
-    # inverse) can sit on the other side of such a threshold for one substep, and the gradient then takes the OTHER
-    # branch's value.  Probe: perturb the start state by 1e-7 .. 3e-6 (relative), recompute the gradient with the scalar
-    # oracle (reference operation order, same termination rules, same loss); the reference-order gradient must move by at
-    # least a third of this implementation's error for every such environment (measured: it lands on the same values).
-    well = per_env < 1e-3
-    hard = np.where(~well)[0]
-    print("%s: %d of %d sampled environments above 1e-3 (max %.2e, median %.2e)" % (tag, len(hard), len(per_env), per_env.max(), np.median(per_env)))
-    # the budget is checked BEFORE any probing: an adjoint defect puts every environment above 1e-3, and that must fail
-    # at once instead of asking the oracle 128 x 16 times whether each of them is "sensitive"
-    assert len(hard) <= FULLSIZE_PROBE_BUDGET[name], (
-        "%s: %d of %d sampled environments above 1e-3, the budget of branch-boundary environments is %d"
-        % (tag, len(hard), len(per_env), FULLSIZE_PROBE_BUDGET[name]))
-    if len(hard):
+    A, Wn = acts.detach().cpu().numpy(), w.cpu().numpy()
+
+    def oracle_grad(hs, mag, seed):
         from oracle_env import episode_rollout_grad
-        A, Wn = acts.detach().cpu().numpy(), w.cpu().numpy()
-        rr_all = g["grad_actions_strided"].astype(np.float64)[:, ok[::st]]
-        sens = np.zeros(len(hard))
-        todo = np.arange(len(hard))
-        # (a branch flip is a discrete event that a random perturbation hits or misses: the list is walked until every
-        # environment above 1e-3 has shown it, smallest perturbations first; all of them are far inside the 1e-3 trajectory
-        # tolerance of the start state)
-        for mag, seed in ((1e-7, 0), (1e-6, 0), (3e-6, 0), (1e-6, 1), (3e-6, 1), (1e-6, 2), (3e-6, 2), (1e-6, 3), (3e-6, 3),
-                          (1e-6, 4), (3e-6, 4), (1e-6, 5), (3e-6, 5), (1e-5, 0), (1e-5, 1), (1e-5, 2)):
-            if not len(todo):
-                break
-            hs = sel[hard[todo]]
-            rng = np.random.default_rng(seed)
-            scale = (1.0 + mag * rng.normal(size=(len(hs), e.num_joint_q))).astype(np.float32)
-            gp, dp = episode_rollout_grad(name, template_from_golden(name), g["progress0"][hs], A[:, hs], Wn[hs],
-                                          int(g["episode_length"]), q0_scale=scale)
-            rr = rr_all[:, hard[todo]]
-            sens[todo] = np.maximum(sens[todo], np.abs(gp - rr).max(axis=(0, 2)) / (np.abs(rr).max(axis=(0, 2)) + 1e-30))
-            todo = todo[per_env[hard[todo]] >= np.maximum(3.0 * sens[todo], 1e-3)]
-        assert not len(todo), "environments whose error exceeds 3x the reference-order sensitivity: %s" % sel[hard[todo]]
-        # every one of them goes through the ledger: recorded, capped (5e-2) and counted against the budget of this recording
-        # -- the counts measured at the shipped kernels plus two (a re-association of the arithmetic may move an environment
-        # across a branch boundary; a regression of the adjoint moves ALL of them)
-        import probe_ledger
-        budget = FULLSIZE_PROBE_BUDGET[name]
-        for k, (x, y) in enumerate(zip(per_env[hard], sens)):
-            assert x < probe_ledger.accept("rollout", x, y, budget, "%s env %d" % (tag, sel[hard[k]])), (tag, sel[hard[k]], x, y)
-    aw, rw = a[:, well], r[:, well]
-    assert (aw * rw).sum() / (np.linalg.norm(aw) * np.linalg.norm(rw)) > 0.9999
-    # ... and over ALL sampled environments, the branch-boundary ones included (measured: 0.9998 / 0.99999)
-    assert (a * r).sum() / (np.linalg.norm(a) * np.linalg.norm(r)) > 0.999
+        rng = np.random.default_rng(seed)
+        scale = (1.0 + mag * rng.normal(size=(len(hs), e.num_joint_q))).astype(np.float32)
+        return episode_rollout_grad(name, template_from_golden(name), g["progress0"][hs], A[:, hs], Wn[hs],
+                                    int(g["episode_length"]), q0_scale=scale)[0]
+    _per_env_gradient_check(tag, a, r, sel, FULLSIZE_PROBE_BUDGET[name], oracle_grad)
 
 
 # ---- environments that blow up (humanoid.py:340-356 invalid-state rule; nan_to_num hooks humanoid.py:195-206) -------
