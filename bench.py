@@ -119,6 +119,29 @@ def pmc_record(name, n, mm):
     return None
 
 
+def census_record():
+    """profiles/opcode_census.json (tools/opcode_census.py: static census of the kernels' substep loops -- the share of VALU
+    instructions that carries floating-point work and the flops each carries), if it was taken at THESE kernel sources"""
+    try:
+        c = json.load(open(os.path.join(ROOT, "profiles", "opcode_census.json")))
+        return c if c.get("csrc_hash") == csrc_hash() else None
+    except Exception:
+        return None
+
+
+KERNEL_TAG = {"ant": "Ant", "humanoid": "Humanoid", "snu": "Snu", "cartpole": "Cartpole", "hopper": "Hopper", "cheetah": "Cheetah"}
+
+
+def census_flops_per_inst(census, kernel, name, waves_per_env):
+    """flops per VALU instruction of the kernel variant the counters describe (helper-wave kernels: 2 waves per environment,
+    pair kernels: half a wave, otherwise the plain mapping)"""
+    if not census or waves_per_env is None:
+        return None
+    mode = "helper" if abs(waves_per_env - 2.0) < 1e-6 else ("pair" if abs(waves_per_env - 0.5) < 1e-6 else "plain")
+    k = census["kernels"].get("%s<%s,%s>" % (kernel, KERNEL_TAG.get(name, "generic"), mode))
+    return k["flops_per_valu_inst"] if k else None
+
+
 SIMDS = 1024            # MI355X: 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 FP32_VALU_PEAK = 157.3e12
 CLOCK_HZ = 2.4e9        # shader clock (MI355X_MICROARCH.md)
@@ -176,19 +199,26 @@ def roofline_record(env, name, n, H, mm, device, reps, counters=True):
     # read (q,qd,act) + write (q',qd')  (the fused kernels also move obs / reward rows; SURVEY's figure is kept)
     bwd_bytes = 4 * n * ((nq + nd + na_in) + (nq + nd) + (nq + nd + na_in))
     fwd_bytes = 4 * n * ((nq + nd + na_in) + (nq + nd))
-    achieved = bwd_bytes / t_bwd / 1e9
+    # the roofline object is for the DOMINANT launch: the longer of the two kernels of an env-step (round 4: the adjoint; since
+    # its body level became one phase the forward is as long or longer) -- `kernel` names it, `achieved` is ITS algorithmic bytes
+    # over ITS duration; both kernels' times and byte counts are in the record either way
+    fwd_dominant = t_fwd > t_bwd
+    achieved = (fwd_bytes / t_fwd if fwd_dominant else bwd_bytes / t_bwd) / 1e9
     eng = env.model.engine()
     ckpt_floats = int(eng._lib.dsim_ckpt_floats_mm(eng._h, env.sim_substeps, mm))
     traffic = 4 * n * ckpt_floats + bwd_bytes
     traffic_src = "analytic: checkpoint words x N x 4 + boundary tensors (no counter file for these kernel sources)"
     pmc = pmc_record(name, n, mm) if counters else None   # (the committed counter files describe the SPECIALISED kernels)
-    r = {"bound": "valu-issue", "kernel": "dsim_env_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": achieved / HBM_PEAK_GBS, "alg_bytes_per_launch": bwd_bytes, "kernel_ms": t_bwd * 1e3,
-         "fwd_kernel_ms": t_fwd * 1e3, "fwd_alg_bytes_per_launch": fwd_bytes, "csrc_hash": csrc_hash(),
+    r = {"bound": "valu-issue", "kernel": "dsim_env_fwd_kernel" if fwd_dominant else "dsim_env_bwd_kernel",
+         "dominant_launch": "forward" if fwd_dominant else "adjoint", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "alg_bytes_per_launch": fwd_bytes if fwd_dominant else bwd_bytes, "kernel_ms": t_bwd * 1e3,
+         "fwd_kernel_ms": t_fwd * 1e3, "fwd_alg_bytes_per_launch": fwd_bytes, "bwd_alg_bytes_per_launch": bwd_bytes,
+         "fwd_alg_frac": fwd_bytes / t_fwd / (HBM_PEAK_GBS * 1e9), "bwd_alg_frac": bwd_bytes / t_bwd / (HBM_PEAK_GBS * 1e9),
+         "csrc_hash": csrc_hash(),
          "ckpt_bytes_per_env_step": 4 * ckpt_floats, "ckpt_bytes_per_rollout": 4 * ckpt_floats * n * H,
          "valu_issue_frac": None, "fwd_valu_issue_frac": None, "valu_simd_frac": None, "fwd_valu_simd_frac": None,
          "stall_frac": None, "fwd_stall_frac": None, "valu_insts_per_env_step": None,
-         "note": "achieved / frac: ALGORITHMIC bytes of the adjoint launch against the HBM peak, as BASELINE.json asks -- not what "
+         "note": "achieved / frac: ALGORITHMIC bytes of the dominant launch (`kernel`: the longer of the env-step's two) against the HBM peak, as BASELINE.json asks; alg_frac_step: the whole env-step's 748 B (Ant) x the measured env-steps/s against 8 TB/s -- not what "
                  "binds these kernels (~1,900 flop per algorithmic byte, SURVEY 8d).  bound: the instruction stream of the ONE "
                  "wavefront an environment's phases run on.  valu_simd_frac = VALU instructions per occupied SIMD x 2 cycles "
                  "/ kernel cycles: the fraction of the SIMD-32's VALU rate, i.e. of the machine; valu_issue_frac = busy fraction "
@@ -218,16 +248,31 @@ def roofline_record(env, name, n, H, mm, device, reps, counters=True):
             r["valu_insts_per_env_step"] = b["valu_insts_per_env_step"] + f["valu_insts_per_env_step"]
             lanes = [x.get("valu_active_lanes_avg") for x in (b, f)]
             if all(lanes):
-                # fp32 vector-ALU view: lane-operations actually executed (instructions x active lanes), each counted as one
-                # FMA = 2 flop (an upper bound: moves, compares and selects are VALU instructions too), against the packed-
-                # fp32 vector peak
-                ops = n * (b["valu_insts_per_env_step"] * lanes[0] + f["valu_insts_per_env_step"] * lanes[1])
-                r["fp32_valu_frac_est"] = 2.0 * ops / (t_bwd + t_fwd) / FP32_VALU_PEAK
+                # fp32 vector-ALU view: lane-operations actually executed (instructions x active lanes) ...
+                ops_b, ops_f = n * b["valu_insts_per_env_step"] * lanes[0], n * f["valu_insts_per_env_step"] * lanes[1]
+                # ... each counted as one FMA = 2 flop: an UPPER bound (moves, compares and selects are VALU instructions too)
+                r["fp32_valu_frac_upper_bound"] = 2.0 * (ops_b + ops_f) / (t_bwd + t_fwd) / FP32_VALU_PEAK
+                # ... and with the flops the instructions of these kernels actually carry (static census of the substep loops,
+                # tools/opcode_census.py -> profiles/opcode_census.json: ~1.0 flop per VALU instruction -- a third are multiply-
+                # adds, a third single operations, a third moves / selects / compares / integer work)
+                cen = census_record()
+                fb = census_flops_per_inst(cen, "dsim_env_bwd_kernel", name, b.get("waves_per_env"))
+                ff = census_flops_per_inst(cen, "dsim_env_fwd_kernel", name, f.get("waves_per_env"))
+                if fb and ff:
+                    r["flops_per_valu_inst"] = {"adjoint": fb, "forward": ff, "source": "profiles/opcode_census.json"}
+                    r["fp32_valu_frac_est"] = (ops_b * fb + ops_f * ff) / (t_bwd + t_fwd) / FP32_VALU_PEAK
+                    r["flop_per_env_step"] = (ops_b * fb + ops_f * ff) / n
+                else:
+                    r["fp32_valu_frac_est"] = None
         wf = (pmc.get("forward_kernel") or {}).get("traffic_bytes_per_launch")
         if wf:
             r["fwd_hbm_measured_frac"] = wf / t_fwd / (HBM_PEAK_GBS * 1e9)
     r["traffic"], r["traffic_source"] = traffic, traffic_src
     r["hbm_measured_frac"] = traffic / t_bwd / (HBM_PEAK_GBS * 1e9)
+    if fwd_dominant and pmc and (pmc.get("forward_kernel") or {}).get("traffic_bytes_per_launch"):
+        # (`traffic` describes the dominant launch, like `achieved`; the adjoint's figure stays in bwd_traffic)
+        r["bwd_traffic"] = traffic
+        r["traffic"] = pmc["forward_kernel"]["traffic_bytes_per_launch"]
     return r
 
 
@@ -264,6 +309,7 @@ def measure_other_config(name, n, H, mm, device, steps=10, generic=False):
         el = time.perf_counter() - t0
         assert torch.isfinite(acts.grad).all()
         rf = roofline_record(env, name, n, H, mm, device, 20, counters=not generic)
+        rf["alg_frac_step"] = ALG_BYTES[name] * (steps * n * H / el) / (HBM_PEAK_GBS * 1e9)
         return {"workload": "%s %d envs x H=%d, MM_caching_frequency %d" % (name, n, H, mm), "value": steps * n * H / el,
                 "unit": "env-steps/s", "steps": steps, "ms_per_rollout": el / steps * 1e3, "kernel_ms": rf["kernel_ms"],
                 "fwd_kernel_ms": rf["fwd_kernel_ms"], "ckpt_bytes_per_env_step": rf["ckpt_bytes_per_env_step"],
@@ -388,7 +434,10 @@ def main(argv=None):
         # (RCCL needs one device per rank: oversubscribed ranks talk over gloo, with host tensors)
         sharding.init("nccl" if (use_gpu and not over) else "gloo", device if (use_gpu and not over) else None)
         rccl_ranks = td.get_world_size()
-        assert rccl_ranks == a.gpus * a.oversubscribe
+        if rccl_ranks != a.gpus * a.oversubscribe:   # (never print a job of another size under the requested label)
+            sys.stderr.write("bench.py: the process group has %d ranks, --gpus %d x --oversubscribe %d asked for %d\n"
+                             % (rccl_ranks, a.gpus, a.oversubscribe, a.gpus * a.oversubscribe))
+            return 2
     red_dev = device if (use_gpu and not over) else torch.device("cpu")   # where the timing all-reduce lives
 
     def barrier():
@@ -404,11 +453,16 @@ def main(argv=None):
         barrier()
         t0 = time.perf_counter()
         time.sleep(0.01 * (1 + rank))
+        el_rank = time.perf_counter() - t0   # this rank's own work, before it waits for the others
         barrier()
         el = sharding.max_over_ranks(time.perf_counter() - t0, red_dev)
         owned = sharding.sum_over_ranks(hi - lo, red_dev)
+        per_rank = sharding.gather_over_ranks([rank, el_rank, hi - lo], red_dev)
+        names = sharding.gather_strings(torch.cuda.get_device_name(device) if use_gpu else "cpu")
         if rank == 0:
             print(json.dumps({"metric": "fwd+adjoint env-steps/sec", "dry_run": True, "value": None, "unit": "env-steps/s",
+                              "per_rank": [{"rank": int(r[0]), "elapsed_s": r[1], "envs": int(r[2]), "device": names[i]}
+                                           for i, r in enumerate(per_rank)],
                               "n_gpus": a.gpus, "rccl_ranks": rccl_ranks, "backend": "nccl" if (use_gpu and not over) else "gloo",
                               "oversubscribed": over,
                               "steps": a.steps, "warmup": a.warmup, "scaling": "weak", "envs_total": int(owned),
@@ -475,16 +529,26 @@ def main(argv=None):
         grad = one()
     if marks:
         marks[a.steps].record()
+    if use_gpu:
+        torch.cuda.synchronize()
+    el_own = time.perf_counter() - t0   # this rank's own K steps, before it waits for the others (per_rank in the JSON line)
     barrier()
     el = time.perf_counter() - t0
     gc.enable()
     per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)) if marks else []
     assert torch.isfinite(grad).all()
+    el_rank = el_own
     el = sharding.max_over_ranks(el, red_dev)
     total_env_steps = a.steps * world * n * H
     value = total_env_steps / el
+    # every rank's own figures on rank 0 (straggler diagnosis of the 2 / 4 / 8-GPU runs: the job's time is the slowest rank's)
+    per_rank = sharding.gather_over_ranks([rank, el_rank, per_step_ms[len(per_step_ms) // 2] if per_step_ms else 0.0,
+                                           per_step_ms[-1] if per_step_ms else 0.0], red_dev)
+    dev_names = sharding.gather_strings("%s (cuda:%d)" % (torch.cuda.get_device_name(device), device.index) if use_gpu else "cpu")
     eager_value = None
-    if roll is not None and rank == 0 and not a.no_extras:
+    # (the informational legs below are rank 0's alone: with several ranks they are skipped, so that no rank waits more than the
+    # second or two of the kernel timings at the closing barrier)
+    if roll is not None and rank == 0 and not a.no_extras and world == 1:
         # the same rollouts driven step by step from Python (what a caller that does not capture gets)
         env2 = make_env(a.env, n, str(device))
         for _ in range(2):
@@ -503,6 +567,10 @@ def main(argv=None):
         out = {
             "metric": "fwd+adjoint env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": a.gpus,
             "rccl_ranks": rccl_ranks, "oversubscribed": over,
+            "backend": ("nccl" if (use_gpu and not over) else "gloo") if dist else None,
+            "per_rank": [{"rank": int(r[0]), "value": a.steps * n * H / r[1], "ms_per_step": r[1] / a.steps * 1e3,
+                          "ms_per_step_median": r[2], "ms_per_step_max": r[3], "device": dev_names[i]}
+                         for i, r in enumerate(per_rank)],
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
             "ms_per_step_min": per_step_ms[0] if per_step_ms else None,
             "ms_per_step_median": per_step_ms[len(per_step_ms) // 2] if per_step_ms else None,
@@ -518,8 +586,9 @@ def main(argv=None):
             "roofline": rf,
             "fp32_valu_frac_est": rf.get("fp32_valu_frac_est"),
         }
+        rf["alg_frac_step"] = ALG_BYTES[a.env] * (value / world) / (HBM_PEAK_GBS * 1e9)   # per GPU: whole env-step bytes x rate / 8 TB/s
         # forward-only serving path (dflex.config.no_grad: no checkpoint traffic), SURVEY.md 8(f).4 -- informational
-        if not a.no_extras:
+        if not a.no_extras and world == 1:
             with torch.no_grad():
                 spec = env._spec()
                 q, qd = env.state.joint_q.detach().clone(), env.state.joint_qd.detach().clone()

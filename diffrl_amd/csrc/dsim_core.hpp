@@ -1578,6 +1578,10 @@ DSIM_FN void dsim_trunk_sum(const Ctx& c, Exec& ex, int lane, const float* ldata
 // associated by tree level instead of by index: not bit-identical to them (the tests hold both to the reference).
 template <class Ctx, class Exec> DSIM_FN void dsim_rowtree_sum(const Ctx&, Exec& ex, const DsimTopoRegs& tp, sv6& x) {
     using D = decltype(Ctx::d);
+    // Two environments per wavefront (Exec::NL == 32): wave_shl:1 makes the LAST lane of the first environment's half read lane
+    // 0 of the second environment.  Its weight there is 0 -- but 0 * Inf / NaN of a diverged neighbour is NaN -- so that lane must
+    // not hold a link at all: its value is then never stored and never summed.  (dsim_pair_ok asks for L <= 16.)
+    static_assert(Exec::NL >= DSIM_NL || D::L < Exec::NL, "row-tree sums with two environments per wavefront: the half's last lane must stay free");
     dsim_static_for<0, D::RT_N>([&](auto ss) {
         constexpr int s_ = decltype(ss)::value, dist = D::rt_d[s_], kind = D::rt_kind[s_];
         // The DPP steps are inline asm, which the compiler's hazard recognizer cannot see into: the s_nop in front of a step's six
@@ -2071,6 +2075,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_check_unit_quats(const Ctx& c
                 const q4 r = ldq(WF(q) + cs + (type == DSIM_JOINT_FREE ? 3 : 0));
                 if (!(fabsf(qdot(r, r) - 1.0f) <= DSIM_UNIT_QUAT_TOL)) {   // (also catches NaN)
                     g_status[1] = env;
+                    ex.system_fence();   // the environment index is in host memory before the flag that makes the host read it
                     g_status[0] = 1;
                 }
             }

@@ -341,6 +341,8 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false, int EPW = 1> stru
     }
     // this wave's earlier LDS stores are visible to its later LDS loads (DS operations of a wave execute in order)
     __device__ __forceinline__ void lds_fence() { dsim_wave_sync(); }
+    // earlier stores to (host-mapped) global memory are visible system-wide before later ones (the model's status words)
+    __device__ __forceinline__ void system_fence() { __threadfence_system(); }
     __device__ __forceinline__ void sync() {
         if constexpr (NW == 1) dsim_wave_sync();
         else __syncthreads();
@@ -864,6 +866,7 @@ template <int NW> struct TimingExec {
         return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
     }
     __device__ __forceinline__ void lds_fence() { __syncthreads(); }
+    __device__ __forceinline__ void system_fence() { __threadfence_system(); }
     long long* buf;
     int idx, cap;
     int tag = 0;

@@ -53,3 +53,26 @@ def sum_over_ranks(value, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     td.all_reduce(t, op=td.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_over_ranks(values, device="cpu"):
+    """[world][len(values)] floats: every rank's figures on every rank (straggler diagnosis of a multi-GPU job: which rank was
+    slow, not only that one was).  One all_gather of a few doubles; a single process returns [values]."""
+    import torch.distributed as td
+    vals = [float(v) for v in values]
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return [vals]
+    t = torch.tensor(vals, dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(td.get_world_size())]
+    td.all_gather(out, t)
+    return [o.cpu().tolist() for o in out]
+
+
+def gather_strings(text):
+    """[world] strings (device names of the ranks); host-side all_gather_object"""
+    import torch.distributed as td
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return [text]
+    out = [None] * td.get_world_size()
+    td.all_gather_object(out, text)
+    return out

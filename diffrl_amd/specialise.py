@@ -182,22 +182,42 @@ def main(argv=None):
     ap.add_argument("--lib-out", help="build this library instead of csrc/libdsim_hip.so (use it with DSIM_LIB=<path>)")
     ap.add_argument("--only", action="store_true", help="compile the generic kernels + this model's set only (~40 s instead of minutes)")
     ap.add_argument("--no-build", action="store_true", help="generate the header, do not run hipcc")
+    ap.add_argument("--also", action="append", default=[], metavar="NAME=template.npz",
+                    help="(with --header-out) further user models for the same header / the same --only library; may be repeated")
     a = ap.parse_args(argv)
     t = ArticulationTemplate.load(a.template)
     models = shipped_templates()
+    # everything that can refuse the request is checked BEFORE anything is written: a bad name must not leave a template in
+    # csrc/user_models/ that breaks every later regeneration (tools/gen_static_layouts.py included)
+    if not re.fullmatch(r"[A-Za-z][A-Za-z0-9]*", a.name):
+        ap.error("--name %r: letters and digits only, starting with a letter (it becomes part of C++ identifiers)" % a.name)
+    if a.name in [tag for tag, _ in models]:
+        ap.error("--name %s is the name of a shipped kernel set; choose another" % a.name)
+    if a.only and not a.lib_out and not a.no_build:
+        ap.error("--only builds a library WITHOUT the shipped specialised sets (Ant, Humanoid, ... would silently fall back to the "
+                 "generic kernels at about half speed): it needs --lib-out <path> so that csrc/libdsim_hip.so is not overwritten")
     known = matches(t, render(models))
     if known:
         print("this model already has a specialised kernel set: %s (nothing to do)" % known)
         return 0
+    extra = []
+    for spec in a.also:
+        n2, _, path2 = spec.partition("=")
+        if not re.fullmatch(r"[A-Za-z][A-Za-z0-9]*", n2) or not path2 or n2 == a.name or n2 in [tag for tag, _ in models]:
+            ap.error("--also %r: expected NAME=template.npz with a fresh identifier as NAME" % spec)
+        if not a.header_out:
+            ap.error("--also belongs to --header-out builds (the in-tree header takes its user models from csrc/user_models/)")
+        extra.append((n2, ArticulationTemplate.load(path2)))
     if a.header_out:
-        models = models + [(n, u) for n, u in user_templates() if n != a.name] + [(a.name, t)]
+        models = models + [(n, u) for n, u in user_templates() if n != a.name and n not in [e[0] for e in extra]] + [(a.name, t)] + extra
         header = a.header_out
     else:
+        models = models + [(n, u) for n, u in user_templates() if n != a.name] + [(a.name, t)]
+        header = HEADER
+    txt = render(models)   # (raises on anything the layout builder refuses: still nothing written)
+    if not a.header_out:
         os.makedirs(USER_DIR, exist_ok=True)
         t.save(os.path.join(USER_DIR, a.name + ".npz"))
-        models = models + user_templates()
-        header = HEADER
-    txt = render(models)
     open(header, "w").write(txt)
     assert matches(t, txt) == a.name
     off, dims = layout(t)
@@ -206,7 +226,7 @@ def main(argv=None):
     if a.no_build:
         return 0
     out = a.lib_out or os.path.join(CSRC, "libdsim_hip.so")
-    build_library(out, header if a.header_out else None, [a.name] if a.only else None)
+    build_library(out, header if a.header_out else None, ([a.name] + [e[0] for e in extra]) if a.only else None)
     print("built %s; a model created from this template now reports dsim_model_variant > 0%s"
           % (out, "" if not a.lib_out else " (run with DSIM_LIB=%s)" % os.path.abspath(out)))
     return 0

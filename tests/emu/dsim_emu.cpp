@@ -12,7 +12,11 @@
 
 #define DSIM_FN static inline
 #include "../../diffrl_amd/csrc/dsim_core.hpp"
+#ifdef DSIM_STATIC_LAYOUTS_FILE   // (a generated header with user models: tests/inject/dsim_static_layouts_user.hpp, see the Makefile)
+#include DSIM_STATIC_LAYOUTS_FILE
+#else
 #include "../../diffrl_amd/csrc/dsim_static_layouts.hpp"
+#endif
 
 // NW wavefronts per environment: NL = 64 * NW lanes (the library's kernels use 1 or 4).
 //
@@ -126,6 +130,7 @@ template <int NW, int LANES = DSIM_NL> struct HostExecT {
         a3 = __builtin_fmaf(y3, w, a3); a4 = __builtin_fmaf(y4, w, a4); a5 = __builtin_fmaf(y5, w, a5);
     }
     void lds_fence() { arrive(); }
+    void system_fence() {}
     template <class F> void fire(F&& f) { run(f); }
     // the helper wavefront of the device executor (dsim_hip.hip) does not exist here: both blocks of a split phase run in
     // the one emulated wave, one after the other

@@ -34,6 +34,10 @@ def test_dry_run_launches_two_ranks_on_cpu():
     assert j["dry_run"] is True and j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["backend"] == "gloo"
     assert j["envs_total"] == 2048 and j["scaling"] == "weak"          # every env owned by exactly one rank
     assert j["slowest_rank_s"] >= 0.02                                     # MAX over ranks (rank 1 sleeps longer)
+    # every rank's own figures (straggler diagnosis): two ranks, each with its shard, the slower one is rank 1
+    pr = j["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and [r["envs"] for r in pr] == [1024, 1024] and all(r["device"] == "cpu" for r in pr)
+    assert pr[1]["elapsed_s"] > pr[0]["elapsed_s"] + 5e-3 and max(r["elapsed_s"] for r in pr) <= j["slowest_rank_s"]
 
 
 def test_dry_run_oversubscribed_keeps_the_gpu_label():
@@ -83,6 +87,28 @@ def test_bench_through_the_launcher_rccl_group_of_one():
     assert j["config"]["submission_fallback"] is False
     assert j["value"] > 1e5 and j["roofline"]["traffic"] > j["roofline"]["alg_bytes_per_launch"]
     assert j["roofline"]["bound"] == "valu-issue" and "valu_issue_frac" in j["roofline"] and "hbm_measured_frac" in j["roofline"]
+    # round 5: the group really is RCCL, per-rank figures are in the line, the roofline object names the LONGER launch
+    assert j["backend"] == "nccl" and len(j["per_rank"]) == 1
+    r0 = j["per_rank"][0]
+    assert r0["rank"] == 0 and "cuda:0" in r0["device"] and j["value"] <= r0["value"] < 1.05 * j["value"]   # (own time: before the closing barrier)
+    assert 0.95 * j["ms_per_step"] < r0["ms_per_step"] <= j["ms_per_step"] and r0["ms_per_step_max"] >= r0["ms_per_step_median"] > 0
+    rf = j["roofline"]
+    longer = "dsim_env_fwd_kernel" if rf["fwd_kernel_ms"] > rf["kernel_ms"] else "dsim_env_bwd_kernel"
+    assert rf["kernel"] == longer and rf["dominant_launch"] == ("forward" if longer.endswith("fwd_kernel") else "adjoint")
+    assert abs(rf["alg_frac_step"] - 748 * j["value"] / 8e12) < 1e-9 and 0 < rf["alg_frac_step"] < 0.01
+    if rf.get("counters"):   # counter file at these kernel sources: the flop view comes from the opcode census, not "every VALU op is an FMA"
+        assert rf["fp32_valu_frac_est"] is None or rf["fp32_valu_frac_est"] < rf["fp32_valu_frac_upper_bound"]
+
+
+@pytest.mark.gpu
+def test_dry_run_through_the_launcher_initialises_rccl():
+    """what the driver's multi-GPU launch exercises before any kernel runs: torch.distributed.run -> ranks -> RCCL process group
+    (backend nccl with a device per rank) -> barrier -> timing all-reduce / all_gather -> one JSON line, here with one rank"""
+    out = _run(["--gpus", "1", "--dry-run", "--envs-per-gpu", "1024"], timeout=600)
+    assert out.returncode == 0, out.stderr[-1500:]
+    j = _json_line(out)
+    assert j["dry_run"] is True and j["backend"] == "nccl" and j["rccl_ranks"] == 1 and j["n_gpus"] == 1
+    assert j["per_rank"][0]["envs"] == 1024 and j["per_rank"][0]["device"] != "cpu"
 
 
 @pytest.mark.gpu

@@ -249,3 +249,71 @@ def test_half_angle_polynomials_at_and_beyond_their_range():
     X = first_substep(t, ck)["X_sc"]
     assert relerr(X, dbg["X_sc"]) < 1e-6
     assert relerr(qo, o_q) < 1e-6
+
+
+def _caterpillar():
+    """A pre-order tree of 17 links whose ROW-TREE step list (dsim_layout.hpp: DsimDims::rt_kind) mixes all three kinds and puts a
+    FAR step in front of row-shift steps: a spine 0-2-4-...-14 (each spine link the child of the one two below it), a leaf on every
+    spine link (1, 3, ..., 13: distance 1), and two leaves on the last one -- 15 (distance 1) and 16 (distance 2 ACROSS the 16-lane
+    row boundary: no row shift reaches from lane 16 to lane 14, so the layout builder emits a FAR step, by v_readlane, at the
+    deepest level, followed by the wave / row shifts of the shallower levels).  Floating base, hinges in rotated frames, capsules
+    with ground contacts.  (The shipped models have FAR steps only at the END of their lists; the s_nop hazard guard in front of
+    the inline-asm DPP steps must also cover a DPP step that follows compiler-generated v_readlane + v_fma code.)"""
+    rng = np.random.default_rng(11)
+    b = df.sim.ModelBuilder()
+    b.add_articulation()
+    parents = [-1]
+    for i in range(1, 17):
+        if i in (15, 16):
+            parents.append(14)
+        elif i % 2 == 0:
+            parents.append(i - 2)   # spine
+        else:
+            parents.append(i - 1)   # leaf of the spine link below it
+    for i in range(17):
+        kind = df.JOINT_FREE if i == 0 else df.JOINT_REVOLUTE
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        rot = rng.normal(size=4)
+        rot /= np.linalg.norm(rot)
+        pos = (0.0, 0.0, 0.0) if i == 0 else ((0.22, 0.0, 0.0) if i % 2 == 0 else tuple(rng.uniform(-0.15, 0.15, 3)))
+        link = b.add_link(parents[i], df.transform(pos, tuple(rot)), tuple(axis), kind, stiffness=float(rng.uniform(0, 2)),
+                          damping=float(rng.uniform(0.05, 0.5)), limit_lower=-0.8, limit_upper=0.8, armature=0.02)
+        b.add_shape_capsule(link, pos=(0.08, 0.0, 0.0), radius=0.04, half_width=0.08, ke=1e4, kd=1e3, kf=1e3, mu=float(rng.uniform(0.3, 1.0)))
+    b.joint_q[0:3] = [0.0, 0.2, 0.0]
+    m = b.finalize("cpu")
+    m.ground = True
+    m.gravity = (0.0, -9.81, 0.0)
+    m.collide()
+    return m.template(), parents
+
+
+def test_caterpillar_row_tree_has_a_far_step_in_front_of_shift_steps():
+    t, parents = _caterpillar()
+    off, d = layout(t)
+    n = d["RT_N"]
+    kinds = d["rt_kind"][:n]
+    assert d["flags"] & 1 and d["L"] == 17 and n > 0
+    FAR, ROW, WAVE1 = 2, 0, 1
+    assert FAR in kinds and ROW in kinds and WAVE1 in kinds
+    far_at = [k for k in range(n) if kinds[k] == FAR]
+    assert any(k + 1 < n and kinds[k + 1] in (ROW, WAVE1) for k in far_at), kinds   # the case the hazard guard must cover
+    assert any(d["rt_d"][k] == 16 and d["rt_lvl"][k] == 14 for k in far_at)           # child lane 16 -> parent lane 14
+
+
+def test_caterpillar_emulated_kernels_vs_oracle():
+    """the generic phase code on the caterpillar (forward + adjoint) against the scalar oracle"""
+    t, parents = _caterpillar()
+    rng = np.random.default_rng(21)
+    q, qd, act = _tree_states(t, rng, 1)
+    gq, gqd = rng.normal(0, 1, q.shape).astype(np.float32), rng.normal(0, 1, qd.shape).astype(np.float32)
+    S, mm = 2, 2
+    dt = S / 960.0
+    o = oracle_backward(t, q, qd, act, None, dt, S, mm, gq, gqd)
+    qo, qdo, ck = emu_forward(t, q, qd, act, None, dt, S, mm, want_ckpt=True)
+    r = emu_backward(t, ck, act, None, dt, S, mm, gq, gqd)
+    assert relerr(qo, o["q_out"]) < 5e-5 and relerr(qdo, o["qd_out"]) < 5e-4
+    err = dict(gq=relerr(project_tangent(t, q, r["gq"]), project_tangent(t, q, o["gq"])), gqd=relerr(r["gqd"], o["gqd"]),
+               gact=relerr(r["gact"], o["gact"]))
+    tol = step_grad_tolerance(t, q, qd, act, None, dt, S, mm, gq, gqd, err, ref=o)
+    assert all(err[k] < tol[k] for k in err), (err, tol)
