@@ -12,7 +12,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, env, n, name = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 note = sys.argv[5] if len(sys.argv) > 5 else ""
-src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, env))
+mm_arg = int(sys.argv[6]) if len(sys.argv) > 6 else 0   # MM_caching_frequency of the profiled run (0: the environment's default)
+suffix = ("_n%d" % n if (env == "ant" and n != 1024) else "") + ("_mm%d" % mm_arg if mm_arg else "")
+src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s%s" % (tag, env, suffix))
 summ = open(os.path.join(src, "summary.txt")).read()
 cmd = open(os.path.join(src, "command.txt")).read().strip().replace(os.environ.get("GRAFT_REPO_ROOT", "/nonexistent"), ".")
 cmd = re.sub(r"python \S*/bench.py", "python bench.py", cmd)
@@ -53,12 +55,12 @@ header = [
     "# SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* in quad-cycles summed over the wavefronts of a launch.",
 ]
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-open(os.path.join(ROOT, "profiles", "%s_%s_rocprofv3_summary.txt" % (name, env)), "w").write("\n".join(header) + "\n" + summ)
-rec = {"env": env, "n_envs": n, "mm_freq": MM[env], "kernel": "dsim_env_bwd_kernel", "csrc_hash": h,
+open(os.path.join(ROOT, "profiles", "%s_%s%s_rocprofv3_summary.txt" % (name, env, suffix)), "w").write("\n".join(header) + "\n" + summ)
+rec = {"env": env, "n_envs": n, "mm_freq": mm_arg or MM[env], "kernel": "dsim_env_bwd_kernel", "csrc_hash": h,
        "fetch_size_kib_per_launch": fetch_b, "write_size_kib_per_launch": write_b,
        "traffic_bytes_per_launch": int(fetch_b * 2 * 1024 + write_b * 1024) if fetch_b is not None and write_b is not None else None,
        "forward_kernel": {"fetch_size_kib_per_launch": fetch_f, "write_size_kib_per_launch": write_f,
                           "traffic_bytes_per_launch": int(fetch_f * 2 * 1024 + write_f * 1024) if fetch_f is not None and write_f is not None else None},
-       "sq_adjoint": sq, "sq_forward": sqf, "source": "profiles/%s_%s_rocprofv3_summary.txt" % (name, env)}
-json.dump(rec, open(os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (name, env)), "w"), indent=1)
+       "sq_adjoint": sq, "sq_forward": sqf, "source": "profiles/%s_%s%s_rocprofv3_summary.txt" % (name, env, suffix)}
+json.dump(rec, open(os.path.join(ROOT, "profiles", "%s_%s%s_pmc.json" % (name, env, suffix)), "w"), indent=1)
 print(json.dumps(rec)[:400])

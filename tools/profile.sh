@@ -9,7 +9,13 @@ OUT=$REPO/gpurun_out/prof_${TAG}_$ENVN
 RAW=/tmp/prof_raw_$ENVN
 mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-extras --env $ENVN --envs-per-gpu $ENVS"
+MMF=${4:-0}   # MM_caching_frequency (0: the environment's examples/cfg/shac value)
+SUFFIX=""; [ "$MMF" != "0" ] && SUFFIX="_mm$MMF"
+[ "$ENVS" != "1024" ] && [ "$ENVN" = "ant" ] && SUFFIX="_n$ENVS$SUFFIX"
+OUT=$REPO/gpurun_out/prof_${TAG}_$ENVN$SUFFIX
+RAW=/tmp/prof_raw_$ENVN$SUFFIX
+mkdir -p $OUT $RAW
+CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-extras --env $ENVN --envs-per-gpu $ENVS --mm-freq $MMF"
 echo "$CMD" > $OUT/command.txt
 python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(bench.csrc_hash())" > $OUT/csrc_hash.txt 2>/dev/null
 run() { timeout 240 rocprofv3 --output-format csv "$@" < /dev/null; }
