@@ -67,3 +67,15 @@ def test_saturated_regime_kernels_keep_two_waves_per_simd(kernels):
             if k["vgpr_count"] + k.get("agpr_count", 0) > 256:
                 over.append((n, k["vgpr_count"], k.get("agpr_count", 0)))
     assert not over, over
+
+
+def test_several_wavefront_kernels_keep_two_waves_per_simd(kernels):
+    """SNUHumanoid runs four wavefronts per environment and its LDS image allows two environments per CU: eight waves, two per
+    SIMD -- 256 registers per lane, accumulation registers included.  One more halves the environments in flight (round 5: the
+    operator-level adjoint at 257 registers ran 0.53 instead of 0.29 ms); the kernels are compiled with that bound
+    (dsim_hip.hip: DSIM_WIDE_WAVES), which must hold WITHOUT scratch memory (test_no_kernel_uses_scratch_memory)."""
+    from kernel_meta import short
+    wide = [k for k in kernels if k.get("max_flat_workgroup_size") == 256 and ", lean" not in short(k["name"])]
+    assert any("<Snu," in short(k["name"]) and "bwd" in short(k["name"]) for k in wide), [short(k["name"]) for k in wide]
+    over = [(short(k["name"]), k["vgpr_count"], k.get("agpr_count", 0)) for k in wide if k["vgpr_count"] + k.get("agpr_count", 0) > 256]
+    assert not over, over
