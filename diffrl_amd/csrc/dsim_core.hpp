@@ -1020,6 +1020,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_scan_fk_lane(const Ctx& c, Ex
     });
     if (on) stsv(WF(a) + 6 * i, a);
     ex.stamp();
+    ex.mid2();   // (several wavefronts: chunk sums and contact wrenches of the other wavefronts are complete, their per-body gather may start)
     // ---- COM, world inertia about the origin (Theta = R Ic R^T, A = Theta + m(c.c 1 - c c^T), h = m c) and body force
     const v3 cm = rotate(r, com) + p;
     v3 rx, ry, rz;
@@ -1139,11 +1140,24 @@ template <class Ctx> DSIM_FN void dsim_fwd_muscle_segments(const Ctx& c, int lan
 // kinematics of the links; the others copy the head of the checkpoint row while they wait for the poses, evaluate the muscle
 // segments from the published poses (mid2) while the first wavefront goes on with motion subspaces and twists, then (mid: twists
 // published, muscle rows complete) sum the muscle rows per chunk and evaluate the ground contacts while the first wavefront does
-// bias accelerations, inertias and body forces.  The phase ends with a workgroup barrier; the per-body gather (dsim_fwd_external)
-// follows.
+// bias accelerations, then (mid2) gather muscle and contact wrenches per body while it does inertias and body forces; behind
+// side_done_w the first wavefront adds the per-body rows to its body forces and sums f_tot over the subtrees on registers.
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_wide(const Ctx& c, Exec& ex, float* g_row) {
     constexpr int NLR = Exec::NL - DSIM_NL;
-    ex.fork_wave0([&](int lane) { dsim_scan_fk_lane(c, ex, lane); }, [&](int lane) {
+    using D = decltype(c.d);
+    ex.fork_wave0([&](int lane) {
+        dsim_scan_fk_lane(c, ex, lane);
+        // f_tot = subtree sums of (body force + the body's muscle and contact wrenches, gathered per body by the other wavefronts
+        // meanwhile): a row-tree sum on the link lanes' registers -- round 4 ran the gather and the sums as two more phases of all
+        // four wavefronts
+        ex.side_done_w();
+        const int i = lane < D::L ? lane : 0;
+        sv6 x = ldsv(WF(f) + 6 * i) + ldsv(WF(cwb) + 6 * i);   // (lanes without a link: link 0's values, which no step's weight selects)
+        dsim_rowtree_sum(c, ex, ex.topo(lane), x);
+        if (lane < D::L) stsv(WF(ftot) + 6 * lane, x);
+        // (the joint-space forces behind it on the same wavefront's dof lanes -- no phase of their own -- measured +-0: 0.2371 ->
+        // 0.2374 ms; they stay a phase of all wavefronts)
+    }, [&](int lane) {
         if (g_row) dsim_ckpt_store_row<Ctx, NLR, 1>(c, lane, g_row);   // head of the checkpoint row: (q, qd) entering the substep
         ex.mid2();   // poses
         dsim_fwd_muscle_segments(c, lane, NLR);
@@ -1153,6 +1167,12 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_wide(const Ctx
             const int b = CI(cbody)[k];
             stsv(WF(cw) + 6 * k, dsim_contact_wrench(dsim_contact_load(c, k), ld3(WF(xsc) + 7 * b), ldq(WF(xsc) + 7 * b + 3), ldsv(WF(v) + 6 * b)));
         }
+        ex.mid2();   // chunk sums and contact wrenches of all three wavefronts
+        for (int it = lane; it < 6 * c.d.L; it += NLR) {   // per body: its chunks' sums + its own contact wrenches
+            const int b = it / 6, k = it - 6 * b;
+            WF(cwb)[it] = dsim_body_contact_sum(c, b, WF(cw), 6, k, dsim_body_chunk_sum(c, b, k, 0.f));
+        }
+        ex.side_done_w();
     });
 }
 
@@ -1403,6 +1423,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Ex
     constexpr bool in_kin = DsimContactsInKin<Ctx, Exec::NL>::value || DsimScanFk<Ctx, Exec::NL>::value ||
                             DsimContactsAfterWalk<Ctx, Exec::NL>::value || wide;  // contacts were done by the kinematics phase
     if ((c.d.C == 0 || in_kin) && c.d.NS == 0) return;
+    if constexpr (wide) return;   // ... and so did the per-body gather and the subtree sums (dsim_fwd_kinematics_wide)
     if constexpr (!wide) {
         ex.run([&](int lane) {
             if constexpr (!in_kin) {
@@ -1641,33 +1662,35 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_ftot(const Ctx& c, Exec& 
     });
 }
 // joint-space forces (sim.py:1421-1502, 1792-1842)
-template <class Ctx, class Exec> DSIM_FN void dsim_fwd_tau(const Ctx& c, Exec& ex) {
-    dsim_fwd_ftot(c, ex);
-    ex.run([&](int lane) {
-        for (int d = lane; d < c.d.nd; d += Exec::NL) {
-            int i, type, cs, ds;
-            if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
-                const DsimTopoRegs& tp = ex.topo(lane);
-                i = tp.dof_link; type = tp.dof_type; cs = tp.dof_cs; ds = tp.dof_ds;
-                DSIM_OPAQUE(type);
-            } else {
-                i = CI(dof_link)[d]; type = CI(jtype)[i]; cs = CI(qstart)[i]; ds = CI(qdstart)[i];
-            }
-            float t = 0.0f - sdot(ldsv(WF(S) + 6 * d), ldsv(WF(ftot) + 6 * i));
-            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
-                const float q = WF(q)[cs], qd = WF(qd)[d];
-                const float lower = CF(lower)[cs], upper = CF(upper)[cs], lke = CF(lke)[i];
-                float limit_f = 0.0f;
-                if (q < lower) limit_f = lke * (lower - q);
-                if (q > upper) limit_f = lke * (upper - q);
-                t = t - CF(tke)[i] * (q - CF(target)[cs]) - CF(tkd)[i] * qd + WF(act)[d] + limit_f - CF(lkd)[i] * qd;
-            } else if (type == DSIM_JOINT_BALL) {
-                const int k = d - ds;
-                t = t - WF(qd)[d] * CF(tkd)[i] - WF(q)[cs + k] * CF(tke)[i];
-            }
-            WF(tau)[d] = t;
+// joint-space forces of the dofs `lane`, `lane + NL`, ... from f_tot (one lane per dof)
+template <class Ctx, class Exec> DSIM_FN void dsim_tau_lane(const Ctx& c, Exec& ex, int lane) {
+    for (int d = lane; d < c.d.nd; d += Exec::NL) {
+        int i, type, cs, ds;
+        if constexpr (DsimRoleRegs<Ctx, Exec::NL>::value) {
+            const DsimTopoRegs& tp = ex.topo(lane);
+            i = tp.dof_link; type = tp.dof_type; cs = tp.dof_cs; ds = tp.dof_ds;
+            DSIM_OPAQUE(type);
+        } else {
+            i = CI(dof_link)[d]; type = CI(jtype)[i]; cs = CI(qstart)[i]; ds = CI(qdstart)[i];
         }
-    });
+        float t = 0.0f - sdot(ldsv(WF(S) + 6 * d), ldsv(WF(ftot) + 6 * i));
+        if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
+            const float q = WF(q)[cs], qd = WF(qd)[d];
+            const float lower = CF(lower)[cs], upper = CF(upper)[cs], lke = CF(lke)[i];
+            float limit_f = 0.0f;
+            if (q < lower) limit_f = lke * (lower - q);
+            if (q > upper) limit_f = lke * (upper - q);
+            t = t - CF(tke)[i] * (q - CF(target)[cs]) - CF(tkd)[i] * qd + WF(act)[d] + limit_f - CF(lkd)[i] * qd;
+        } else if (type == DSIM_JOINT_BALL) {
+            const int k = d - ds;
+            t = t - WF(qd)[d] * CF(tkd)[i] - WF(q)[cs + k] * CF(tke)[i];
+        }
+        WF(tau)[d] = t;
+    }
+}
+template <class Ctx, class Exec> DSIM_FN void dsim_fwd_tau(const Ctx& c, Exec& ex) {
+    if constexpr (!DsimWideOverlap<Ctx, Exec>::value) dsim_fwd_ftot(c, ex);   // (several wavefronts: summed behind the kinematics)
+    ex.run([&](int lane) { dsim_tau_lane(c, ex, lane); });
 }
 
 // composite inertias Ic[i] = sum over subtree(i), F_b = Ic[link(b)] S_b
@@ -3258,13 +3281,13 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
         ex.stamp();
         // ---- the contact (and muscle) terms of the own body, reduced per body by the side block / the phases before this one /
         // the other wavefronts
-        if constexpr (WIDE) {
-            ex.mid2();          // (chunk sums done, the per-body gather may start)
-            ex.side_done_w();   // the per-body rows are there
-        } else {
-            ex.side_done();
-        }
-        const sv6 cpose = ldsv(WF(agx) + 12 * i), ctw = ldsv(WF(agx) + 12 * i + 6);
+        // (several wavefronts: two hand-overs -- the contacts' twist cotangents per body need no muscle chunk sums and come first,
+        // mid2; the pose wrenches per body, side_done_w, are picked up further down, in front of the last subtree sum)
+        if constexpr (WIDE) ex.mid2();
+        else ex.side_done();
+        sv6 cpose = zerosv();
+        if constexpr (!WIDE) cpose = ldsv(WF(agx) + 12 * i);
+        const sv6 ctw = ldsv(WF(agx) + 12 * i + 6);
         ex.loads_landed();
         // ---- avtot = subtree sum of (a_v + contact twist cotangents); cotangents of qd and of S; S is attached to the joint frame
         sv6 T = a_v + ctw;
@@ -3287,6 +3310,11 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
             }
         }
         // ---- azs = subtree sum of the pose wrenches (inertia + gravity, joint frame of the children's S, contacts / muscles)
+        if constexpr (WIDE) {
+            ex.side_done_w();   // the per-body pose wrenches of muscles + contacts are there
+            cpose = ldsv(WF(agx) + 12 * i);
+            ex.loads_landed();
+        }
         sv6 Z = W + Wp + cpose;
         dsim_rowtree_sum(c, ex, tp, Z);
         const sv6 Wt = Z - Wp;   // without the part attached to the link's own joint frame
@@ -3337,12 +3365,14 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
             dsim_bwd_external_items_n<NLR>(c, ex, lane);
             ex.mid();
             dsim_muscle_chunk_sums(c, lane, NLR);
+            for (int it = lane; it < 6 * c.d.L; it += NLR) {   // per body: twist cotangents of its contacts (no muscle terms)
+                const int i = it / 6, r = 6 + it - 6 * i;
+                WF(agx)[12 * i + r] = dsim_body_contact_sum(c, i, WF(acx), 12, r, 0.f);
+            }
             ex.mid2();
-            for (int it = lane; it < 12 * c.d.L; it += NLR) {
-                const int i = it / 12, r = it - 12 * i;
-                float acc = 0.f;
-                if (r < 6) acc = dsim_body_chunk_sum(c, i, r, 0.f);
-                WF(agx)[it] = dsim_body_contact_sum(c, i, WF(acx), 12, r, acc);
+            for (int it = lane; it < 6 * c.d.L; it += NLR) {   // per body: pose wrenches of its muscle rows (chunk sums) + its contacts
+                const int i = it / 6, r = it - 6 * i;
+                WF(agx)[12 * i + r] = dsim_body_contact_sum(c, i, WF(acx), 12, r, dsim_body_chunk_sum(c, i, r, 0.f));
             }
             ex.side_done_w();
             // nothing the first wavefront still needs: the activation cotangents (one sum per muscle) and the next row
