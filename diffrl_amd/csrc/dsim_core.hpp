@@ -136,6 +136,9 @@ DSIM_FN float dsim_range_sum_m(const float* data, int stride, int comp, int firs
 }
 // Bounds: whole lists for small trees (each lane makes one pass over its items); 8 for larger models, where the lanes
 // loop over several items and loading a long mostly-unused tail per item costs more issue slots than it saves latency.
+#ifndef DSIM_GENERIC_BATCH
+#define DSIM_GENERIC_BATCH 8   // entries the generic kernels' range sums request per round trip (the LDS image's spare tail covers the overrun)
+#endif
 template <class D> constexpr int dsim_cap_links() { return D::L <= 10 ? D::L : 8; }
 template <class D> constexpr int dsim_cap_subtree_contacts() { return D::C > 32 ? 8 : (D::C > 0 ? D::C : 1); }
 template <class D> constexpr int dsim_cap_body_contacts() { return D::C >= 8 ? 8 : (D::C > 0 ? D::C : 1); }
@@ -161,8 +164,8 @@ template <class Ctx> DSIM_FN float dsim_subtree_sum(const Ctx& c, const float* d
         const int n = n_known >= 0 ? n_known : reinterpret_cast<const dsim_int_a*>(c.k)[c.o.linfo + 8 * i + 5];
         if constexpr (DsimIsStatic<Ctx>::value)
             return dsim_range_sum_b<dsim_cap_links<decltype(c.d)>()>(data, stride, comp, i, n, 0.f);
-        else
-            return dsim_range_sum(data, stride, comp, i, n, 0.f);
+        else   // (generic kernels, round 5: the first eight entries in ONE round trip, whatever the count; the rest in the loop)
+            return dsim_range_sum_b<DSIM_GENERIC_BATCH>(data, stride, comp, i, n, 0.f);
     }
     return dsim_gather_sum(data, stride, comp, CI(sub_list), CI(sub_start)[i], CI(sub_start)[i + 1], 0.f);
 }
@@ -1456,7 +1459,7 @@ template <class Ctx> DSIM_FN float dsim_body_contact_sum(const Ctx& c, int i, co
         if constexpr (DsimIsStatic<Ctx>::value)
             return dsim_range_sum_b<dsim_cap_body_contacts<decltype(c.d)>()>(cdata, cstride, ck, b0, b1 - b0, acc);
         else
-            return dsim_range_sum(cdata, cstride, ck, b0, b1 - b0, acc);
+            return dsim_range_sum_b<DSIM_GENERIC_BATCH>(cdata, cstride, ck, b0, b1 - b0, acc);
     }
     return dsim_gather_sum(cdata, cstride, ck, CI(cb_list), b0, b1, acc);
 }
@@ -1500,8 +1503,8 @@ DSIM_FN float dsim_subtree_contact_sum(const Ctx& c, Exec& ex, int lane, int i, 
             acc = dsim_range_sum_b<dsim_cap_links<decltype(c.d)>()>(ldata, 6, k, i, li.nsub, 0.f);
             acc = dsim_range_sum_b<dsim_cap_subtree_contacts<decltype(c.d)>()>(cdata, cstride, ck, li.c0, li.nc, acc);
         } else {
-            acc = dsim_range_sum(ldata, 6, k, i, li.nsub, 0.f);
-            acc = dsim_range_sum(cdata, cstride, ck, li.c0, li.nc, acc);
+            acc = dsim_range_sum_b<DSIM_GENERIC_BATCH>(ldata, 6, k, i, li.nsub, 0.f);
+            acc = dsim_range_sum_b<DSIM_GENERIC_BATCH>(cdata, cstride, ck, li.c0, li.nc, acc);
         }
     } else {
         acc = dsim_gather_sum(ldata, 6, k, CI(sub_list), CI(sub_start)[i], CI(sub_start)[i + 1], 0.f);
@@ -1739,6 +1742,10 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_mass(const Ctx& c, Exec& 
     // wavefront with v_readlane (Exec::wave_gj), instead of 2 nd phases of LDS round trips.  Same formulas, same order.
     if constexpr (DsimWaveGj<Ctx, Exec>::value) {
         ex.template wave_gj<decltype(c.d)::nd>(WF(hinv));
+    } else if (Exec::WAVE_GJ_PAD && nd <= 32) {
+        // generic kernels: the same register inversion on the matrix padded to 16 or 32 (dsim_hip.hip: dsim_wave_gj_pad)
+        if (nd <= 16) ex.template wave_gj_pad<16>(WF(hinv), nd);
+        else ex.template wave_gj_pad<32>(WF(hinv), nd);
     } else {
         for (int k = 0; k < nd; ++k) {
             ex.run([&](int lane) {

@@ -111,6 +111,38 @@ template <int N, int NW> __device__ __forceinline__ void dsim_wave_gj(float* H) 
     }
 }
 
+// The same for a RUN-TIME size n <= NB (generic kernels: no compile-time nd): the matrix is padded with an identity block to
+// NB x NB in registers -- lane i < n holds (row i, zeros), lane i >= n the unit row e_i -- so the padded pivots are 1, their
+// multipliers 0, and the leading n x n block of the result is H^-1.  NB pivots of NB columns instead of 2 n phases of LDS round
+// trips (round 5: the generic Ant forward launch spent 39 k of its 273 k cycles in those phases).
+template <int NB, int NW> __device__ __forceinline__ void dsim_wave_gj_pad(float* H, int n) {
+    const int lane = (int)threadIdx.x;
+    if (NW > 1 && lane >= DSIM_NL) return;
+    float row[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) row[j] = (lane < n && j < n) ? H[lane * n + j] : ((j == lane) ? 1.0f : 0.0f);
+    float scale = 1.0f;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const float piv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row[k]), k));
+        const float rp = dsim_pivot_rcp(piv);
+        const bool own = lane == k;
+        const float f = own ? 0.0f : row[k] * rp;
+        scale = own ? rp : scale;
+        row[k] = own ? 1.0f : 0.0f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float hkj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row[j]), k));
+            row[j] = __builtin_fmaf(-f, hkj, row[j]);
+        }
+    }
+    if (lane < n) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (j < n) H[lane * n + j] = row[j] * scale;
+    }
+}
+
 // The same for two environments per wavefront (rows of the second one in lanes 32 ..): the pivot row travels through the LDS
 // crossbar (ds_bpermute), whose source lane may differ between the halves.
 template <int N> __device__ __forceinline__ void dsim_half_gj(float* H, int lane, int half_addr) {
@@ -513,6 +545,12 @@ template <int NW, int PF = 6, int CW = 0, bool HELPER = false, int EPW = 1> stru
         else if (!helper_) dsim_wave_gj<N, NW>(H);
         sync();
     }
+    // ... of a run-time size n <= NB (generic kernels), padded in registers
+    static constexpr bool WAVE_GJ_PAD = EPW == 1;
+    template <int NB> __device__ __forceinline__ void wave_gj_pad(float* H, int n) {
+        if (!helper_) dsim_wave_gj_pad<NB, NW>(H, n);
+        sync();
+    }
     // lane-private accumulators of the mass-matrix cotangent (dsim_core.hpp: DSIM_HACC_MAX registers per lane)
     float hacc_[DSIM_HACC_MAX];
     __device__ __forceinline__ float* hacc(int) { return hacc_; }
@@ -668,12 +706,19 @@ template <class O, class D> struct KCommonT {
 // prefetch registers a model's checkpoint row needs (compile-time layouts), or the generic default of 6 (rows up to 1536 floats
 // at one wavefront per environment; longer rows are read at commit time)
 // models that get a helper wavefront: specialised one-wave kernels of models with ground contacts and without muscles
-template <class D, int NW> constexpr bool dsim_has_helper() {
+// FWD: a forward kernel.  The GENERIC one-wave kernels (run-time layout) get a helper wavefront for their ADJOINT only (round 5):
+// its fork_join phases -- the af block beside the accumulators of adj H and the per-dof cotangents, contacts^T beside the per-link
+// block of the body level -- are the same phase code; the generic forward has no split phase, a helper would only idle there.
+template <class D, int NW, bool FWD = false> constexpr bool dsim_has_helper() {
 #ifdef DSIM_NO_HELPER
     return false;
 #else
     if constexpr (std::is_empty<D>::value) return NW == 1 && D::C > 0 && D::NS == 0 && D::L + D::C <= DSIM_NL;
+#ifdef DSIM_NO_GENERIC_HELPER   // (A/B builds)
     else return false;
+#else
+    else return NW == 1 && !FWD;
+#endif
 #endif
 }
 // models that get two-environments-per-wave kernels: specialised one-wave models whose phases fit 32 lanes
@@ -693,7 +738,7 @@ template <class D, int NW, bool FWD, class F> int dsim_with_flags(bool lean, int
     using M0 = std::integral_constant<int, DSIM_MODE_PLAIN>;
     using M1 = std::integral_constant<int, DSIM_MODE_HELPER>;
     using M2 = std::integral_constant<int, DSIM_MODE_PAIR>;
-    if constexpr (dsim_has_helper<D, NW>()) {
+    if constexpr (dsim_has_helper<D, NW, FWD>()) {
         if (mode == DSIM_MODE_HELPER) return lean ? f(std::true_type{}, M1{}) : f(std::false_type{}, M1{});
     }
 #ifdef DSIM_PAIR_BWD
@@ -950,6 +995,10 @@ template <int NW> struct TimingExec {
     }
     template <int N> __device__ __forceinline__ void wave_gj(float* H) {
         run([&](int) { dsim_wave_gj<N, NW>(H); });
+    }
+    static constexpr bool WAVE_GJ_PAD = true;
+    template <int NB> __device__ __forceinline__ void wave_gj_pad(float* H, int n) {
+        run([&](int) { dsim_wave_gj_pad<NB, NW>(H, n); });
     }
     float hacc_[DSIM_HACC_MAX];
     __device__ __forceinline__ float* hacc(int) { return hacc_; }
@@ -1253,7 +1302,15 @@ int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
                     if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             };
             raise(std::integral_constant<int, DSIM_MODE_PLAIN>{});
-            if constexpr (dsim_has_helper<D, NW>()) raise(std::integral_constant<int, DSIM_MODE_HELPER>{});
+            if constexpr (dsim_has_helper<D, NW, true>()) raise(std::integral_constant<int, DSIM_MODE_HELPER>{});
+            else if constexpr (dsim_has_helper<D, NW, false>()) {   // (generic kernels: helper-wave ADJOINT kernels only)
+                const void* fns[] = {reinterpret_cast<const void*>(dsim_bwd_kernel<O, D, NW, false, DSIM_MODE_HELPER>),
+                                     reinterpret_cast<const void*>(dsim_env_bwd_kernel<O, D, NW, false, DSIM_MODE_HELPER>),
+                                     reinterpret_cast<const void*>(dsim_bwd_kernel<O, D, NW, true, DSIM_MODE_HELPER>),
+                                     reinterpret_cast<const void*>(dsim_env_bwd_kernel<O, D, NW, true, DSIM_MODE_HELPER>)};
+                for (const void* fn : fns)
+                    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            }
             if constexpr (dsim_has_pair<D, NW>()) {
                 const void* fns[] = {reinterpret_cast<const void*>(dsim_fwd_kernel<O, D, NW, false, DSIM_MODE_PAIR>),
                                      reinterpret_cast<const void*>(dsim_env_fwd_kernel<O, D, NW, false, DSIM_MODE_PAIR>),
@@ -1299,15 +1356,20 @@ void dsim_helper_capacity(dsim_model* m) {
                 ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 2 * DSIM_NL, (size_t)words * 4) == hipSuccess;
                 if (n < per_cu) per_cu = n;
             };
+            constexpr bool FWD_TOO = dsim_has_helper<D, NW, true>();   // (generic kernels: the adjoint alone)
             cap(dsim_env_bwd_kernel<O, D, NW, false, DSIM_MODE_HELPER>, m->lay.o.total_words);
-            cap(dsim_env_fwd_kernel<O, D, NW, false, DSIM_MODE_HELPER>, m->lay.o.fwd_words);
             cap(dsim_bwd_kernel<O, D, NW, false, DSIM_MODE_HELPER>, m->lay.o.total_words);
-            cap(dsim_fwd_kernel<O, D, NW, false, DSIM_MODE_HELPER>, m->lay.o.fwd_words);
+            if constexpr (FWD_TOO) {
+                cap(dsim_env_fwd_kernel<O, D, NW, false, DSIM_MODE_HELPER>, m->lay.o.fwd_words);
+                cap(dsim_fwd_kernel<O, D, NW, false, DSIM_MODE_HELPER>, m->lay.o.fwd_words);
+            }
             if (m->lean) {   // (the mode is chosen right after creation; dsim_model_set_ckpt_mode re-evaluates)
                 cap(dsim_env_bwd_kernel<O, D, NW, true, DSIM_MODE_HELPER>, m->lay.o.total_words);
-                cap(dsim_env_fwd_kernel<O, D, NW, true, DSIM_MODE_HELPER>, m->lay.o.fwd_words);
                 cap(dsim_bwd_kernel<O, D, NW, true, DSIM_MODE_HELPER>, m->lay.o.total_words);
-                cap(dsim_fwd_kernel<O, D, NW, true, DSIM_MODE_HELPER>, m->lay.o.fwd_words);
+                if constexpr (FWD_TOO) {
+                    cap(dsim_env_fwd_kernel<O, D, NW, true, DSIM_MODE_HELPER>, m->lay.o.fwd_words);
+                    cap(dsim_fwd_kernel<O, D, NW, true, DSIM_MODE_HELPER>, m->lay.o.fwd_words);
+                }
             }
             m->helper_max_envs = ok ? cus * per_cu : 0;
             if (const char* f = getenv("DSIM_HELPER")) m->helper_max_envs = atoi(f) ? (1 << 30) : 0;

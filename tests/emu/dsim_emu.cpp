@@ -208,6 +208,15 @@ template <int NW, int LANES = DSIM_NL> struct HostExecT {
         for (int i = 0; i < N; ++i)
             for (int j = 0; j < N; ++j) H[i * N + j] *= scale[i];
     }
+    static constexpr bool WAVE_GJ_PAD = true;
+    template <int NB> void wave_gj_pad(float* H, int n) {   // (device: the matrix padded with an identity block in registers)
+        float P[NB * NB];
+        for (int i = 0; i < NB; ++i)
+            for (int j = 0; j < NB; ++j) P[i * NB + j] = (i < n && j < n) ? H[i * n + j] : (i == j ? 1.0f : 0.0f);
+        wave_gj<NB>(P);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) H[i * n + j] = P[i * NB + j];
+    }
     void mark(int) {}
     void begin_request() {}
     void begin() {}   // the host image is set up by make_ctx (constants copied, work area zero)
