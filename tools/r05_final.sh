@@ -9,4 +9,4 @@ DSIM_LIB=$PWD/tools/libdsim_snu_stamps.so python tools/stamps.py snu 512 > gpuru
 DSIM_HELPER=1 DSIM_LIB=$PWD/tools/libdsim_ant_stamps.so python tools/stamps.py ant 1024 > gpurun_out/r05_stamps_ant.txt 2>&1
 DSIM_HELPER=1 DSIM_LIB=$PWD/tools/libdsim_hum_stamps.so python tools/stamps.py humanoid 1024 > gpurun_out/r05_stamps_humanoid.txt 2>&1
 cat gpurun_out/r05_ablation_snu.txt
-bash tools/gpu_profiles.sh r05f ant humanoid snu
+bash tools/gpu_profiles.sh r05f ant humanoid snu ant8192 antmm1
