@@ -110,26 +110,32 @@ class DsimError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
 EXPECTED_ABI = 106   # dsim_version() of the library this binding was written against (argument lists of include/dsim.h)
 
 
 def lib():
     """Loads libdsim_hip.so; raises if it is absent (no fallback by design)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    return load(LIB_PATH)
+
+
+def load(path):
+    """Binding of the library at `path` (libdsim_hip.so, or a library of the same sources built for a user model by
+    diffrl_amd.specialise); one handle per path."""
+    path = os.path.abspath(path)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise DsimError("HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                        "(there is no CPU fallback)" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+                        "(there is no CPU fallback)" % path)
+    L = C.CDLL(path)
     vp = C.c_void_p
     L.dsim_last_error.restype = C.c_char_p
     L.dsim_version.restype = C.c_int
     if int(L.dsim_version()) != EXPECTED_ABI:
         raise DsimError("%s reports ABI version %d, this binding expects %d: stale build or a DSIM_LIB override built "
                         "against other argument lists; rebuild (DSIM_FORCE_REBUILD=1 python __graft_entry__.py)"
-                        % (LIB_PATH, int(L.dsim_version()), EXPECTED_ABI))
+                        % (path, int(L.dsim_version()), EXPECTED_ABI))
     L.dsim_model_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp)]
     L.dsim_model_destroy.argtypes = [vp]
     L.dsim_model_variant.argtypes = [vp]
@@ -157,13 +163,14 @@ def lib():
                L.dsim_env_step_forward, L.dsim_env_step_backward, L.dsim_env_observe, L.dsim_model_status,
                L.dsim_body_transforms):
         fn.restype = C.c_int
-    _lib = L
+    _libs[path] = L
     return L
 
 
-def check(rc):
+def check(rc, L=None):
+    """L: the library the call went to (default: the product library)"""
     if rc != 0:
-        raise DsimError("dsim error %d: %s" % (rc, lib().dsim_last_error().decode()))
+        raise DsimError("dsim error %d: %s" % (rc, (L or lib()).dsim_last_error().decode()))
 
 
 EXPORTS = ("dsim_last_error", "dsim_version", "dsim_model_create", "dsim_model_destroy", "dsim_model_variant", "dsim_model_device",

@@ -18,9 +18,13 @@ def _ptr(t):
 class Engine:
     """Owns the device copy of one articulation template on one GPU."""
 
-    def __init__(self, template: ArticulationTemplate, device, ckpt_mode=None):
+    def __init__(self, template: ArticulationTemplate, device, ckpt_mode=None, specialise=None):
         """ckpt_mode: "full" (default; $DIFFRL_AMD_CKPT overrides) -- the forward launch streams every intermediate the
-        adjoint reads to HBM -- or "lean" -- (q, qd) per substep only, the adjoint recomputes (include/dsim.h)."""
+        adjoint reads to HBM -- or "lean" -- (q, qd) per substep only, the adjoint recomputes (include/dsim.h).
+        specialise: True -- a model that matches none of the compiled layout tables (it would run the generic kernels, about
+        half the speed) gets a kernel set of its own, compiled with hipcc on first use and cached next to the library
+        (diffrl_amd.specialise.ensure_library: about a minute, once per model and source version); None: $DSIM_AUTO_SPECIALISE
+        (default off: nothing is compiled at run time unless asked for)."""
         self.template = template
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -29,16 +33,25 @@ class Engine:
         if self.device.index is None:   # "cuda" means the current device; tensors report an explicit index
             self.device = torch.device("cuda", torch.cuda.current_device())
         self._desc, self._keep = capi.make_desc(template)
-        h = C.c_void_p()
-        with torch.cuda.device(self.device):
-            capi.check(self._lib.dsim_model_create(C.byref(self._desc), C.byref(h)))
-        self._h = h
         import os
+        if specialise is None:
+            specialise = os.environ.get("DSIM_AUTO_SPECIALISE", "0") not in ("", "0")
+        h = self._create()
+        if specialise and int(self._lib.dsim_model_variant(h)) == 0:
+            from . import specialise as sp
+            path = sp.ensure_library(template)   # None: hipcc missing or the build failed (warned about); the generic kernels stay
+            if path is not None:
+                self._lib.dsim_model_destroy(h)
+                self._lib = capi.load(path)
+                h = self._create()
+                if int(self._lib.dsim_model_variant(h)) == 0:
+                    raise capi.DsimError("%s was built for this model but dsim_model_create does not match it" % path)
+        self._h = h
         self.ckpt_mode = (ckpt_mode or os.environ.get("DIFFRL_AMD_CKPT", "full")).lower()
         if self.ckpt_mode not in ("full", "lean"):
             raise capi.DsimError("ckpt_mode must be 'full' or 'lean'")
         with torch.cuda.device(self.device):   # (re-evaluates the occupancy of the helper-wave kernels on the model's device)
-            capi.check(self._lib.dsim_model_set_ckpt_mode(h, capi.CKPT_LEAN if self.ckpt_mode == "lean" else capi.CKPT_FULL))
+            self._ck(self._lib.dsim_model_set_ckpt_mode(h, capi.CKPT_LEAN if self.ckpt_mode == "lean" else capi.CKPT_FULL))
         assert int(self._lib.dsim_model_device(h)) == self.device.index
         self.variant = int(self._lib.dsim_model_variant(h))  # 0 = generic kernels, > 0 = specialised for this model
         self.n_q, self.n_qd, self.n_muscles = template.n_q, template.n_qd, template.n_muscles
@@ -46,6 +59,15 @@ class Engine:
         # environment -- never a reference to the checkpoint itself, which is hundreds of MB for the humanoid and must die with
         # its autograd node): what State.body_X_sc derives the reference's lagging transforms from (dflex/sim.py)
         self.last_q_in = None
+
+    def _ck(self, rc):
+        capi.check(rc, self._lib)
+
+    def _create(self):
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            self._ck(self._lib.dsim_model_create(C.byref(self._desc), C.byref(h)))
+        return h
 
     def __del__(self):
         try:
@@ -59,7 +81,7 @@ class Engine:
         """Raises DsimError if a forward launch since the last report was handed a non-unit quaternion (include/dsim.h:
         the path is defined on unit quaternions only).  Host-side read of two mapped words; synchronise first for a
         definitive answer about launches still in flight."""
-        capi.check(self._lib.dsim_model_status(self._h, None))
+        self._ck(self._lib.dsim_model_status(self._h, None))
 
     def body_transforms(self, q):
         """(X_sc, X_sm), each [n_envs * n_links, 7]: link frames and centre-of-mass frames in the world for the joint
@@ -72,7 +94,7 @@ class Engine:
         xsm = torch.empty((n * L, 7), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            capi.check(self._lib.dsim_body_transforms(self._h, n, _ptr(q), _ptr(xsc), _ptr(xsm), st))
+            self._ck(self._lib.dsim_body_transforms(self._h, n, _ptr(q), _ptr(xsc), _ptr(xsm), st))
         return xsc, xsm
 
     def last_substep_q(self, ckpt, substeps):
@@ -113,7 +135,7 @@ class Engine:
         self.last_q_in = None
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            capi.check(self._lib.dsim_step_forward(self._h, n, _ptr(q), _ptr(qd), _ptr(act),
+            self._ck(self._lib.dsim_step_forward(self._h, n, _ptr(q), _ptr(qd), _ptr(act),
                                                    _ptr(mact) if self.n_muscles else None, C.c_float(dt), substeps,
                                                    mm_freq, _ptr(q_out), _ptr(qd_out), _ptr(ckpt), st))
         if ckpt is not None and keep_q_in:
@@ -140,7 +162,7 @@ class Engine:
         gm = torch.empty(n * self.n_muscles, dtype=torch.float32, device=self.device) if self.n_muscles else None
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            capi.check(self._lib.dsim_step_backward(self._h, n, _ptr(ckpt), _ptr(act),
+            self._ck(self._lib.dsim_step_backward(self._h, n, _ptr(ckpt), _ptr(act),
                                                     _ptr(mact) if self.n_muscles else None, C.c_float(dt), substeps,
                                                     mm_freq, _ptr(gq_out), _ptr(gqd_out), _ptr(gq), _ptr(gqd),
                                                     _ptr(gact), _ptr(gm), st))
@@ -165,7 +187,7 @@ class Engine:
             ep, extra = episode.bind(self, n, spec.n_obs)
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            capi.check(self._lib.dsim_env_step_forward(self._h, C.byref(spec), n, _ptr(q), _ptr(qd), _ptr(actions),
+            self._ck(self._lib.dsim_env_step_forward(self._h, C.byref(spec), n, _ptr(q), _ptr(qd), _ptr(actions),
                                                        C.c_float(dt), substeps, mm_freq, _ptr(q_out), _ptr(qd_out),
                                                        _ptr(obs), _ptr(rew), _ptr(ckpt),
                                                        C.byref(ep) if ep is not None else None, st))
@@ -180,7 +202,7 @@ class Engine:
         ga = torch.empty((n, spec.n_act), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            capi.check(self._lib.dsim_env_step_backward(self._h, C.byref(spec), n, _ptr(ckpt), _ptr(actions),
+            self._ck(self._lib.dsim_env_step_backward(self._h, C.byref(spec), n, _ptr(ckpt), _ptr(actions),
                                                         C.c_float(dt), substeps, mm_freq, _ptr(gq_out), _ptr(gqd_out),
                                                         _ptr(gobs), _ptr(grew), _ptr(gobs_before), _ptr(gq), _ptr(gqd),
                                                         _ptr(ga), st))
@@ -192,7 +214,7 @@ class Engine:
         rew = torch.empty(n, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            capi.check(self._lib.dsim_env_observe(self._h, C.byref(spec), n, _ptr(q), _ptr(qd), _ptr(stored_actions),
+            self._ck(self._lib.dsim_env_observe(self._h, C.byref(spec), n, _ptr(q), _ptr(qd), _ptr(stored_actions),
                                                   _ptr(obs), _ptr(rew), st))
         return obs, rew
 

@@ -12,9 +12,11 @@ and sizes as compile-time constants.  This module
   4. rebuilds csrc/libdsim_hip.so with hipcc (the flags of __graft_entry__.build(); ~40 s per model).
 At run time dsim_model_create compares the layout it builds with the tables and uses a specialised set only on an exact match;
 `dsim_model_variant(m) > 0` (Engine.variant) confirms it.  Build-time constants only: nothing is generated or compiled at run
-time.  (tools/gen_static_layouts.py, the developer tool that regenerates the shipped tables, calls render() below.)
+time -- unless asked for: Engine(..., specialise=True) / DSIM_AUTO_SPECIALISE=1 runs steps 1, 3 and 4 for the one model into
+a library of its own on first use (ensure_library below; csrc/user_libs/, keyed by layout and source hash).  (tools/gen_static_layouts.py, the developer tool that regenerates the shipped tables, calls render() below.)
 """
 import argparse
+import shutil
 import ctypes as C
 import os
 import re
@@ -160,17 +162,90 @@ def matches(t, header_text):
     return None
 
 
-def build_library(out, header=None, only=None):
+def build_library(out, header=None, only=None, quiet=False):
     """hipcc: csrc/dsim_hip.hip -> out.  header: another generated layouts header than csrc/dsim_static_layouts.hpp;
-    only: list of model names to compile specialised sets for (the generic kernels are always there)"""
+    only: list of model names to compile specialised sets for (the generic kernels are always there);
+    quiet: capture the compiler's output (it is in the CalledProcessError if the build fails)"""
     cmd = ["hipcc"] + HIPCC_FLAGS
     if header:
         cmd.append('-DDSIM_STATIC_LAYOUTS_FILE="%s"' % os.path.abspath(header))
     if only:
         cmd.append("-DDSIM_STATIC_VARIANTS(X)=" + " ".join("X(%s)" % m for m in only))
     cmd += [os.path.join(CSRC, "dsim_hip.hip"), "-o", out]
-    subprocess.check_call(cmd)
+    if quiet:
+        subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    else:
+        subprocess.check_call(cmd)
     return out
+
+
+USER_LIBS = os.path.join(CSRC, "user_libs")
+
+
+def source_hash():
+    """hash of the kernel sources a library is built from (the layout tables excepted: a user library brings its own)"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("dsim_core.hpp", "dsim_hip.hip", "dsim_math.hpp", "dsim_layout.hpp", os.path.join("..", "..", "include", "dsim.h")):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def ensure_library(t, cache_dir=None, log=None):
+    """Path of a library that holds a specialised kernel set for template t, compiling one on first use
+    (Engine(..., specialise=True) / DSIM_AUTO_SPECIALISE=1; the reference compiles ALL its kernels on first use,
+    dflex/dflex/adjoint.py:2201-2263 -- here only a model that matches no compiled table does, and only when asked).
+
+    * t matches a table of the product library: that library's path, nothing is built.
+    * otherwise: <cache_dir>/libdsim_U<layout hash>_<source hash>.so; built with hipcc (generic kernels +
+      this model's set, the recipe of `python -m diffrl_amd.specialise --only`) under a file lock, so that the ranks of a job
+      that create the same model at the same time compile it once; written under a temporary name and renamed.
+    * no hipcc, or the build fails (a tree shape one of the specialised phases refuses at compile time): a warning and None --
+      the caller keeps the generic kernels, which run every model the layout builder accepts.
+    cache_dir: default $DSIM_USER_LIBS, else csrc/user_libs/ (next to the product library, so that it travels with the package)."""
+    import fcntl
+    import hashlib
+    import warnings
+    header_txt = open(HEADER).read()
+    if os.environ.get("DSIM_LIB") is None and matches(t, header_txt):
+        return capi.LIB_PATH
+    flat = flat_table(*layout(t))
+    name = "U" + hashlib.sha1(",".join(str(v) for v in flat).encode()).hexdigest()[:12]
+    src = hashlib.sha1((source_hash() + "|" + " ".join(HIPCC_FLAGS)).encode()).hexdigest()[:10]
+    cache_dir = cache_dir or os.environ.get("DSIM_USER_LIBS") or USER_LIBS
+    out = os.path.join(cache_dir, "libdsim_%s_%s.so" % (name, src))
+    if os.path.exists(out):
+        return out
+    if shutil.which("hipcc") is None:
+        warnings.warn("diffrl_amd.specialise: hipcc not found, this model keeps the generic kernels")
+        return None
+    os.makedirs(cache_dir, exist_ok=True)
+    say = log or (lambda m: print("[diffrl_amd.specialise] " + m, file=sys.stderr, flush=True))
+    with open(os.path.join(cache_dir, ".lock_" + name), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if os.path.exists(out):   # another process built it while this one waited
+                return out
+            header = os.path.join(cache_dir, "dsim_static_layouts_%s.hpp" % name)
+            open(header, "w").write(render([(name, t)]))
+            tmp = out + ".tmp%d" % os.getpid()
+            say("compiling a kernel set for this model (%d links, %d dofs, %d contacts): %s, about a minute, once"
+                % (t.n_links, t.n_qd, t.n_contacts, out))
+            try:
+                build_library(tmp, header, [name], quiet=True)
+            except subprocess.CalledProcessError as e:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                warnings.warn("diffrl_amd.specialise: hipcc refused the specialised kernels of this model (it keeps the generic "
+                              "ones):\n%s" % (e.output or b"").decode(errors="replace")[-2000:])
+                return None
+            os.replace(tmp, out)
+            for f in os.listdir(cache_dir):   # this model's libraries of earlier source versions
+                if f.startswith("libdsim_%s_" % name) and f.endswith(".so") and os.path.join(cache_dir, f) != out:
+                    os.remove(os.path.join(cache_dir, f))
+            return out
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def main(argv=None):

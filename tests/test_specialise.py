@@ -188,3 +188,88 @@ def test_row_tree_user_model_specialised_paths_match_generic_on_the_host_harness
     # same terms, associated by tree level instead of by index (and, since round 5, a 22 x 22 inverse padded to 32 on the generic
     # side): measured 2.4e-5 over forward + adjoint of this 17-link, 9-level tree; the shipped models hold 2e-5
     assert float(res[0].split("worst_rel=")[1].split()[0]) < 5e-5, res[0]
+
+
+def test_ensure_library_builds_once_per_model_and_falls_back_loudly(tmp_path, monkeypatch):
+    """the compile-on-first-use path (Engine(..., specialise=True)): a shipped model needs nothing; a user model gets ONE build per
+    layout and source version (hipcc replaced by a stub here: the real compile is build()'s job and the GPU test's); a build that
+    fails leaves no file and returns None with a warning (the caller keeps the generic kernels)"""
+    from oracle_lib import template_from_golden
+    from diffrl_amd import capi
+    monkeypatch.delenv("DSIM_LIB", raising=False)
+    calls = []
+
+    def fake_build(out, header=None, only=None, quiet=False):
+        txt = open(header).read()
+        assert only and ("struct DsimOff%s " % only[0]) in txt and ("X(%s)" % only[0]) in txt
+        assert specialise.matches(user, txt) == only[0] or specialise.matches(other, txt) == only[0]
+        calls.append(out)
+        open(out, "wb").write(b"stub")
+        return out
+
+    monkeypatch.setattr(specialise, "build_library", fake_build)
+    monkeypatch.setattr(specialise.shutil, "which", lambda x: "/usr/bin/" + x)
+    user, other = ArticulationTemplate.load(FIXTURE), ArticulationTemplate.load(ROWTREE)
+    assert specialise.ensure_library(template_from_golden("ant"), cache_dir=str(tmp_path)) == capi.LIB_PATH and not calls
+    p1 = specialise.ensure_library(user, cache_dir=str(tmp_path), log=lambda m: None)
+    assert p1 and os.path.dirname(p1) == str(tmp_path) and os.path.exists(p1) and len(calls) == 1
+    assert specialise.ensure_library(user, cache_dir=str(tmp_path)) == p1 and len(calls) == 1          # cached
+    p2 = specialise.ensure_library(other, cache_dir=str(tmp_path), log=lambda m: None)
+    assert p2 != p1 and len(calls) == 2                                                                  # keyed by the layout
+    monkeypatch.setattr(specialise, "source_hash", lambda: "0" * 12)                                      # the kernel sources changed
+    p3 = specialise.ensure_library(user, cache_dir=str(tmp_path), log=lambda m: None)
+    assert p3 != p1 and len(calls) == 3 and not os.path.exists(p1) and os.path.exists(p2)               # rebuilt, the stale one removed
+
+    def failing(out, header=None, only=None, quiet=False):
+        open(out, "wb").write(b"partial")
+        raise subprocess.CalledProcessError(1, "hipcc", output=b"error: static assertion failed")
+
+    monkeypatch.setattr(specialise, "build_library", failing)
+    monkeypatch.setattr(specialise, "source_hash", lambda: "1" * 12)
+    with pytest.warns(UserWarning, match="keeps the generic"):
+        assert specialise.ensure_library(user, cache_dir=str(tmp_path), log=lambda m: None) is None
+    assert not [f for f in os.listdir(tmp_path) if ".tmp" in f]
+
+
+_AUTO_SCRIPT = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, %(root)r)
+from diffrl_amd.engine import Engine
+from diffrl_amd.template import ArticulationTemplate
+from test_edge_cases_cpu import _tree_states
+dev = torch.device("cuda:0")
+t = ArticulationTemplate.load(%(fixture)r)
+rng = np.random.default_rng(11)
+q, qd, act = _tree_states(t, rng, 64)
+gq, gqd = rng.normal(0, 1, q.shape).astype(np.float32), rng.normal(0, 1, qd.shape).astype(np.float32)
+T = lambda a: torch.tensor(a, device=dev).reshape(-1)
+outs = []
+for auto in (False, True):
+    eng = Engine(t, dev, specialise=auto)
+    assert (eng.variant > 0) == auto, (eng.variant, auto)
+    qo, qdo, ck = eng.forward(T(q), T(qd), T(act), None, 4 / 960.0, 4, 2, True)
+    g = eng.backward(ck, T(act), None, 4 / 960.0, 4, 2, T(gq), T(gqd))
+    torch.cuda.synchronize()
+    eng.status()
+    outs.append([x.cpu().numpy() for x in (qo, qdo) + tuple(y for y in g if y is not None)])
+ant = Engine(__import__("oracle_lib").template_from_golden("ant"), dev, specialise=True)     # a shipped model: the product library's own set
+assert ant.variant > 0 and ant._lib is __import__("diffrl_amd.capi", fromlist=["x"]).lib()
+worst = max(float(np.abs(a - b).max() / (np.abs(a).max() + 1e-30)) for a, b in zip(*outs))
+print("RESULT worst_rel=%%.3e" %% worst)
+'''
+
+
+@pytest.mark.gpu
+def test_engine_compiles_a_kernel_set_on_first_use_when_asked():
+    """Engine(template, device, specialise=True) (or DSIM_AUTO_SPECIALISE=1) on a model without a compiled table: a library of its
+    own from csrc/user_libs/ (build() prepared it; compiled here otherwise, about a minute), variant > 0, same results as the generic
+    kernels; without the flag nothing changes; a shipped model keeps the product library"""
+    e = dict(os.environ)
+    for k in ("DSIM_LIB", "DSIM_FORCE_GENERIC", "DSIM_AUTO_SPECIALISE"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", _AUTO_SCRIPT % dict(root=ROOT, fixture=FIXTURE)], cwd=ROOT, env=e, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+    worst = float(r.stdout.split("worst_rel=")[1].split()[0])
+    assert worst < 1e-4, r.stdout
