@@ -1,0 +1,35 @@
+"""GPU: launch-time guard of the three BASELINE configurations.  The kernels' speed rests on instruction scheduling that only A/B
+runs used to watch (CHANGELOG "measured and rejected"): a toolchain or source change that costs a launch
+30 % or more -- a phase state landing in scratch, a lost helper wavefront, a register row spilled -- fails HERE instead of
+surfacing in the next bench.  Bounds: 1.3 x the round-5 launch times (box-to-box spread over the round
+was 1 %), measured as bench.py measures them (HIP events around the env-step launches, same shapes as the rollout)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+# env, environments, (forward, adjoint) launch in ms at round 5
+RECORDED = [("ant", 1024, 0.0529, 0.0534), ("humanoid", 1024, 0.1808, 0.1776), ("snu", 512, 0.2476, 0.2516)]
+MARGIN = 1.3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n,fwd_ms,bwd_ms", RECORDED)
+def test_env_step_launches_stay_within_the_recorded_times(name, n, fwd_ms, bwd_ms):
+    if os.environ.get("DSIM_LIB") or os.environ.get("DSIM_FORCE_GENERIC"):
+        pytest.skip("developer override in the environment: the bounds belong to the shipped specialised kernels")
+    import bench
+    device = torch.device("cuda:0")
+    env = bench.make_env(name, n, str(device))
+    assert env.model.engine().variant > 0, "the specialised kernel set of %s was not selected" % name
+    best = [1e9, 1e9]
+    for _ in range(3):   # minimum of three: a neighbour on the box must not fail the guard
+        rf = bench.roofline_record(env, name, n, 32, bench.MM_FREQ[name], device, 20, counters=False)
+        best = [min(best[0], rf["fwd_kernel_ms"]), min(best[1], rf["kernel_ms"])]
+    print("%s %d: forward %.4f ms (recorded %.4f), adjoint %.4f ms (recorded %.4f)" % (name, n, best[0], fwd_ms, best[1], bwd_ms))
+    assert best[0] < MARGIN * fwd_ms, "forward launch %.4f ms, recorded %.4f" % (best[0], fwd_ms)
+    assert best[1] < MARGIN * bwd_ms, "adjoint launch %.4f ms, recorded %.4f" % (best[1], bwd_ms)
