@@ -1,7 +1,7 @@
 """GPU: launch-time guard of the three BASELINE configurations.  The kernels' speed rests on instruction scheduling that only A/B
 runs used to watch (CHANGELOG "measured and rejected"): a toolchain or source change that costs a launch
-30 % or more -- a phase state landing in scratch, a lost helper wavefront, a register row spilled -- fails HERE instead of
-surfacing in the next bench.  Bounds: 1.3 x the round-5 launch times (box-to-box spread over the round
+half as much again -- a phase state landing in scratch, a lost helper wavefront, a register row spilled -- fails HERE instead of
+surfacing in the next bench.  Bounds: 1.5 x the round-5 launch times (box-to-box spread over the round
 was 1 %), measured as bench.py measures them (HIP events around the env-step launches, same shapes as the rollout)."""
 import os
 import sys
@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 # env, environments, (forward, adjoint) launch in ms at round 5
 RECORDED = [("ant", 1024, 0.0529, 0.0534), ("humanoid", 1024, 0.1808, 0.1776), ("snu", 512, 0.2476, 0.2516)]
-MARGIN = 1.3
+MARGIN = 1.5
 
 
 @pytest.mark.gpu
