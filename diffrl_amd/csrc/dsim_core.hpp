@@ -118,6 +118,24 @@ DSIM_FN float dsim_range_sum_b(const float* data, int stride, int comp, int firs
     if (count > B) acc = dsim_range_sum(data, stride, comp, first + B, count - B, acc);
     return acc;
 }
+// ... and for ranges that are filled up to B entries with zeros (the chunks of muscle rows, dsim_layout.hpp: seg_slot): B
+// unconditional additions; x + 0 = x, so the result is that of dsim_range_sum over the entries that exist (up to the sign of a zero)
+// (G: entries requested per round trip -- B at once, or in groups where the registers are short; same additions in the same order)
+template <int B, int G = B> DSIM_FN float dsim_range_sum_all(const float* data, int stride, int comp, int first) {
+    static_assert(B % G == 0, "groups tile the range");
+    const float* p = data + comp + stride * first;
+    float acc = 0.f;
+#pragma unroll
+    for (int g = 0; g < B; g += G) {
+        float x[G];
+#pragma unroll
+        for (int e = 0; e < G; ++e) x[e] = p[stride * (g + e)];
+        if (G < B) asm volatile("" ::: "memory");   // (keeps the groups apart: the next group's loads are not hoisted over these additions)
+#pragma unroll
+        for (int e = 0; e < G; ++e) acc += x[e];
+    }
+    return acc;
+}
 // The same with a per-entry weight m[e] in {1.0f, 0.0f} instead of the comparison + select: x * 1 is exact and
 // acc + 0 leaves acc alone, so the result is that of dsim_range_sum_b (up to the sign of a zero) for one fused
 // multiply-add per entry instead of three instructions.  The weights are per-lane constants of the launch kept in
@@ -1011,6 +1029,50 @@ template <class Ctx, class Exec> DSIM_FN void dsim_scan_fk_lane(const Ctx& c, Ex
                   mk3(ex.shfl(v.v.x, src), ex.shfl(v.v.y, src), ex.shfl(v.v.z, src)));
     });
     if (on) stsv(WF(v) + 6 * i, v);
+    // ---- COM, world inertia about the origin (Theta = R Ic R^T, A = Theta + m(c.c 1 - c c^T), h = m c) and body force.
+    // Several wavefronts (DsimWideOverlap): the other wavefronts are the longer side between the hand-over points from here on
+    // (measured by leaving their blocks out: the muscle segments cost the launch 8 %, chunk sums + contacts 12 %, while this
+    // wavefront's work behind the LAST hand-over ran alone), so the pose-only part goes HERE, in front of `mid` -- the segments
+    // are still running -- and the body force behind the accelerations, in front of the next hand-over.  Same arithmetic.
+    constexpr bool EARLY = DsimWideOverlap<Ctx, Exec>::value;
+    v3 cm;
+    inertia10 I;
+    sv6 fg;
+    auto inertia = [&]() __attribute__((always_inline)) {
+        cm = rotate(r, com) + p;
+        v3 rx, ry, rz;
+        rotate_basis(r, rx, ry, rz);
+        const v3 b0 = rx * ic0 + ry * ic1 + rz * ic2;
+        const v3 b1 = rx * ic1 + ry * ic3 + rz * ic4;
+        const v3 b2 = rx * ic2 + ry * ic4 + rz * ic5;
+        I.m = m;
+        I.h = cm * m;
+        const float cc = dot(cm, cm);
+        I.axx = b0.x * rx.x + b1.x * ry.x + b2.x * rz.x + m * (cc - cm.x * cm.x);
+        I.axy = b0.x * rx.y + b1.x * ry.y + b2.x * rz.y - m * cm.x * cm.y;
+        I.axz = b0.x * rx.z + b1.x * ry.z + b2.x * rz.z - m * cm.x * cm.z;
+        I.ayy = b0.y * rx.y + b1.y * ry.y + b2.y * rz.y + m * (cc - cm.y * cm.y);
+        I.ayz = b0.y * rx.z + b1.y * ry.z + b2.y * rz.z - m * cm.y * cm.z;
+        I.azz = b0.z * rx.z + b1.z * ry.z + b2.z * rz.z + m * (cc - cm.z * cm.z);
+        const v3 mg = grav * m;
+        fg = mksv(cross(cm, mg), mg);
+        if (on) st_i10(WF(i10) + 10 * i, I);
+    };
+    auto body_force = [&](const sv6& a) __attribute__((always_inline)) {
+        const sv6 fb = inertia_mul(I, a) + scross_dual(v, inertia_mul(I, v));
+        if (on) {
+            stsv(WF(f) + 6 * i, fb - fg);
+            float* S = WF(S) + 6 * ds;
+            if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
+                stsv(S, s0);
+            } else if (type == DSIM_JOINT_BALL) {
+                stsv(S, s0);
+                stsv(S + 6, s1);
+                stsv(S + 12, s2);
+            }
+        }
+    };
+    if constexpr (EARLY) inertia();
     ex.stamp();
     ex.mid();   // X_sc and v of every link are final: the contacts may start
     // ---- bias accelerations: c_i = v_i x v_j,i (exactly zero at the root: a vector crossed with itself), prefix sums in a
@@ -1022,39 +1084,12 @@ template <class Ctx, class Exec> DSIM_FN void dsim_scan_fk_lane(const Ctx& c, Ex
                   mk3(ex.shfl(a.v.x, src), ex.shfl(a.v.y, src), ex.shfl(a.v.z, src)));
     });
     if (on) stsv(WF(a) + 6 * i, a);
+    if constexpr (EARLY) body_force(a);
     ex.stamp();
     ex.mid2();   // (several wavefronts: chunk sums and contact wrenches of the other wavefronts are complete, their per-body gather may start)
-    // ---- COM, world inertia about the origin (Theta = R Ic R^T, A = Theta + m(c.c 1 - c c^T), h = m c) and body force
-    const v3 cm = rotate(r, com) + p;
-    v3 rx, ry, rz;
-    rotate_basis(r, rx, ry, rz);
-    const v3 b0 = rx * ic0 + ry * ic1 + rz * ic2;
-    const v3 b1 = rx * ic1 + ry * ic3 + rz * ic4;
-    const v3 b2 = rx * ic2 + ry * ic4 + rz * ic5;
-    inertia10 I;
-    I.m = m;
-    I.h = cm * m;
-    const float cc = dot(cm, cm);
-    I.axx = b0.x * rx.x + b1.x * ry.x + b2.x * rz.x + m * (cc - cm.x * cm.x);
-    I.axy = b0.x * rx.y + b1.x * ry.y + b2.x * rz.y - m * cm.x * cm.y;
-    I.axz = b0.x * rx.z + b1.x * ry.z + b2.x * rz.z - m * cm.x * cm.z;
-    I.ayy = b0.y * rx.y + b1.y * ry.y + b2.y * rz.y + m * (cc - cm.y * cm.y);
-    I.ayz = b0.y * rx.z + b1.y * ry.z + b2.y * rz.z - m * cm.y * cm.z;
-    I.azz = b0.z * rx.z + b1.z * ry.z + b2.z * rz.z + m * (cc - cm.z * cm.z);
-    const sv6 fb = inertia_mul(I, a) + scross_dual(v, inertia_mul(I, v));
-    const v3 mg = grav * m;
-    const sv6 fg = mksv(cross(cm, mg), mg);
-    if (on) {
-        st_i10(WF(i10) + 10 * i, I);
-        stsv(WF(f) + 6 * i, fb - fg);
-        float* S = WF(S) + 6 * ds;
-        if (type == DSIM_JOINT_PRISMATIC || type == DSIM_JOINT_REVOLUTE) {
-            stsv(S, s0);
-        } else if (type == DSIM_JOINT_BALL) {
-            stsv(S, s0);
-            stsv(S + 6, s1);
-            stsv(S + 12, s2);
-        }
+    if constexpr (!EARLY) {
+        inertia();
+        body_force(a);
     }
 }
 
@@ -1080,7 +1115,9 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_scan(const Ctx
     });
 }
 
-template <class Ctx> DSIM_FN void dsim_muscle_chunk_sums(const Ctx& c, int lane, int nl);
+template <int G = DSIM_MUSCLE_CHUNK, class Ctx> DSIM_FN void dsim_muscle_chunk_sums(const Ctx& c, int lane, int nl);
+// where the activation cotangents of the segments start in `mus` (behind the chunks' rows)
+template <class Ctx> DSIM_FN int dsim_mus_act(const Ctx& c) { return 6 * c.d.MK * DSIM_MUSCLE_STRIDE; }
 // ground contacts and muscle segments of the environment on the NLR lanes `lane` of the wavefronts behind the first one, from the
 // published poses and twists (forward: wrenches; DsimWideOverlap).  Contacts are dealt from the top lane down, segments from
 // lane 0 up, so that a lane's second item is of the other kind where the lists allow it.
@@ -1101,12 +1138,19 @@ struct DsimSegIn {
     q4 r0, r1;
     float act;
 };
-template <class Ctx> DSIM_FN DsimSegIn dsim_seg_load(const Ctx& c, const DsimSegRec& g) {
-    DsimSegIn in;
-    in.p0 = ld3(WF(xsc) + g.x0); in.r0 = ldq(WF(xsc) + g.x0 + 3);
-    in.p1 = ld3(WF(xsc) + g.x1); in.r1 = ldq(WF(xsc) + g.x1 + 3);
+// (in two parts: what does not depend on the poses -- waypoints in link coordinates, the muscle's activation -- and the poses)
+template <class Ctx> DSIM_FN void dsim_seg_load_const(const Ctx& c, const DsimSegRec& g, DsimSegIn& in) {
     in.m0 = ld3(CF(mpoints) + g.wp); in.m1 = ld3(CF(mpoints) + g.wp + 3);
     in.act = WF(mact)[g.m];
+}
+template <class Ctx> DSIM_FN void dsim_seg_load_pose(const Ctx& c, const DsimSegRec& g, DsimSegIn& in) {
+    in.p0 = ld3(WF(xsc) + g.x0); in.r0 = ldq(WF(xsc) + g.x0 + 3);
+    in.p1 = ld3(WF(xsc) + g.x1); in.r1 = ldq(WF(xsc) + g.x1 + 3);
+}
+template <class Ctx> DSIM_FN DsimSegIn dsim_seg_load(const Ctx& c, const DsimSegRec& g) {
+    DsimSegIn in;
+    dsim_seg_load_pose(c, g, in);
+    dsim_seg_load_const(c, g, in);
     return in;
 }
 template <class Ctx> DSIM_FN void dsim_fwd_muscle_segment_eval(const Ctx& c, const DsimSegRec& g, const DsimSegIn& in) {
@@ -1162,20 +1206,55 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics_wide(const Ctx
         // 0.2374 ms; they stay a phase of all wavefronts)
     }, [&](int lane) {
         if (g_row) dsim_ckpt_store_row<Ctx, NLR, 1>(c, lane, g_row);   // head of the checkpoint row: (q, qd) entering the substep
-        ex.mid2();   // poses
-        dsim_fwd_muscle_segments(c, lane, NLR);
-        ex.mid();    // twists (and: every muscle row is written)
-        dsim_muscle_chunk_sums(c, lane, NLR);
-        for (int k = NLR - 1 - lane; k < c.d.C; k += NLR) {
-            const int b = CI(cbody)[k];
-            stsv(WF(cw) + 6 * k, dsim_contact_wrench(dsim_contact_load(c, k), ld3(WF(xsc) + 7 * b), ldq(WF(xsc) + 7 * b + 3), ldsv(WF(v) + 6 * b)));
+        // These wavefronts are the longer side between the hand-over points (measured by leaving blocks out: without the segments the
+        // forward launch is 8 % shorter, without chunk sums + contacts 12 %), and each of their blocks starts with index / constant
+        // loads that do not depend on what the hand-over publishes: they are requested in FRONT of it -- records, waypoints and
+        // activations of the lane's segments while the poses are still being composed, the contact's constants behind the
+        // segments, the body's bounds behind the contacts -- one dependent LDS round trip less per block.
+        constexpr bool PRE = D::NS <= 2 * NLR && D::C <= NLR && 6 * D::MK <= NLR && 6 * D::L <= NLR;
+        if constexpr (PRE) {
+            const int sa = lane < D::NS ? lane : 0, sb = lane + NLR < D::NS ? lane + NLR : sa;
+            const bool one = lane < D::NS, two = lane + NLR < D::NS;
+            const DsimSegRec ga = dsim_seg_rec(c, sa), gb = dsim_seg_rec(c, sb);
+            DsimSegIn ia, ib;
+            dsim_seg_load_const(c, ga, ia);
+            dsim_seg_load_const(c, gb, ib);
+            ex.mid2();   // poses
+            dsim_seg_load_pose(c, ga, ia);
+            dsim_seg_load_pose(c, gb, ib);
+            if (one) dsim_fwd_muscle_segment_eval(c, ga, ia);
+            if (two) dsim_fwd_muscle_segment_eval(c, gb, ib);
+            const int kc = NLR - 1 - lane, kcl = kc < D::C ? kc : 0;
+            const DsimContactConst cc = dsim_contact_load(c, kcl);
+            const int cb = CI(cbody)[kcl];
+            const int ce = lane / 6, ck = lane - 6 * ce;
+            ex.mid();    // twists (and: every muscle row is written)
+            if (ce < D::MK) WF(mpart)[lane] = dsim_range_sum_all<DSIM_MUSCLE_CHUNK>(WF(mus), 6, ck, ce * DSIM_MUSCLE_STRIDE);
+            if (kc < D::C) stsv(WF(cw) + 6 * kc, dsim_contact_wrench(cc, ld3(WF(xsc) + 7 * cb), ldq(WF(xsc) + 7 * cb + 3), ldsv(WF(v) + 6 * cb)));
+            const int gbd = ce < D::L ? ce : 0;   // (lane = 6 * body + component, as for the chunks)
+            const int m0 = CI(mb_start)[gbd], mn = CI(mb_start)[gbd + 1] - m0, c0 = CI(cb_start)[gbd], cn = CI(cb_start)[gbd + 1] - c0;
+            ex.mid2();   // chunk sums and contact wrenches of all three wavefronts
+            if (ce < D::L) {   // per body: its chunks' sums + its own contact wrenches
+                const float acc = dsim_range_sum_b<8>(WF(mpart), 6, ck, m0, mn, 0.f);
+                WF(cwb)[lane] = dsim_range_sum_b<dsim_cap_body_contacts<D>()>(WF(cw), 6, ck, c0, cn, acc);
+            }
+            ex.side_done_w();
+        } else {
+            ex.mid2();   // poses
+            dsim_fwd_muscle_segments(c, lane, NLR);
+            ex.mid();    // twists (and: every muscle row is written)
+            dsim_muscle_chunk_sums(c, lane, NLR);
+            for (int k = NLR - 1 - lane; k < c.d.C; k += NLR) {
+                const int b = CI(cbody)[k];
+                stsv(WF(cw) + 6 * k, dsim_contact_wrench(dsim_contact_load(c, k), ld3(WF(xsc) + 7 * b), ldq(WF(xsc) + 7 * b + 3), ldsv(WF(v) + 6 * b)));
+            }
+            ex.mid2();   // chunk sums and contact wrenches of all three wavefronts
+            for (int it = lane; it < 6 * c.d.L; it += NLR) {   // per body: its chunks' sums + its own contact wrenches
+                const int b = it / 6, k = it - 6 * b;
+                WF(cwb)[it] = dsim_body_contact_sum(c, b, WF(cw), 6, k, dsim_body_chunk_sum(c, b, k, 0.f));
+            }
+            ex.side_done_w();
         }
-        ex.mid2();   // chunk sums and contact wrenches of all three wavefronts
-        for (int it = lane; it < 6 * c.d.L; it += NLR) {   // per body: its chunks' sums + its own contact wrenches
-            const int b = it / 6, k = it - 6 * b;
-            WF(cwb)[it] = dsim_body_contact_sum(c, b, WF(cw), 6, k, dsim_body_chunk_sum(c, b, k, 0.f));
-        }
-        ex.side_done_w();
     });
 }
 
@@ -1399,11 +1478,12 @@ template <class Ctx, class Exec> DSIM_FN void dsim_fwd_kinematics(const Ctx& c, 
 }
 
 // mpart[e][k] = sum of component k over the muscle wrench rows of chunk e (forward: wrenches; adjoint: pose cotangents)
-template <class Ctx> DSIM_FN void dsim_muscle_chunk_sums(const Ctx& c, int lane, int nl) {
+// G: rows requested per round trip by the specialised kernels (the adjoint's several-wavefront kernel is at its register limit: two groups of 8)
+template <int G, class Ctx> DSIM_FN void dsim_muscle_chunk_sums(const Ctx& c, int lane, int nl) {
     for (int it = lane; it < 6 * c.d.MK; it += nl) {
         const int e = it / 6, k = it - 6 * e;
-        // (specialised kernels: all rows of the chunk in one round trip, rows past its end selected away)
-        if constexpr (DsimIsStatic<Ctx>::value) WF(mpart)[it] = dsim_range_sum_b<DSIM_MUSCLE_CHUNK>(WF(mus), 6, k, CI(mc_row)[e], CI(mc_cnt)[e], 0.f);
+        // (specialised kernels: all rows of the chunk in one round trip; the rows behind its last one are zeros)
+        if constexpr (DsimIsStatic<Ctx>::value) WF(mpart)[it] = dsim_range_sum_all<DSIM_MUSCLE_CHUNK, G>(WF(mus), 6, k, e * DSIM_MUSCLE_STRIDE);
         else WF(mpart)[it] = dsim_range_sum(WF(mus), 6, k, CI(mc_row)[e], CI(mc_cnt)[e], 0.f);
     }
 }
@@ -1416,8 +1496,8 @@ template <class Ctx> DSIM_FN float dsim_body_chunk_sum(const Ctx& c, int i, int 
 // cotangent of muscle activation m: sum over its active segments (consecutive words behind the wrench rows)
 template <class Ctx> DSIM_FN float dsim_muscle_act_sum(const Ctx& c, int m) {
     const int s0 = CI(ms_start)[m], n = CI(ms_start)[m + 1] - s0;
-    if constexpr (DsimIsStatic<Ctx>::value) return dsim_range_sum_b<4>(WF(mus) + 12 * c.d.NS, 1, 0, s0, n, 0.f);
-    else return dsim_range_sum(WF(mus) + 12 * c.d.NS, 1, 0, s0, n, 0.f);
+    if constexpr (DsimIsStatic<Ctx>::value) return dsim_range_sum_b<4>(WF(mus) + dsim_mus_act(c), 1, 0, s0, n, 0.f);
+    else return dsim_range_sum(WF(mus) + dsim_mus_act(c), 1, 0, s0, n, 0.f);
 }
 // ground contacts (sim.py:1137-1206) and muscle segments (sim.py:1209-1242): per-item wrenches
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_external(const Ctx& c, Exec& ex) {
@@ -2707,7 +2787,7 @@ template <int NLX, class Ctx, class Exec> DSIM_FN void dsim_bwd_external_items_n
         // the forward wrench rows are dead by now: same buffer, same body-sorted rows + one activation cotangent per segment
         stsv(WF(mus) + sg.r0, mksv(cross(pos0, a_p0), a_p0));
         stsv(WF(mus) + sg.r1, mksv(cross(pos1, a_p1), a_p1));
-        WF(mus)[12 * c.d.NS + s] = a_act;
+        WF(mus)[dsim_mus_act(c) + s] = a_act;
     }
 }
 template <class Ctx, class Exec> DSIM_FN void dsim_bwd_external_items(const Ctx& c, Exec& ex, int real_lane) {
@@ -3265,8 +3345,9 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
             a_v = zerosv();
             W = zerosv();
         }
-        if constexpr (WIDE) ex.mid();   // (the other wavefronts: per-item cotangents done, their chunk sums may start)
         // ---- aatot = subtree sum of aa; joint motion^T
+        // (several wavefronts: still in front of the first hand-over -- the other wavefronts' per-item block is the longer side there,
+        // measured by leaving it out: 11 % of the adjoint launch)
         dsim_rowtree_sum(c, ex, tp, A);
         sv6 vj = zerosv();
         if constexpr (HAS_FREE) {
@@ -3290,8 +3371,12 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
         // the other wavefronts
         // (several wavefronts: two hand-overs -- the contacts' twist cotangents per body need no muscle chunk sums and come first,
         // mid2; the pose wrenches per body, side_done_w, are picked up further down, in front of the last subtree sum)
-        if constexpr (WIDE) ex.mid2();
-        else ex.side_done();
+        if constexpr (WIDE) {
+            ex.mid();    // (the other wavefronts: per-item cotangents done, the contacts' twist cotangents are gathered per body ...
+            ex.mid2();   // ... and are there)
+        } else {
+            ex.side_done();
+        }
         sv6 cpose = zerosv();
         if constexpr (!WIDE) cpose = ldsv(WF(agx) + 12 * i);
         const sv6 ctw = ldsv(WF(agx) + 12 * i + 6);
@@ -3300,6 +3385,7 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
         sv6 T = a_v + ctw;
         dsim_rowtree_sum(c, ex, tp, T);
         a_vj += T;
+        if constexpr (WIDE) ex.mid2();   // (the other wavefronts: chunk sums of the muscle rows done -- beside the subtree sum above --, the per-body pose gather may start)
         sv6 Wp = zerosv();
         float aqd_new = g0, aqd_new1 = g1, aqd_new2 = g2;
         if (hinge) {
@@ -3371,11 +3457,14 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_bodies_rowtree(const Ctx&
         }, [&](int lane) {
             dsim_bwd_external_items_n<NLR>(c, ex, lane);
             ex.mid();
-            dsim_muscle_chunk_sums(c, lane, NLR);
             for (int it = lane; it < 6 * c.d.L; it += NLR) {   // per body: twist cotangents of its contacts (no muscle terms)
                 const int i = it / 6, r = 6 + it - 6 * i;
                 WF(agx)[12 * i + r] = dsim_body_contact_sum(c, i, WF(acx), 12, r, 0.f);
             }
+            ex.mid2();
+            // (the chunk sums are needed by the pose gather only: behind the hand-over of the twist cotangents, which the first
+            // wavefront waits for -- leaving them in front of it cost 6 % of the launch)
+            dsim_muscle_chunk_sums<8>(c, lane, NLR);
             ex.mid2();
             for (int it = lane; it < 6 * c.d.L; it += NLR) {   // per body: pose wrenches of its muscle rows (chunk sums) + its contacts
                 const int i = it / 6, r = it - 6 * i;

@@ -18,6 +18,7 @@
 #define DSIM_TRUNK_MAX 6
 #define DSIM_TRUNK_CH 4
 #define DSIM_LIGHT_CAP 8    // register budget of the light sums: LCAP, CCAP <= this
+#define DSIM_MUSCLE_STRIDE 17  // rows from one chunk to the next in `mus` (see seg_slot below)
 #define DSIM_MUSCLE_CHUNK 16   // rows per chunk of the per-body muscle-row gather (SNUHumanoid: 396 rows in 30 chunks -- 180 (chunk, component) items,
                                // one pass over the 192 lanes that sum them beside the first wavefront's link-level work)
 #define DSIM_TAIL_PAD 384
@@ -81,19 +82,16 @@ struct DsimOff {
     int scb_start, scb_list;    // contacts of all bodies in subtree(i) (ascending contact index)
     int rel;                    // [nd*nd] 0 unrelated, 1: link(b) in subtree(link(a)), 2: link(a) strictly below link(b)
     int cbody;
-    int seg_wp, seg_m;          // active muscle segment -> first waypoint index / muscle index
-    int ml_start, ml_list;      // link -> list of (segment*2 + side)
-    int seg_slot;               // [2*NS] (segment, side) -> position in ml_list: wrench rows are kept sorted by body
-    int ms_start;               // muscle -> [first, last) active segment
-    // The muscle wrench rows of a body (consecutive, seg_slot) are gathered in two steps: chunks of at most DSIM_MUSCLE_CHUNK
-    // rows are summed by one lane each (one LDS round trip), then the chunk sums of a body -- a body with 86 rows was 11
-    // dependent round trips of one lane.  mc_row / mc_cnt: first row and row count of chunk e; mb_start: body -> its chunks.
+    int ms_start;               // muscle -> [first, last) active segment (a segment is active if its two waypoints lie on different links)
+    // The muscle wrench rows of a body (one per segment end on it, kept together) are gathered in two steps: chunks of at most
+    // DSIM_MUSCLE_CHUNK rows are summed by one lane each (one LDS round trip), then the chunk sums of a body -- a body with 86 rows was
+    // 11 dependent round trips of one lane.  mc_row / mc_cnt: first row and row count of chunk e; mb_start: body -> its chunks.
     int mc_row, mc_cnt, mb_start;
     // packed per-segment record [NS][8] (16-byte aligned): 7 * link 0, 7 * link 1 (X_sc offsets), 3 * first waypoint (mpoints offset),
-    // muscle index, 6 * row of link 0, 6 * row of link 1 (offsets into `mus`), 0, 0 -- ONE LDS round trip (two 16-byte reads) for what
-    // seg_wp -> mlinks -> ... is three dependent ones
+    // muscle index, 6 * row of link 0, 6 * row of link 1 (offsets into `mus`), 0, 0 -- ONE LDS round trip (two 16-byte reads).  The
+    // tables it is built from (segment -> waypoint / muscle, waypoint -> link, link -> segment ends, segment end -> row) are not
+    // in the image any more: no kernel reads them, and they were 7 KB of SNUHumanoid's LDS image and of every launch's constant load.
     int seg_rec;
-    int mlinks;
     // ---- constant block: floats
     int xpj, com, axis, ic6, mass, tke, tkd, lke, lkd, target, lower, upper, arm;
     int cpoint, cdist, cmat, grav, mpoints;
@@ -361,28 +359,27 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.scb_list = put_i(scb_list.data(), scb_list.size());
     o.rel = put_i(rel.data(), rel.size());
     o.cbody = put_i(m.contact_body, C);
-    o.seg_wp = put_i(seg_wp.data(), NS);
-    o.seg_m = put_i(seg_m.data(), NS);
-    o.ml_start = put_i(ml_start.data(), L + 1);
-    o.ml_list = put_i(ml_list.data(), ml_list.size());
+    // Rows in `mus`: chunk e owns the DSIM_MUSCLE_CHUNK rows from row e * DSIM_MUSCLE_STRIDE on; a body's last chunk is filled up
+    // with rows that nothing ever writes (the work area starts out as zeros), so that a chunk sum is 16 unconditional additions,
+    // and the chunks lie 17 rows = 102 words apart: (chunk, component) lanes of a wavefront then read 64 different banks
+    // (16 rows = 96 words = 32 banks apart, every other chunk met the same ones).
     std::vector<int> seg_slot(2 * NS, 0);
-    for (size_t e = 0; e < ml_list.size(); ++e) seg_slot[ml_list[e]] = (int)e;
-    o.seg_slot = put_i(seg_slot.data(), seg_slot.size());
-    o.ms_start = put_i(ms_start.data(), M + 1);
     std::vector<int> mc_row, mc_cnt, mb_start(L + 1, 0);
     for (int i = 0; i < L; ++i) {
         mb_start[i] = (int)mc_row.size();
         for (int r = ml_start[i]; r < ml_start[i + 1]; r += DSIM_MUSCLE_CHUNK) {
-            mc_row.push_back(r);
-            mc_cnt.push_back(ml_start[i + 1] - r < DSIM_MUSCLE_CHUNK ? ml_start[i + 1] - r : DSIM_MUSCLE_CHUNK);
+            const int e = (int)mc_row.size(), n = ml_start[i + 1] - r < DSIM_MUSCLE_CHUNK ? ml_start[i + 1] - r : DSIM_MUSCLE_CHUNK;
+            mc_row.push_back(e * DSIM_MUSCLE_STRIDE);
+            mc_cnt.push_back(n);
+            for (int j = 0; j < n; ++j) seg_slot[ml_list[r + j]] = e * DSIM_MUSCLE_STRIDE + j;
         }
     }
     mb_start[L] = (int)mc_row.size();
     const int MK = (int)mc_row.size();
+    o.ms_start = put_i(ms_start.data(), M + 1);
     o.mc_row = put_i(mc_row.data(), MK);
     o.mc_cnt = put_i(mc_cnt.data(), MK);
     o.mb_start = put_i(mb_start.data(), L + 1);
-    o.mlinks = put_i(m.muscle_links, W);
     {
         while (blob.size() % 4) blob.push_back(0);
         std::vector<int> rec(8 * (size_t)NS, 0);
@@ -445,7 +442,7 @@ inline std::string dsim_build_layout(const dsim_model_desc& m, DsimLayout& out) 
     o.ua = take(M > nd ? M : nd); o.obs = take(16 + nq + nd + (M > nd ? M : nd));
     o.f = take(6 * L); o.cw = take(6 * C); o.cwb = take(6 * L); o.tau = take(nd);
     o.ic10 = take(10 * L); o.F = take(6 * nd); o.hinv = take(nd * nd); o.prow = take(nd); o.pcol = take(nd);
-    o.mus = take(13 * NS);  // 2 NS wrench rows of 6 floats, sorted by body (seg_slot), + (adjoint) NS activation cotangents
+    o.mus = take(6 * MK * DSIM_MUSCLE_STRIDE + NS);  // the chunks' wrench rows of 6 floats (2 NS of them written, sorted by body: seg_slot), + (adjoint) NS activation cotangents
     o.mpart = take(6 * MK);
     o.epf = take(4);
     o.fwd_words = cur;

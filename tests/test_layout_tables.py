@@ -195,7 +195,8 @@ def _chain(parents, j):
 
 def test_muscle_chunk_tables_cover_the_body_rows():
     """mc_row / mc_cnt / mb_start (dsim_layout.hpp): the chunks of a body tile its muscle wrench rows, at most DSIM_MUSCLE_CHUNK = 16
-    rows each; seg_rec: the packed per-segment records agree with the tables they replace on the item phases"""
+    rows each, in the padded row numbering of `mus`; seg_rec: the packed per-segment records against the tables they are built from,
+    recomputed here from the template (they are not in the image: no kernel reads them)"""
     from emu_lib import layout
     from oracle_lib import template_from_golden
     t = template_from_golden("snu")
@@ -203,21 +204,38 @@ def test_muscle_chunk_tables_cover_the_body_rows():
     img, off2, _ = substep_image(t, t.joint_q0[None], np.zeros((1, t.n_qd), np.float32), np.zeros((1, t.n_qd), np.float32),
                                  np.zeros((1, t.n_muscles), np.float32), 1.0 / 2880.0)
     I = img.view(np.int32)
-    L, K = t.n_links, d["MK"]
+    L, K, NS = t.n_links, d["MK"], d["NS"]
     assert K > 0
-    ml = I[off2["ml_start"]:off2["ml_start"] + L + 1].tolist()
+    for gone in ("seg_wp", "seg_m", "ml_start", "ml_list", "seg_slot", "mlinks"):
+        assert gone not in off2
+    # active segments (two consecutive waypoints of a muscle on different links), in muscle order; per link the list of its segment ends
+    links, ms = np.asarray(t.muscle_links), np.asarray(t.muscle_start)
+    wp = np.array([w for m in range(t.n_muscles) for w in range(ms[m], ms[m + 1] - 1) if links[w] != links[w + 1]])
+    sm = np.array([m for m in range(t.n_muscles) for w in range(ms[m], ms[m + 1] - 1) if links[w] != links[w + 1]])
+    assert len(wp) == NS
+    np.testing.assert_array_equal(I[off2["ms_start"]:off2["ms_start"] + t.n_muscles + 1],
+                                  np.searchsorted(sm, np.arange(t.n_muscles + 1)))
+    ends = [[] for _ in range(L)]   # link -> [2 * segment + side], by segment
+    for s_, w in enumerate(wp):
+        ends[links[w]].append(2 * s_)
+        ends[links[w + 1]].append(2 * s_ + 1)
     mb = I[off2["mb_start"]:off2["mb_start"] + L + 1].tolist()
     row, cnt = I[off2["mc_row"]:off2["mc_row"] + K].tolist(), I[off2["mc_cnt"]:off2["mc_cnt"] + K].tolist()
     assert mb[0] == 0 and mb[L] == K
+    # chunk e owns the 16 rows from row 17 e on (DSIM_MUSCLE_STRIDE: 102 words, so that the (chunk, component) lanes of a wavefront
+    # read different banks); the first cnt[e] of them are the rows of the body's segment ends, in the order of the body's list, the
+    # rest are never written (zeros: a chunk sum is 16 unconditional additions)
+    assert row == [17 * e for e in range(K)]
+    slot = np.full(2 * NS, -1)
     for i in range(L):
         rows = [r for e in range(mb[i], mb[i + 1]) for r in range(row[e], row[e] + cnt[e])]
-        assert rows == list(range(ml[i], ml[i + 1]))
+        assert len(rows) == len(ends[i]), "body %d" % i
+        slot[ends[i]] = rows
         assert all(0 < cnt[e] <= 16 for e in range(mb[i], mb[i + 1]))
+        assert all(cnt[e] == 16 for e in range(mb[i], mb[i + 1] - 1)), "only a body's last chunk is filled up"
+    assert (slot >= 0).all() and len(set(slot.tolist())) == 2 * NS
+    assert off2["mpart"] - off2["mus"] >= 6 * 17 * K + NS, "rows of all chunks + the activation cotangents behind them"
     assert 6 * K <= 192, "one pass of the (chunk, component) items over the three wavefronts behind the first one"
-    NS = d["NS"]
-    wp, sm = I[off2["seg_wp"]:off2["seg_wp"] + NS], I[off2["seg_m"]:off2["seg_m"] + NS]
-    slot = I[off2["seg_slot"]:off2["seg_slot"] + 2 * NS]
-    links = I[off2["mlinks"]:off2["mlinks"] + d["W"]]
     rec = I[off2["seg_rec"]:off2["seg_rec"] + 8 * NS].reshape(NS, 8)
     assert off2["seg_rec"] % 4 == 0
     np.testing.assert_array_equal(rec[:, 0], 7 * links[wp])
