@@ -9,4 +9,5 @@ DSIM_LIB=$PWD/tools/libdsim_snu_stamps.so python tools/stamps.py snu 512 > gpuru
 DSIM_HELPER=1 DSIM_LIB=$PWD/tools/libdsim_ant_stamps.so python tools/stamps.py ant 1024 > gpurun_out/r05_stamps_ant.txt 2>&1
 DSIM_HELPER=1 DSIM_LIB=$PWD/tools/libdsim_hum_stamps.so python tools/stamps.py humanoid 1024 > gpurun_out/r05_stamps_humanoid.txt 2>&1
 cat gpurun_out/r05_ablation_snu.txt
+{ echo "# python tools/snu_refresh_probe.py, MI355X, shipped kernels, minimum of 3 x 20 launches"; python tools/snu_refresh_probe.py 2>&1 | grep -v amdgpu.ids; } > gpurun_out/r05_snu_refresh_probe.txt
 bash tools/gpu_profiles.sh r05f ant humanoid snu ant8192 antmm1
