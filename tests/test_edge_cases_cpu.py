@@ -225,6 +225,36 @@ def test_random_trees_with_muscles(seed, floating):
     assert np.abs(o["gmact"]).max() > 0 and all(err[k] < tol[k] for k in err), (err, tol)
 
 
+def test_random_tree_with_many_muscles_fills_several_chunks_per_body():
+    """40 muscles over 6-9 links: bodies with more than DSIM_MUSCLE_CHUNK = 16 segment ends, i.e. several chunks of muscle rows per
+    body, the last one of each filled up with rows nothing writes (dsim_layout.hpp: seg_slot / mc_row) -- the run-time-layout kernels
+    sum the rows by their counts, so a wrong row number or a fill row that is not zero shows up against the scalar oracle"""
+    t, parents = _random_tree(7, True, muscles=40)
+    off, dims = layout(t)
+    from emu_lib import substep_image
+    img, off2, _ = substep_image(t, t.joint_q0[None], np.zeros((1, t.n_qd), np.float32), np.zeros((1, t.n_qd), np.float32),
+                                 np.zeros((1, t.n_muscles), np.float32), 1.0 / 960.0)
+    I = img.view(np.int32)
+    mb = I[off2["mb_start"]:off2["mb_start"] + t.n_links + 1]
+    cnt = I[off2["mc_cnt"]:off2["mc_cnt"] + dims["MK"]]
+    assert np.diff(mb).max() >= 2 and cnt.min() < 16 and cnt.max() == 16, "several chunks on one body, and chunks that are filled up"
+    assert cnt.sum() == 2 * dims["NS"]
+    rng = np.random.default_rng(207)
+    q, qd, act = _tree_states(t, rng, 2)
+    mact = rng.uniform(0.0, 10.0, (2, t.n_muscles)).astype(np.float32)
+    gq, gqd = rng.normal(0, 1, q.shape).astype(np.float32), rng.normal(0, 1, qd.shape).astype(np.float32)
+    S, mm = 2, 2
+    dt = S / 960.0
+    o = oracle_backward(t, q, qd, act, mact, dt, S, mm, gq, gqd)
+    qo, qdo, ck = emu_forward(t, q, qd, act, mact, dt, S, mm, want_ckpt=True)
+    r = emu_backward(t, ck, act, mact, dt, S, mm, gq, gqd)
+    assert relerr(qo, o["q_out"]) < 5e-5 and relerr(qdo, o["qd_out"]) < 5e-4
+    err = dict(gq=relerr(project_tangent(t, q, r["gq"]), project_tangent(t, q, o["gq"])), gqd=relerr(r["gqd"], o["gqd"]),
+               gact=relerr(r["gact"], o["gact"]), gmact=relerr(r["gmact"], o["gmact"]))
+    tol = step_grad_tolerance(t, q, qd, act, mact, dt, S, mm, gq, gqd, err, ref=o)   # 1e-3, or probed
+    assert np.abs(o["gmact"]).max() > 0 and all(err[k] < tol[k] for k in err), (err, tol)
+
+
 def test_half_angle_polynomials_at_and_beyond_their_range():
     """dsim_math.hpp::half_angle_sincos replaces sinf / cosf of a joint half-angle by degree-11 / 12 polynomials for
     |angle / 2| <= pi / 2 and falls back to the library routines beyond.  Isolated here: a revolute chain whose joint angles sit

@@ -66,16 +66,17 @@ def test_generic_kernels_on_random_trees(seed, floating):
         assert all(err[k] < tol[k] for k in err), (err, tol)
 
 
-@pytest.mark.parametrize("seed,floating", [(5, True), (6, False)])
-def test_generic_kernels_on_random_trees_with_muscles(seed, floating):
+# (7, True, 40): bodies with several chunks of muscle rows, the last one of each filled up with rows nothing writes (dsim_layout.hpp)
+@pytest.mark.parametrize("seed,floating,muscles", [(5, True, 4), (6, False, 4), (7, True, 40)])
+def test_generic_kernels_on_random_trees_with_muscles(seed, floating, muscles):
     from diffrl_amd.engine import Engine
-    t, parents = _random_tree(seed, floating, muscles=4)
+    t, parents = _random_tree(seed, floating, muscles=muscles)
     eng = Engine(t, DEV)
     dev = torch.device(DEV)
     rng = np.random.default_rng(200 + seed)
     n = 9
     q, qd, act = _tree_states(t, rng, n)
-    mact = rng.uniform(0.0, 30.0, (n, t.n_muscles)).astype(np.float32)
+    mact = rng.uniform(0.0, 30.0 if muscles <= 4 else 10.0, (n, t.n_muscles)).astype(np.float32)
     gq, gqd = rng.normal(0, 1, q.shape).astype(np.float32), rng.normal(0, 1, qd.shape).astype(np.float32)
     S, mm = 4, 2
     dt = S / 960.0
