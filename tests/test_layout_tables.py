@@ -244,3 +244,16 @@ def test_muscle_chunk_tables_cover_the_body_rows():
     np.testing.assert_array_equal(rec[:, 3], sm)
     np.testing.assert_array_equal(rec[:, 4], 6 * slot[0::2])
     np.testing.assert_array_equal(rec[:, 5], 6 * slot[1::2])
+
+
+def test_every_array_of_the_shipped_models_is_within_the_lds_offset_field():
+    """An LDS instruction addresses base register + 16-bit byte offset.  The specialised kernels know every array's offset at compile
+    time; an array that starts beyond 64 KiB needs its address in a register of its own (round 5: SNUHumanoid's aH / gua / agx did --
+    the adjoint kernel sat at 256 VGPRs with two spilled once the image grew by another 700 words; without 1,836 words of tables that
+    no kernel read everything is below the limit again and the launch is 2 % shorter)"""
+    from diffrl_amd import specialise
+    for tag, t in specialise.shipped_templates():
+        off, dims = specialise.layout(t)
+        last = max(v for k, v in off.items() if k not in ("total_words", "fwd_words", "save_words", "const_words") and v >= 0)
+        assert 4 * last < 65536, (tag, last)
+        assert 4 * off["total_words"] <= 65536 + 4 * 384, (tag, off["total_words"])   # (the spare tail behind the last array may cross it)
