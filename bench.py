@@ -209,24 +209,19 @@ def roofline_record(env, name, n, H, mm, device, reps, counters=True):
     traffic = 4 * n * ckpt_floats + bwd_bytes
     traffic_src = "analytic: checkpoint words x N x 4 + boundary tensors (no counter file for these kernel sources)"
     pmc = pmc_record(name, n, mm) if counters else None   # (the committed counter files describe the SPECIALISED kernels)
+    t_dom = t_fwd if fwd_dominant else t_bwd
     r = {"bound": "valu-issue", "kernel": "dsim_env_fwd_kernel" if fwd_dominant else "dsim_env_bwd_kernel",
          "dominant_launch": "forward" if fwd_dominant else "adjoint", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": achieved / HBM_PEAK_GBS, "alg_bytes_per_launch": fwd_bytes if fwd_dominant else bwd_bytes, "kernel_ms": t_bwd * 1e3,
-         "fwd_kernel_ms": t_fwd * 1e3, "fwd_alg_bytes_per_launch": fwd_bytes, "bwd_alg_bytes_per_launch": bwd_bytes,
+         "frac": achieved / HBM_PEAK_GBS, "alg_bytes_per_launch": fwd_bytes if fwd_dominant else bwd_bytes,
+         # kernel_ms: the launch `kernel` names (the pair achieved / kernel_ms / traffic always describes ONE kernel);
+         # both launches' own times are first-class next to it
+         "kernel_ms": t_dom * 1e3, "fwd_kernel_ms": t_fwd * 1e3, "bwd_kernel_ms": t_bwd * 1e3,
+         "fwd_alg_bytes_per_launch": fwd_bytes, "bwd_alg_bytes_per_launch": bwd_bytes,
          "fwd_alg_frac": fwd_bytes / t_fwd / (HBM_PEAK_GBS * 1e9), "bwd_alg_frac": bwd_bytes / t_bwd / (HBM_PEAK_GBS * 1e9),
          "csrc_hash": csrc_hash(),
          "ckpt_bytes_per_env_step": 4 * ckpt_floats, "ckpt_bytes_per_rollout": 4 * ckpt_floats * n * H,
          "valu_issue_frac": None, "fwd_valu_issue_frac": None, "valu_simd_frac": None, "fwd_valu_simd_frac": None,
-         "stall_frac": None, "fwd_stall_frac": None, "valu_insts_per_env_step": None,
-         "note": "achieved / frac: ALGORITHMIC bytes of the dominant launch (`kernel`: the longer of the env-step's two) against the HBM peak, as BASELINE.json asks; alg_frac_step: the whole env-step's 748 B (Ant) x the measured env-steps/s against 8 TB/s -- not what "
-                 "binds these kernels (~1,900 flop per algorithmic byte, SURVEY 8d).  bound: the instruction stream of the ONE "
-                 "wavefront an environment's phases run on.  valu_simd_frac = VALU instructions per occupied SIMD x 2 cycles "
-                 "/ kernel cycles: the fraction of the SIMD-32's VALU rate, i.e. of the machine; valu_issue_frac = busy fraction "
-                 "of the issue slots a LONE wave can use (1.0 = an instruction every 4 cycles = half the SIMD's rate); stall_frac "
-                 "= 1 - (the environment's instructions x the 4.3-cycle lone-wave cadence) / kernel cycles, a lower bound of the "
-                 "share of the kernel spent waiting (LDS / cross-lane round trips, barriers, sqrt / div); hbm_measured_frac = "
-                 "counter traffic / kernel time / 8 TB/s (the traffic is the saved forward block the adjoint reads back instead "
-                 "of recomputing, DESIGN.md section 4)"}
+         "stall_frac": None, "fwd_stall_frac": None, "valu_insts_per_env_step": None}
     if pmc:
         traffic, traffic_src = pmc["traffic_bytes_per_launch"], "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), " + pmc["file"]
         r["counters"] = pmc["file"]
@@ -264,15 +259,19 @@ def roofline_record(env, name, n, H, mm, device, reps, counters=True):
                     r["flop_per_env_step"] = (ops_b * fb + ops_f * ff) / n
                 else:
                     r["fp32_valu_frac_est"] = None
-        wf = (pmc.get("forward_kernel") or {}).get("traffic_bytes_per_launch")
-        if wf:
-            r["fwd_hbm_measured_frac"] = wf / t_fwd / (HBM_PEAK_GBS * 1e9)
-    r["traffic"], r["traffic_source"] = traffic, traffic_src
-    r["hbm_measured_frac"] = traffic / t_bwd / (HBM_PEAK_GBS * 1e9)
-    if fwd_dominant and pmc and (pmc.get("forward_kernel") or {}).get("traffic_bytes_per_launch"):
-        # (`traffic` describes the dominant launch, like `achieved`; the adjoint's figure stays in bwd_traffic)
-        r["bwd_traffic"] = traffic
-        r["traffic"] = pmc["forward_kernel"]["traffic_bytes_per_launch"]
+    # measured HBM traffic per launch, each kernel against ITS OWN duration; `traffic` / `hbm_measured_frac` are the dominant
+    # launch's pair (like `achieved`), the other kernel's stay in bwd_* / fwd_*
+    wf = (pmc.get("forward_kernel") or {}).get("traffic_bytes_per_launch") if pmc else None
+    r["bwd_traffic"], r["fwd_traffic"], r["traffic_source"] = traffic, wf, traffic_src
+    r["bwd_hbm_measured_frac"] = traffic / t_bwd / (HBM_PEAK_GBS * 1e9)
+    r["fwd_hbm_measured_frac"] = wf / t_fwd / (HBM_PEAK_GBS * 1e9) if wf else None
+    if fwd_dominant:
+        # (no counter file: the forward writes the checkpoint block the adjoint reads back -- the analytic figure minus the
+        # gradient tensors)
+        r["traffic"] = wf if wf else 4 * n * ckpt_floats + fwd_bytes
+        r["hbm_measured_frac"] = r["traffic"] / t_fwd / (HBM_PEAK_GBS * 1e9)
+    else:
+        r["traffic"], r["hbm_measured_frac"] = traffic, r["bwd_hbm_measured_frac"]
     return r
 
 
@@ -312,7 +311,8 @@ def measure_other_config(name, n, H, mm, device, steps=10, generic=False):
         rf["alg_frac_step"] = ALG_BYTES[name] * (steps * n * H / el) / (HBM_PEAK_GBS * 1e9)
         return {"workload": "%s %d envs x H=%d, MM_caching_frequency %d" % (name, n, H, mm), "value": steps * n * H / el,
                 "unit": "env-steps/s", "steps": steps, "ms_per_rollout": el / steps * 1e3, "kernel_ms": rf["kernel_ms"],
-                "fwd_kernel_ms": rf["fwd_kernel_ms"], "ckpt_bytes_per_env_step": rf["ckpt_bytes_per_env_step"],
+                "fwd_kernel_ms": rf["fwd_kernel_ms"], "bwd_kernel_ms": rf["bwd_kernel_ms"],
+                "ckpt_bytes_per_env_step": rf["ckpt_bytes_per_env_step"],
                 "kernels": "generic (run-time layout)" if generic else "specialised (compile-time layout)", "roofline": rf}
     except Exception as ex:
         return {"workload": "%s %d envs x H=%d" % (name, n, H), "value": None, "error": str(ex)[:200]}
@@ -344,6 +344,90 @@ def csrc_hash():
         if f.endswith((".hip", ".hpp")):
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:12]
+
+
+MAX_LINE_BYTES = 4096   # the driver reads the LAST stdout line out of a bounded tail: round 5's 21 KB line was not parsed
+
+
+def _sig(x, digits=5):
+    """floats to `digits` significant digits (the printed line only; the full record keeps every bit)"""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "fwd_kernel_ms", "bwd_kernel_ms",
+                 "fwd_alg_frac", "bwd_alg_frac", "alg_frac_step", "alg_bytes_per_launch", "hbm_measured_frac",
+                 "fwd_hbm_measured_frac", "bwd_hbm_measured_frac", "valu_simd_frac", "fwd_valu_simd_frac", "fp32_valu_frac_est",
+                 "counters", "csrc_hash")
+
+
+def compact_line(full, side_file=None):
+    """the ONE line bench.py prints: the contract's keys, a numeric-only roofline, the CPU baseline's figures and one short
+    object per other configuration -- under MAX_LINE_BYTES whatever the number of ranks.  Everything else (per-kernel counter
+    views, samples, sources, per-config roofline objects) is in the full record (`side_file`)."""
+    keep = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "backend", "oversubscribed", "steps", "warmup", "ms_per_step",
+            "ms_per_step_min", "ms_per_step_median", "ms_per_step_max", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "eager_env_steps_per_s", "no_grad_forward_env_steps_per_s", "dry_run", "envs_total", "slowest_rank_s")
+    out = {k: full[k] for k in keep if k in full}
+    cfg = dict(full.get("config") or {})
+    if "submission" in cfg:
+        cfg["submission"] = "eager" if cfg["submission"].startswith("eager") else "hip-graph"
+    out["config"] = cfg
+    if full.get("per_rank"):
+        out["per_rank"] = [{k: r[k] for k in ("rank", "value", "ms_per_step", "ms_per_step_median", "ms_per_step_max", "elapsed_s",
+                                              "envs", "device") if k in r} for r in full["per_rank"]]
+    rf = full.get("roofline")
+    if rf:
+        out["roofline"] = {k: rf.get(k) for k in ROOFLINE_KEYS}
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "sample": (cb.get("sample") or "")[:120],
+                               "single_thread": (cb.get("single_thread") or {}).get("value"),
+                               "reference_recorded": (cb.get("reference_recorded") or {}).get("value"),
+                               "reference_unavailable": cb.get("reference_unavailable")}
+    if full.get("other_configs"):
+        oc = []
+        for o in full["other_configs"]:
+            r = o.get("roofline") or {}
+            c = {"workload": o["workload"].replace(", MM_caching_frequency ", " mm") + (" generic" if str(o.get("kernels", "")).startswith("generic") else ""),
+                 "value": o.get("value"), "fwd_ms": o.get("fwd_kernel_ms"), "bwd_ms": o.get("bwd_kernel_ms"),
+                 "frac": r.get("frac"), "alg_frac_step": r.get("alg_frac_step"), "hbm_measured_frac": r.get("hbm_measured_frac")}
+            if o.get("error"):
+                c["error"] = o["error"][:80]
+            oc.append(c)
+        out["other_configs"] = oc
+    if full.get("note"):
+        out["note"] = full["note"][:200]
+    if side_file:
+        out["full_record"] = side_file
+    line = json.dumps(_sig(out), separators=(",", ":"))
+    if len(line) >= MAX_LINE_BYTES:   # (cannot happen with <= 8 ranks; keep the contract's keys whatever grows)
+        for k in ("per_rank", "other_configs", "note"):
+            out.pop(k, None)
+        line = json.dumps(_sig(out), separators=(",", ":"))
+    assert len(line) < MAX_LINE_BYTES, len(line)
+    return line
+
+
+def emit(full):
+    """writes the full record next to bench.py (bench_full.json; gpurun_out/ too when it exists) and prints the compact line"""
+    side = None
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_full.json"), "w") as f:
+                    json.dump(full, f, indent=1)
+                side = side or os.path.relpath(os.path.join(d, "bench_full.json"), ROOT)
+            except OSError:
+                pass
+    sys.stdout.flush()
+    print(compact_line(full, side), flush=True)
 
 
 def parse_args(argv=None):
@@ -460,7 +544,7 @@ def main(argv=None):
         per_rank = sharding.gather_over_ranks([rank, el_rank, hi - lo], red_dev)
         names = sharding.gather_strings(torch.cuda.get_device_name(device) if use_gpu else "cpu")
         if rank == 0:
-            print(json.dumps({"metric": "fwd+adjoint env-steps/sec", "dry_run": True, "value": None, "unit": "env-steps/s",
+            print(compact_line({"metric": "fwd+adjoint env-steps/sec", "dry_run": True, "value": None, "unit": "env-steps/s",
                               "per_rank": [{"rank": int(r[0]), "elapsed_s": r[1], "envs": int(r[2]), "device": names[i]}
                                            for i, r in enumerate(per_rank)],
                               "n_gpus": a.gpus, "rccl_ranks": rccl_ranks, "backend": "nccl" if (use_gpu and not over) else "gloo",
@@ -621,7 +705,7 @@ def main(argv=None):
                                     measure_other_config("ant", n, H, MM_FREQ["ant"], device, generic=True)]
         if not a.no_cpu_baseline and world == 1:   # reported at N = 1 only (the host cores are the same for every N)
             out["cpu_baseline"] = cpu_baseline(a.env)
-        print(json.dumps(out))
+        emit(out)
     if dist:
         td.barrier()   # rank 0 is still measuring its extras (eager loop, CPU baseline): tear the group down together
         td.destroy_process_group()

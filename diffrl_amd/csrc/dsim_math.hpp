@@ -95,6 +95,10 @@ DSIM_FN q4 rotate_adj_q(q4 q, v3 x, v3 r) {
 // quat.h:70-83).  Device code: v_rsq_f32 + one Newton step -- as accurate as the reference's two correctly rounded operations
 // (square root, division) together (< 1 ulp), ~6 instead of ~30 dependent instructions on the one lane that integrates the free
 // root; not the same bits (-DDSIM_EXACT_DIV_SQRT builds the A/B variant; the host harness of tests/emu always takes that path).
+// v_rsq_f32 flushes a denormal input to zero: rsq = +inf, and the correction steps then make inf - inf = NaN.  A squared length
+// below the smallest normal (a tangential contact velocity of ~1e-19, a quaternion of that norm) is treated as zero length,
+// like the exactly-zero case: the force / rotation it would scale is below 1e-15 of anything else in the step.
+#define DSIM_MIN_NORMAL 1.17549435e-38f
 DSIM_FN float dsim_inv_len_exact(float n2) {
     const float l = sqrtf(n2);
     return l > 0.0f ? 1.0f / l : 0.0f;
@@ -103,7 +107,7 @@ DSIM_FN float dsim_inv_len_fast(float n2) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const float y = __builtin_amdgcn_rsqf(n2);
     const float r = y * __builtin_fmaf(-0.5f * n2 * y, y, 1.5f);
-    return n2 > 0.0f ? r : 0.0f;
+    return n2 >= DSIM_MIN_NORMAL ? r : 0.0f;
 #else
     return dsim_inv_len_exact(n2);
 #endif
@@ -119,7 +123,7 @@ DSIM_FN float dsim_inv_len_two_step(float n2) {
     l = __builtin_fmaf(__builtin_fmaf(-l, l, n2), 0.5f * y, l);
     float c = __builtin_amdgcn_rcpf(l);
     c = __builtin_fmaf(__builtin_fmaf(-l, c, 1.0f), c, c);
-    return n2 > 0.0f ? c : 0.0f;
+    return n2 >= DSIM_MIN_NORMAL ? c : 0.0f;
 #else
     return dsim_inv_len_exact(n2);
 #endif

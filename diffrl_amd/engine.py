@@ -21,10 +21,13 @@ class Engine:
     def __init__(self, template: ArticulationTemplate, device, ckpt_mode=None, specialise=None):
         """ckpt_mode: "full" (default; $DIFFRL_AMD_CKPT overrides) -- the forward launch streams every intermediate the
         adjoint reads to HBM -- or "lean" -- (q, qd) per substep only, the adjoint recomputes (include/dsim.h).
-        specialise: True -- a model that matches none of the compiled layout tables (it would run the generic kernels, about
-        half the speed) gets a kernel set of its own, compiled with hipcc on first use and cached next to the library
-        (diffrl_amd.specialise.ensure_library: about a minute, once per model and source version); None: $DSIM_AUTO_SPECIALISE
-        (default off: nothing is compiled at run time unless asked for)."""
+        specialise: what a model that matches none of the compiled layout tables gets (it would run the generic kernels, about
+        half the speed).  True / $DSIM_AUTO_SPECIALISE=1: a kernel set of its own, compiled with hipcc on first use and cached
+        next to the library (diffrl_amd.specialise.ensure_library: about a minute, once per model and source version; the
+        constructor waits for it).  "background" (the default when None and $DSIM_AUTO_SPECIALISE is unset or "background"): the
+        cached set if there is one; otherwise this Engine runs the generic kernels while a daemon thread compiles the set, and
+        the next Engine of the model picks it up.  False / $DSIM_AUTO_SPECIALISE=0: nothing is compiled or swapped at run time.
+        A failed build, a missing hipcc or a library that turns out not to hold the set: a warning, the generic kernels stay."""
         self.template = template
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -35,17 +38,38 @@ class Engine:
         self._desc, self._keep = capi.make_desc(template)
         import os
         if specialise is None:
-            specialise = os.environ.get("DSIM_AUTO_SPECIALISE", "0") not in ("", "0")
+            v = os.environ.get("DSIM_AUTO_SPECIALISE", "background").lower()
+            specialise = False if v in ("", "0", "off") else ("background" if v in ("background", "bg") else True)
         h = self._create()
-        if specialise and int(self._lib.dsim_model_variant(h)) == 0:
+        if specialise and int(self._lib.dsim_model_variant(h)) == 0 and os.environ.get("DSIM_FORCE_GENERIC", "0") in ("", "0"):
+            import warnings
             from . import specialise as sp
-            path = sp.ensure_library(template)   # None: hipcc missing or the build failed (warned about); the generic kernels stay
-            if path is not None:
-                self._lib.dsim_model_destroy(h)
-                self._lib = capi.load(path)
-                h = self._create()
-                if int(self._lib.dsim_model_variant(h)) == 0:
-                    raise capi.DsimError("%s was built for this model but dsim_model_create does not match it" % path)
+            if specialise == "background":
+                path, _ = sp.ensure_library_background(template)   # None: compiling now (or no hipcc): generic kernels this time
+            else:
+                path = sp.ensure_library(template)   # None: hipcc missing or the build failed (warned about); the generic kernels stay
+            # (the library already loaded reports variant 0 for this model: a path equal to it cannot help -- e.g. a product library
+            # built with a DSIM_STATIC_VARIANTS subset, or a header regenerated without rebuilding)
+            if path is not None and os.path.realpath(path) != os.path.realpath(getattr(self._lib, "_name", "") or ""):
+                lib2 = capi.load(path)
+                keep_lib, self._lib = self._lib, lib2
+                try:
+                    h2 = self._create()
+                except capi.DsimError as ex:
+                    h2, self._lib = None, keep_lib
+                    warnings.warn("diffrl_amd: %s could not create this model (%s); it keeps the generic kernels" % (path, ex))
+                if h2 is not None:
+                    if int(lib2.dsim_model_variant(h2)) > 0:
+                        keep_lib.dsim_model_destroy(h)
+                        h = h2
+                    else:   # keep the working generic handle, release the extra one
+                        lib2.dsim_model_destroy(h2)
+                        self._lib = keep_lib
+                        warnings.warn("diffrl_amd: %s was built for this model but does not match it; it keeps the generic kernels"
+                                      % path)
+            elif path is not None:
+                warnings.warn("diffrl_amd: the loaded library %s lists a kernel set for this model but was built without it; "
+                              "it keeps the generic kernels" % path)
         self._h = h
         self.ckpt_mode = (ckpt_mode or os.environ.get("DIFFRL_AMD_CKPT", "full")).lower()
         if self.ckpt_mode not in ("full", "lean"):

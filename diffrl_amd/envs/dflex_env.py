@@ -120,10 +120,12 @@ class DFlexEnv:
     def _spec(self):
         if getattr(self, "_spec_cache", None) is None:
             self._spec_cache = self.fused_spec()
-            if self._spec_cache is not None:
-                # the reference's nan_to_num hooks on joint_q / joint_qd / actions (humanoid.py:195-206): done by the adjoint
-                # launch's own output stores (include/dsim.h: sanitize_grads), not by three torch kernels per step
-                self._spec_cache.sanitize_grads = int(bool(self.sanitize_grads))
+        if self._spec_cache is not None:
+            # the reference's nan_to_num hooks on joint_q / joint_qd / actions (humanoid.py:195-206): done by the adjoint
+            # launch's own output stores (include/dsim.h: sanitize_grads), not by three torch kernels per step.  Refreshed on
+            # every call (a host int store): the attribute may be toggled between steps, as on the unfused path -- the value a
+            # step's BACKWARD sees is the one in force when that backward runs (a captured graph keeps the one it captured)
+            self._spec_cache.sanitize_grads = int(bool(self.sanitize_grads))
         return self._spec_cache
 
     def stored_actions(self, actions):

@@ -62,13 +62,20 @@ class GraphedRollout:
                 self._run_once(write_back=False)
         torch.cuda.current_stream(env.device).wait_stream(side)
         torch.cuda.synchronize(env.device)
+        # The last warm-up rollout's autograd graph is still alive through the environment's observation / reward buffers, and
+        # with it the AccumulateGrad nodes of the leaves, bound to the stream they were created on.  Drop it, and capture on the
+        # SAME side stream the warm-up ran on: a leaf's accumulator that survives anyway (the caller holds a loss) then still
+        # matches the stream of the captured backward (no "AccumulateGrad node's stream does not match" synchronisation
+        # inside the replays).
+        env.detach_buffers()
+        gc.collect()
         self.leaves = list(leaves)
         for t in self.leaves:
             t.grad = None
         f0 = env.num_frames
         self.graph = torch.cuda.CUDAGraph()
         # thread-local capture mode: other threads (e.g. the RCCL watchdog of a torch.distributed job) may keep making HIP calls
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
             self.loss = self._run_once(write_back=carry_state)
         self._frames_per_replay = env.num_frames - f0
         torch.cuda.synchronize(env.device)

@@ -51,7 +51,11 @@ def _host_lib():
         so, src = os.path.join(CSRC, "libdsim_layout_host.so"), os.path.join(CSRC, "dsim_layout_host.cpp")
         deps = [src, os.path.join(CSRC, "dsim_layout.hpp"), os.path.join(os.path.dirname(HERE), "include", "dsim.h")]
         if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps if os.path.exists(d)):
-            subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", src, "-o", so])
+            # (two processes may get here together -- build() runs two specialise jobs side by side: each compiles to a name of its
+            # own and renames it into place, so that nobody ever loads a half-written file)
+            tmp = so + ".tmp%d" % os.getpid()
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", src, "-o", tmp])
+            os.replace(tmp, so)
         _host = C.CDLL(so)
     return _host
 
@@ -191,6 +195,64 @@ def source_hash():
     return h.hexdigest()[:12]
 
 
+STALE_DAYS = 30
+_background = {}   # layout name -> threading.Thread of a compile in flight (ensure_library_background)
+
+
+def cached_library(t, cache_dir=None):
+    """path of the library ensure_library would return WITHOUT compiling anything, or None; never raises"""
+    import hashlib
+    try:
+        if os.environ.get("DSIM_LIB") is None and matches(t, open(HEADER).read()):
+            return capi.LIB_PATH
+        flat = flat_table(*layout(t))
+        name = "U" + hashlib.sha1(",".join(str(v) for v in flat).encode()).hexdigest()[:12]
+        src = hashlib.sha1((source_hash() + "|" + " ".join(HIPCC_FLAGS)).encode()).hexdigest()[:10]
+        out = os.path.join(cache_dir or os.environ.get("DSIM_USER_LIBS") or USER_LIBS, "libdsim_%s_%s.so" % (name, src))
+        return out if os.path.exists(out) else None
+    except Exception:
+        return None
+
+
+def ensure_library_background(t, cache_dir=None, log=None):
+    """The default of Engine(...) when hipcc is on PATH: the cached library of this model if there is one, else None -- and a
+    daemon thread that compiles it (ensure_library: same lock, same cache), so that the NEXT Engine of this model picks it up
+    while this one runs the generic kernels.  Returns (path or None, thread or None); wait(t) joins a compile in flight."""
+    import threading
+    path = cached_library(t, cache_dir)
+    if path is not None or shutil.which("hipcc") is None:
+        return path, None
+    import hashlib
+    key = hashlib.sha1(",".join(str(v) for v in flat_table(*layout(t))).encode()).hexdigest()[:12]
+    th = _background.get(key)
+    if th is None or not th.is_alive():
+        def work():
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("always")
+                try:
+                    ensure_library(t, cache_dir, log)
+                except Exception as ex:   # (a background convenience must never take the process down)
+                    print("[diffrl_amd.specialise] background compile failed: %s" % ex, file=sys.stderr, flush=True)
+        th = threading.Thread(target=work, name="dsim-specialise-" + key, daemon=True)
+        _background[key] = th
+        th.start()
+    return None, th
+
+
+def wait(t=None, timeout=None):
+    """joins the background compile of template t (all of them when t is None); True when none is left running"""
+    import hashlib
+    if t is None:
+        ths = list(_background.values())
+    else:
+        key = hashlib.sha1(",".join(str(v) for v in flat_table(*layout(t))).encode()).hexdigest()[:12]
+        ths = [_background[key]] if key in _background else []
+    for th in ths:
+        th.join(timeout)
+    return not any(th.is_alive() for th in ths)
+
+
 def ensure_library(t, cache_dir=None, log=None):
     """Path of a library that holds a specialised kernel set for template t, compiling one on first use
     (Engine(..., specialise=True) / DSIM_AUTO_SPECIALISE=1; the reference compiles ALL its kernels on first use,
@@ -202,7 +264,10 @@ def ensure_library(t, cache_dir=None, log=None):
       that create the same model at the same time compile it once; written under a temporary name and renamed.
     * no hipcc, or the build fails (a tree shape one of the specialised phases refuses at compile time): a warning and None --
       the caller keeps the generic kernels, which run every model the layout builder accepts.
-    cache_dir: default $DSIM_USER_LIBS, else csrc/user_libs/ (next to the product library, so that it travels with the package)."""
+    cache_dir: default $DSIM_USER_LIBS, else csrc/user_libs/ (next to the product library, so that it travels with the package).
+    The lock is flock(): keep the cache on a LOCAL filesystem (on NFS two ranks may both compile; the rename keeps the result
+    whole either way).  Libraries of other source versions are left alone (two checkouts may share one cache) unless they are
+    older than STALE_DAYS."""
     import fcntl
     import hashlib
     import warnings
@@ -240,9 +305,15 @@ def ensure_library(t, cache_dir=None, log=None):
                               "ones):\n%s" % (e.output or b"").decode(errors="replace")[-2000:])
                 return None
             os.replace(tmp, out)
-            for f in os.listdir(cache_dir):   # this model's libraries of earlier source versions
-                if f.startswith("libdsim_%s_" % name) and f.endswith(".so") and os.path.join(cache_dir, f) != out:
-                    os.remove(os.path.join(cache_dir, f))
+            import time
+            for f in os.listdir(cache_dir):   # this model's libraries of other source versions, once nobody has used them for weeks
+                fp = os.path.join(cache_dir, f)
+                if (f.startswith("libdsim_%s_" % name) and f.endswith(".so") and fp != out
+                        and time.time() - max(os.path.getmtime(fp), os.path.getatime(fp)) > STALE_DAYS * 86400):
+                    try:
+                        os.remove(fp)
+                    except OSError:
+                        pass
             return out
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)

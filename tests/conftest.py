@@ -7,6 +7,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# Engine(...)'s default compiles a kernel set for a user model in a background thread and hands it to the NEXT Engine of that model:
+# the tests that assert which kernels ran (generic vs specialised) must not depend on what an earlier test left in the cache
+os.environ.setdefault("DSIM_AUTO_SPECIALISE", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun / the driver's GPU tier)")
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")

@@ -24,7 +24,80 @@ def _run(args, timeout=600, env=None):
 def _json_line(out):
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line expected, got: %r / stderr %r" % (out.stdout[-500:], out.stderr[-500:])
+    # the driver reads the LAST stdout line out of a bounded tail (round 5's 21 KB line came back `parsed: null`)
+    assert out.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 4096, len(lines[0])
     return json.loads(lines[0])
+
+
+def _full_record(ranks):
+    """a full bench record of the shape main() builds (every per-kernel view, note and sample string populated)"""
+    view = {"valu_insts_per_env_step": 32778.32294921875, "lds_insts_per_env_step": 5884.69873046875, "salu_insts_per_env_step": 5542.7,
+            "waves_per_env": 2.0, "valu_issue_frac": 0.5020936554990025, "valu_simd_frac": 0.25209494299590024,
+            "stall_frac": 0.26903840578677873, "lds_bank_conflict_frac": 0.1199660130845999, "valu_active_lanes_avg": 31.94}
+    rf = {"bound": "valu-issue", "kernel": "dsim_env_fwd_kernel", "dominant_launch": "forward", "achieved": 5.6283746, "peak": 8000.0,
+          "unit": "GB/s", "frac": 0.000703546, "alg_bytes_per_launch": 294912, "kernel_ms": 0.0523974, "fwd_kernel_ms": 0.0523974,
+          "bwd_kernel_ms": 0.0529123, "fwd_alg_bytes_per_launch": 294912, "bwd_alg_bytes_per_launch": 471040,
+          "fwd_alg_frac": 0.000703546, "bwd_alg_frac": 0.00111283, "csrc_hash": "3bb1ae48c285", "ckpt_bytes_per_env_step": 30096,
+          "ckpt_bytes_per_rollout": 986185728, "valu_issue_frac": 0.5, "fwd_valu_issue_frac": 0.53, "valu_simd_frac": 0.2520949,
+          "fwd_valu_simd_frac": 0.2503285, "stall_frac": 0.269, "fwd_stall_frac": 0.307, "valu_insts_per_env_step": 25482.9,
+          "counters": "profiles/r05_final_ant_pmc.json", "adjoint": view, "forward": view, "fp32_valu_frac_upper_bound": 0.12,
+          "flops_per_valu_inst": {"adjoint": 1.049, "forward": 0.861, "source": "profiles/opcode_census.json"},
+          "fp32_valu_frac_est": 0.0581825, "flop_per_env_step": 1791864.9, "bwd_traffic": 32300000, "fwd_traffic": 32700000,
+          "traffic_source": "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/r05_final_ant_pmc.json", "traffic": 32700000,
+          "hbm_measured_frac": 0.078, "fwd_hbm_measured_frac": 0.078, "bwd_hbm_measured_frac": 0.0763, "alg_frac_step": 0.0008976}
+    oc = [{"workload": "%s %d envs x H=32, MM_caching_frequency %d" % (nm, n, mm), "value": 2823456.789, "unit": "env-steps/s", "steps": 10,
+           "ms_per_rollout": 11.6, "kernel_ms": 0.18, "fwd_kernel_ms": 0.17, "bwd_kernel_ms": 0.18, "ckpt_bytes_per_env_step": 201000,
+           "kernels": k, "roofline": dict(rf)}
+          for nm, n, mm, k in (("humanoid", 1024, 48, "specialised (compile-time layout)"), ("snu", 512, 8, "specialised (compile-time layout)"),
+                               ("ant", 1024, 1, "specialised (compile-time layout)"), ("ant", 8192, 16, "specialised (compile-time layout)"),
+                               ("ant", 1024, 16, "generic (run-time layout)"))]
+    return {"metric": "fwd+adjoint env-steps/sec", "value": 9603456.789 * ranks, "unit": "env-steps/s", "n_gpus": ranks, "rccl_ranks": ranks,
+            "oversubscribed": False, "backend": "nccl",
+            "per_rank": [{"rank": r, "value": 9603456.789, "ms_per_step": 3.4123456, "ms_per_step_median": 3.41, "ms_per_step_max": 3.52,
+                          "device": "AMD Instinct MI355X (cuda:%d)" % r} for r in range(ranks)],
+            "steps": 20, "warmup": 5, "ms_per_step": 3.4123456, "ms_per_step_min": 3.40, "ms_per_step_median": 3.41, "ms_per_step_max": 3.52,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ant 1024 envs/GPU x H=32 through DFlexEnv.step, loss=-sum(rew), 1 backward", "envs_per_gpu": 1024,
+                       "envs_total": 1024 * ranks, "horizon": 32, "substeps": 16, "mm_freq": 16, "sharding": "envs by index, no collective",
+                       "submission": "one HIP graph per rollout: the 32 forward + 32 adjoint launches captured through DFlexEnv.step",
+                       "submission_fallback": False},
+            "eager_env_steps_per_s": 6543210.123, "roofline": rf, "fp32_valu_frac_est": 0.058, "no_grad_forward_env_steps_per_s": 21e6,
+            "other_configs": oc,
+            "cpu_baseline": {"value": 3922.413606967296, "unit": "env-steps/s", "cores": 64, "kind": "port",
+                             "sample": "47104 ant env-steps (forward + taped reverse sweep, oracle/dsim_oracle.cpp) in 12.0 s on 64 host "
+                                       "threads of 256 cores, environments split over the threads",
+                             "single_thread": {"value": 355.09, "unit": "env-steps/s", "cores": 1, "sample": "x" * 150},
+                             "reference_recorded": {"value": 696.5, "unit": "env-steps/s", "cores": 8, "kernel_threads": 1, "source": "y" * 100}}}
+
+
+@pytest.mark.parametrize("ranks", [1, 8])
+def test_printed_line_is_compact_and_complete(ranks):
+    """the printed line stays under 4 KB whatever the full record holds, and carries the contract's keys, a
+    numeric roofline, the CPU baseline and one short object per other configuration"""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = _full_record(ranks)
+    assert len(json.dumps(full)) > 8000   # (the record main() builds is far over the limit)
+    line = bench.compact_line(full, "bench_full.json")
+    assert len(line) < 4096 and "\n" not in line
+    j = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "per_rank"):
+        assert k in j, k
+    assert j["dtype"] == "f32" and j["config"]["workload"].startswith("ant 1024 envs") and j["config"]["submission"] == "hip-graph"
+    rf = j["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "fwd_alg_frac", "bwd_alg_frac", "alg_frac_step", "kernel_ms",
+              "fwd_kernel_ms", "bwd_kernel_ms", "hbm_measured_frac", "valu_simd_frac", "fwd_valu_simd_frac", "fp32_valu_frac_est", "csrc_hash"):
+        assert k in rf, k
+    assert all(not isinstance(v, (dict, list)) for v in rf.values()) and "note" not in rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 64 and abs(cb["value"] - 3922.4) < 0.1 and cb["single_thread"] > 0 and cb["reference_recorded"] == 696.5
+    assert len(j["per_rank"]) == ranks and len(j["other_configs"]) == 5
+    assert sum(1 for o in j["other_configs"] if o["workload"].endswith("generic")) == 1
+    for o in j["other_configs"]:
+        assert set(o) >= {"workload", "value", "fwd_ms", "bwd_ms", "frac"} and o["value"] > 0
+    assert abs(j["value"] / full["value"] - 1) < 1e-4   # (5 significant digits in the printed line, every bit in the full record)
 
 
 def test_dry_run_launches_two_ranks_on_cpu():
@@ -77,25 +150,31 @@ def test_bench_through_the_launcher_rccl_group_of_one():
         k = o["workload"].split()[0]
         return (k + ("_mm1" if o["workload"].endswith("frequency 1") else "") + ("_generic" if o["kernels"].startswith("generic") else "") +
                 ("_8192" if " 8192 envs" in o["workload"] else ""))
-    oc = {key(o): o for o in j["other_configs"]}
+    full = json.load(open(os.path.join(ROOT, j["full_record"])))   # the full record (per-kernel views, per-config rooflines)
+    assert abs(full["value"] / j["value"] - 1) < 1e-4 and full["steps"] == 2
+    oc = {key(o): o for o in full["other_configs"]}
     assert set(oc) == {"humanoid", "snu", "ant_mm1", "ant_generic", "ant_8192"}, oc
     for k, o in oc.items():   # each measured like the headline (>= 10 timed replays) and with its own roofline object
         assert o["value"] and o["value"] > 1e5 and o["steps"] >= (5 if k == "ant_8192" else 10), o
         r = o["roofline"]
         assert r["bound"] == "valu-issue" and r["traffic"] > r["alg_bytes_per_launch"] and 0 < r["hbm_measured_frac"] < 1, r
+        assert r["kernel_ms"] == max(r["fwd_kernel_ms"], r["bwd_kernel_ms"])   # the triple (kernel, time, traffic) is ONE kernel's
+    assert len(j["other_configs"]) == 5 and all(o["value"] > 1e5 and o["fwd_ms"] > 0 and o["bwd_ms"] > 0 for o in j["other_configs"])
+    assert "AccumulateGrad" not in out.stderr, out.stderr[-600:]   # no autograd node of an earlier stream inside the timed replays
     assert oc["ant_generic"]["value"] < j["value"] < oc["ant_8192"]["value"]
     assert j["config"]["submission_fallback"] is False
     assert j["value"] > 1e5 and j["roofline"]["traffic"] > j["roofline"]["alg_bytes_per_launch"]
-    assert j["roofline"]["bound"] == "valu-issue" and "valu_issue_frac" in j["roofline"] and "hbm_measured_frac" in j["roofline"]
+    assert j["roofline"]["bound"] == "valu-issue" and "valu_simd_frac" in j["roofline"] and "hbm_measured_frac" in j["roofline"]
     # round 5: the group really is RCCL, per-rank figures are in the line, the roofline object names the LONGER launch
     assert j["backend"] == "nccl" and len(j["per_rank"]) == 1
     r0 = j["per_rank"][0]
     assert r0["rank"] == 0 and "cuda:0" in r0["device"] and j["value"] <= r0["value"] < 1.05 * j["value"]   # (own time: before the closing barrier)
     assert 0.95 * j["ms_per_step"] < r0["ms_per_step"] <= j["ms_per_step"] and r0["ms_per_step_max"] >= r0["ms_per_step_median"] > 0
-    rf = j["roofline"]
-    longer = "dsim_env_fwd_kernel" if rf["fwd_kernel_ms"] > rf["kernel_ms"] else "dsim_env_bwd_kernel"
+    rf = full["roofline"]
+    longer = "dsim_env_fwd_kernel" if rf["fwd_kernel_ms"] > rf["bwd_kernel_ms"] else "dsim_env_bwd_kernel"
     assert rf["kernel"] == longer and rf["dominant_launch"] == ("forward" if longer.endswith("fwd_kernel") else "adjoint")
-    assert abs(rf["alg_frac_step"] - 748 * j["value"] / 8e12) < 1e-9 and 0 < rf["alg_frac_step"] < 0.01
+    assert j["roofline"]["kernel"] == longer
+    assert abs(rf["alg_frac_step"] - 748 * full["value"] / 8e12) < 1e-9 and 0 < rf["alg_frac_step"] < 0.01
     if rf.get("counters"):   # counter file at these kernel sources: the flop view comes from the opcode census, not "every VALU op is an FMA"
         assert rf["fp32_valu_frac_est"] is None or rf["fp32_valu_frac_est"] < rf["fp32_valu_frac_upper_bound"]
 

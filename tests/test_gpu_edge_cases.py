@@ -155,3 +155,27 @@ def test_half_angle_polynomials_at_and_beyond_their_range_on_the_gpu():
     o_q, o_qd, dbg = oracle_forward(t, q, qd, act, None, dt, S, mm, debug=True)
     assert relerr(first_substep(t, ck.cpu().numpy())["X_sc"], dbg["X_sc"]) < 1e-6
     assert relerr(qo.cpu().numpy().reshape(n, -1), o_q) < 1e-6
+
+
+def test_denormal_tangential_contact_velocity_stays_finite():
+    """a tangential contact velocity of ~1e-20 makes |vt|^2 denormal; v_rsq_f32 flushes it to zero (rsq = inf) and the
+    correction steps would turn that into NaN for the whole environment.  dsim_inv_len_* treat a squared length below the
+    smallest normal as zero length.  A floating capsule resting in the ground with such a drift: the state stays finite and
+    equals the oracle's (whose exact sqrt / division handle denormals), the gradients are finite."""
+    from diffrl_amd.engine import Engine
+    t = _chain(1, True, True)
+    eng = Engine(t, DEV)
+    n = 4
+    q = np.tile(t.joint_q0, (n, 1)).astype(np.float32)
+    q[:, 1] = 0.03                                   # capsule radius 0.05: both end caps penetrate
+    qd = np.zeros((n, t.n_qd), np.float32)
+    qd[:, 3] = np.array([1e-20, -1e-20, 3e-21, 0.0], np.float32)   # world-frame linear drift along x: vt^2 = 1e-40 .. 0
+    qd[:, 4] = -0.1
+    act = np.zeros((n, t.n_qd), np.float32)
+    gq, gqd = np.ones_like(q), np.ones_like(qd)
+    dt, S, mm = 1.0 / 960.0, 1, 1
+    o = oracle_backward(t, q, qd, act, None, dt, S, mm, gq, gqd)
+    qo, qdo, g_q, g_qd, g_a = _run(eng, t, q, qd, act, dt, S, mm, gq, gqd)
+    for x in (qo, qdo, g_q, g_qd, g_a):
+        assert np.isfinite(x).all(), x
+    assert relerr(qo, o["q_out"]) < 1e-5 and relerr(qdo, o["qd_out"]) < 1e-4

@@ -218,7 +218,14 @@ def test_ensure_library_builds_once_per_model_and_falls_back_loudly(tmp_path, mo
     assert p2 != p1 and len(calls) == 2                                                                  # keyed by the layout
     monkeypatch.setattr(specialise, "source_hash", lambda: "0" * 12)                                      # the kernel sources changed
     p3 = specialise.ensure_library(user, cache_dir=str(tmp_path), log=lambda m: None)
-    assert p3 != p1 and len(calls) == 3 and not os.path.exists(p1) and os.path.exists(p2)               # rebuilt, the stale one removed
+    # rebuilt; the library of the other source version is LEFT ALONE (another checkout sharing the cache may be using it) ...
+    assert p3 != p1 and len(calls) == 3 and os.path.exists(p1) and os.path.exists(p2)
+    # ... until nobody has touched it for STALE_DAYS
+    old = __import__("time").time() - (specialise.STALE_DAYS + 1) * 86400
+    os.utime(p1, (old, old))
+    monkeypatch.setattr(specialise, "source_hash", lambda: "2" * 12)
+    p4 = specialise.ensure_library(user, cache_dir=str(tmp_path), log=lambda m: None)
+    assert len(calls) == 4 and not os.path.exists(p1) and os.path.exists(p3) and os.path.exists(p4)
 
     def failing(out, header=None, only=None, quiet=False):
         open(out, "wb").write(b"partial")
@@ -229,6 +236,41 @@ def test_ensure_library_builds_once_per_model_and_falls_back_loudly(tmp_path, mo
     with pytest.warns(UserWarning, match="keeps the generic"):
         assert specialise.ensure_library(user, cache_dir=str(tmp_path), log=lambda m: None) is None
     assert not [f for f in os.listdir(tmp_path) if ".tmp" in f]
+
+
+def test_background_specialisation_returns_at_once_and_hands_the_library_to_the_next_engine(tmp_path, monkeypatch):
+    """the default of Engine(...): no cached set -> (None, thread): the caller runs the generic kernels while the set compiles;
+    once the thread is done the same call returns the path (what the next Engine of the model loads); one compile per model
+    whatever the number of callers; a shipped model never starts a thread"""
+    import threading
+    from oracle_lib import template_from_golden
+    from diffrl_amd import capi
+    monkeypatch.delenv("DSIM_LIB", raising=False)
+    gate, calls = threading.Event(), []
+
+    def slow_build(out, header=None, only=None, quiet=False):
+        calls.append(out)
+        assert gate.wait(30)
+        open(out, "wb").write(b"stub")
+        return out
+
+    monkeypatch.setattr(specialise, "build_library", slow_build)
+    monkeypatch.setattr(specialise.shutil, "which", lambda x: "/usr/bin/" + x)
+    monkeypatch.setattr(specialise, "_background", {})
+    user = ArticulationTemplate.load(FIXTURE)
+    assert specialise.ensure_library_background(template_from_golden("ant"), cache_dir=str(tmp_path)) == (capi.LIB_PATH, None)
+    p, th = specialise.ensure_library_background(user, cache_dir=str(tmp_path), log=lambda m: None)
+    assert p is None and th is not None and th.daemon
+    p, th2 = specialise.ensure_library_background(user, cache_dir=str(tmp_path), log=lambda m: None)
+    assert p is None and th2 is th                                   # a second caller joins the compile in flight
+    assert specialise.cached_library(user, cache_dir=str(tmp_path)) is None and not specialise.wait(user, timeout=0.05)
+    gate.set()
+    assert specialise.wait(user, timeout=30) and len(calls) == 1
+    p, th3 = specialise.ensure_library_background(user, cache_dir=str(tmp_path))
+    assert p and os.path.exists(p) and th3 is None and p == specialise.cached_library(user, cache_dir=str(tmp_path))
+    monkeypatch.setattr(specialise.shutil, "which", lambda x: None)   # no compiler: nothing starts, nothing warns
+    monkeypatch.setattr(specialise, "source_hash", lambda: "3" * 12)
+    assert specialise.ensure_library_background(user, cache_dir=str(tmp_path)) == (None, None)
 
 
 _AUTO_SCRIPT = r'''
@@ -253,6 +295,11 @@ for auto in (False, True):
     torch.cuda.synchronize()
     eng.status()
     outs.append([x.cpu().numpy() for x in (qo, qdo) + tuple(y for y in g if y is not None)])
+# the DEFAULT path: the set is cached by now -> picked up without asking; switched off -> generic
+assert Engine(t, dev).variant > 0
+os.environ["DSIM_AUTO_SPECIALISE"] = "0"
+assert Engine(t, dev).variant == 0
+del os.environ["DSIM_AUTO_SPECIALISE"]
 ant = Engine(__import__("oracle_lib").template_from_golden("ant"), dev, specialise=True)     # a shipped model: the product library's own set
 assert ant.variant > 0 and ant._lib is __import__("diffrl_amd.capi", fromlist=["x"]).lib()
 worst = max(float(np.abs(a - b).max() / (np.abs(a).max() + 1e-30)) for a, b in zip(*outs))
