@@ -351,7 +351,7 @@ def main():
                     action_seed=np.int64(3), preroll=np.int64(20))
         np.savez_compressed(os.path.join(OUT, "ant_1024x32.npz"), **slim)
         print("golden written: ant_1024x32")
-    for tag, name, n, stride in (("humanoid_1024x32", "humanoid", 1024, 8), ("snu_512x32", "snu", 512, 16)):
+    for tag, name, n, stride in (("humanoid_1024x32", "humanoid", 1024, 2), ("snu_512x32", "snu", 512, 4)):
         if tag in names:
             # BASELINE.json configs[2] / configs[3] literally, through the reference with its termination rules active
             # (random actions make humanoids fall: restarts are part of the recording).  Slimmed like ant_1024x32: actions and

@@ -51,6 +51,10 @@ def pytest_terminal_summary(terminalreporter):
     tr.section("probed tolerances (stated: 1e-3)")
     if not probe_ledger.ENTRIES:
         tr.write_line("none: every gradient comparison of this run passed at the stated 1e-3")
+    for tid, (what, whole, cos, n) in probe_ledger.STATED_FORM.items():
+        tr.write_line("%s %s: BASELINE.md section 4's own form, no probe: whole-tensor max-norm relative error %.3e (stated 1e-3) -> %s; "
+                      "cosine %.6f (stated >= 0.9999) -> %s; %d environments" % (tid, what, whole, "holds" if whole < 1e-3 else "EXCEEDED",
+                                                                                 cos, "holds" if cos >= 0.9999 else "BELOW", n))
     for tid, (n, what) in probe_ledger.SAMPLED.items():
         used = sum(1 for r in probe_ledger.ENTRIES if r["test"] == tid)
         tr.write_line("%s %s: %d of %d compared cases probed (%.2f %%)" % (tid, what, used, n, 100.0 * used / max(n, 1)))

@@ -16,9 +16,10 @@ EP_SUBSTEPS = {"ant": 16, "humanoid": 48, "snu": 48, "hopper": 16, "cheetah": 16
 EP_RULES = {"ant": (True, False), "humanoid": (True, True), "snu": (True, True), "hopper": (True, False),
             "cheetah": (False, False), "cartpole": (False, False)}
 TERM_H = {"ant": 0.27, "humanoid": 0.74, "snu": 0.46, "hopper": -0.45}
-# sampled environments of the full-size recordings that may need a probed tolerance (measured at the shipped kernels, round 5:
-# Humanoid 1024 x 32: 8 of 128 (round 4: 10), SNUHumanoid 512 x 32: 2 of 32 (round 4: 1))
-FULLSIZE_PROBE_BUDGET = {"humanoid": 10, "snu": 3}
+# sampled environments of the full-size recordings that may need a probed tolerance.  Round 6: gradients recorded for every 2nd
+# Humanoid environment (512 sampled; round 5: every 8th, 8 of 128 probed) and every 4th SNUHumanoid environment (128 sampled;
+# round 5: every 16th, 1 of 32 probed); budgets = the counts measured at the shipped kernels plus a margin (PLACEHOLDER until measured)
+FULLSIZE_PROBE_BUDGET = {"humanoid": 48, "snu": 12}
 # Ant 1024 x 32 (BASELINE.json configs[1]), gradients of every 2nd environment (512 sampled; round 5 -- every 8th before, where all
 # 128 passed at 1e-3): measured at the shipped kernels 3 of 512 above 1e-3 (4.9e-3, 3.7e-3, 2.7e-3 -- the same three with every
 # division and square root correctly rounded; 15-17 with a one-step v_rsq_f32 in the integrator, which is why it is not used there:
@@ -205,6 +206,10 @@ def test_gpu_h32_rollout_vs_reference(env):
     assert relerr(e.state.joint_q.detach().view(n, -1).cpu().numpy(), g["q_final"]) < 1e-3
 
 
+# cosine over ALL sampled environments of a recording (branch-boundary environments included), BASELINE.md section 4: >= 0.9999.
+# A recording listed here is held to its measured figure instead, with the reason.
+COS_ALL_MIN = {}
+
 PROBE_LADDER = ((1e-7, 0), (1e-6, 0), (3e-6, 0), (1e-6, 1), (3e-6, 1), (1e-6, 2), (3e-6, 2), (1e-6, 3), (3e-6, 3),
                 (1e-6, 4), (3e-6, 4), (1e-6, 5), (3e-6, 5), (1e-5, 0), (1e-5, 1), (1e-5, 2))
 
@@ -225,6 +230,14 @@ def _per_env_gradient_check(tag, a, r, sel, budget, oracle_grad):
     hard = np.where(~well)[0]
     import probe_ledger
     probe_ledger.note_sampled(len(per_env), tag)
+    # BASELINE.md section 4's own figures, no probe involved: max-norm relative error over the WHOLE gradient tensor (the form the
+    # tolerance is stated in; the per-environment form used below is stricter -- an environment with small gradients is held to
+    # 1e-3 of ITS largest entry) and the cosine over all sampled environments
+    whole = float(np.abs(a - r).max() / (np.abs(r).max() + 1e-30))
+    cos_all = float((a * r).sum() / (np.linalg.norm(a) * np.linalg.norm(r)))
+    probe_ledger.note_stated(tag, whole, cos_all, len(per_env))
+    print("%s: stated-form figures over %d sampled environments: whole-tensor max-norm relative error %.3e (stated 1e-3), "
+          "cosine %.6f (stated >= 0.9999)" % (tag, len(per_env), whole, cos_all))
     print("%s: %d of %d sampled environments above 1e-3 (%.1f %%; max %.2e, median %.2e)"
           % (tag, len(hard), len(per_env), 100.0 * len(hard) / len(per_env), per_env.max(), np.median(per_env)))
     # the budget is checked BEFORE any probing: an adjoint defect puts every environment above 1e-3, and that must fail
@@ -253,8 +266,8 @@ def _per_env_gradient_check(tag, a, r, sel, budget, oracle_grad):
             assert x < probe_ledger.accept("rollout", x, y, budget, "%s env %d" % (tag, sel[hard[k]])), (tag, sel[hard[k]], x, y)
     aw, rw = a[:, well], r[:, well]
     assert (aw * rw).sum() / (np.linalg.norm(aw) * np.linalg.norm(rw)) > 0.9999
-    # ... and over ALL sampled environments, the branch-boundary ones included (measured: 0.9998 / 0.99999)
-    assert (a * r).sum() / (np.linalg.norm(a) * np.linalg.norm(r)) > 0.999
+    # ... and over ALL sampled environments, the branch-boundary ones included: BASELINE.md section 4's 0.9999, un-probed
+    assert cos_all > COS_ALL_MIN.get(tag.split(" ")[0], 0.9999), cos_all
     return well
 
 
