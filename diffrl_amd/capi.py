@@ -111,7 +111,7 @@ class DsimError(RuntimeError):
 
 
 _libs = {}
-EXPECTED_ABI = 106   # dsim_version() of the library this binding was written against (argument lists of include/dsim.h)
+EXPECTED_ABI = 107   # dsim_version() of the library this binding was written against (argument lists of include/dsim.h)
 
 
 def lib():
@@ -151,6 +151,10 @@ def load(path):
     L.dsim_step_forward.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp]
     L.dsim_step_backward.argtypes = [vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp,
                                      vp]
+    L.dsim_step_backward_literal.argtypes = [vp, C.c_int, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.dsim_step_backward_literal.restype = C.c_int
+    L.dsim_literal_scratch_floats.argtypes = [vp]
+    L.dsim_literal_scratch_floats.restype = C.c_int64
     ep = C.POINTER(EnvSpec)
     L.dsim_env_step_forward.argtypes = [vp, ep, C.c_int, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp,
                                         C.POINTER(Episode), vp]
@@ -175,5 +179,5 @@ def check(rc, L=None):
 
 EXPORTS = ("dsim_last_error", "dsim_version", "dsim_model_create", "dsim_model_destroy", "dsim_model_variant", "dsim_model_device",
            "dsim_ckpt_floats", "dsim_ckpt_floats_mm", "dsim_model_set_ckpt_mode",
-           "dsim_step_forward", "dsim_step_backward", "dsim_env_step_forward", "dsim_env_step_backward",
+           "dsim_step_forward", "dsim_step_backward", "dsim_step_backward_literal", "dsim_literal_scratch_floats", "dsim_env_step_forward", "dsim_env_step_backward",
            "dsim_env_observe", "dsim_model_status", "dsim_body_transforms")

@@ -2152,6 +2152,138 @@ DSIM_FN void dsim_fwd_dynamics_wave(const Ctx& c, Exec& ex, float* g_row, float*
     });
 }
 
+// ---- the same for a model with several wavefronts per environment (DsimWideOverlap; round 6) -------------------------------
+// tau -> H^-1 tau -> integrate were three phases of all four wavefronts (three workgroup barriers, two LDS store -> load round
+// trips; 24 dofs and 11 links busy, 192 lanes waiting: 2.9 k of the 11 k cycles of a SNUHumanoid substep).  Now ONE block of the
+// FIRST wavefront, the values changing lanes in registers (tau_j by v_readlane, qdd of a link's dofs by ds_bpermute), while the
+// others wait at ONE hand-over (mid: f_tot, tau and qdd are in LDS) and then copy the rest of the checkpoint row -- X_sc .. qdd,
+// which the integrator's stores do not touch -- beside the integrator.  Same arithmetic in the same order as dsim_tau_lane /
+// dsim_fwd_solve / dsim_integrate_lane.  (-DDSIM_NO_WIDE_DYN builds the three-phase form for A/B runs.)
+template <class Ctx, class Exec> struct DsimWideDyn {
+    static constexpr bool value = []() {
+#ifdef DSIM_NO_WIDE_DYN
+        return false;
+#else
+        if constexpr (DsimWideOverlap<Ctx, Exec>::value) return decltype(Ctx::d)::nd <= 32 && decltype(Ctx::d)::L <= DSIM_NL;
+        else return false;
+#endif
+    }();
+};
+template <class Ctx, class Exec>
+DSIM_FN void dsim_fwd_dynamics_wide(const Ctx& c, Exec& ex, float* g_row, float* g_hinv, bool update_mass) {
+    ex.mark(3);
+    using D = decltype(c.d);
+    constexpr int nd = D::nd, L = D::L, NLR = Exec::NL - DSIM_NL;
+    ex.fork_wave0([&](int lane) {
+        constexpr int MASK = dsim_tmask_static<Ctx>();
+        constexpr int NQ = dsim_mask_nq(MASK), NDF = dsim_mask_nd(MASK);
+        const float h = c.h;
+        const DsimTopoRegs& tp = ex.topo(lane);
+        const bool is_dof = lane < nd, is_link = lane < L;
+        // ---- loads of both roles, issued together
+        int dtype = tp.dof_type;
+        DSIM_OPAQUE(dtype);
+        const int di = tp.dof_link, dcs = tp.dof_cs, dds = tp.dof_ds, d = is_dof ? lane : 0;
+        const bool hinge = dtype == DSIM_JOINT_PRISMATIC || dtype == DSIM_JOINT_REVOLUTE;
+        const int qi = hinge ? dcs : (dtype == DSIM_JOINT_BALL ? dcs + (d - dds) : 0);
+        const sv6 Sd = ldsv(WF(S) + 6 * d);
+        const sv6 F = ldsv(WF(ftot) + 6 * di);   // summed behind the kinematics by this wavefront
+        const float q_d = WF(q)[qi], qd_d = WF(qd)[d], act_d = WF(act)[d];
+        const float lower = CF(lower)[qi], upper = CF(upper)[qi], target = CF(target)[qi];
+        const float lke = CF(lke)[di], tke = CF(tke)[di], tkd = CF(tkd)[di], lkd = CF(lkd)[di];
+        float hrow[nd];
+#pragma unroll
+        for (int j = 0; j < nd; ++j) hrow[j] = WF(hinv)[d * nd + j];
+        int ltype = tp.own_type;
+        DSIM_OPAQUE(ltype);
+        const int lcs = tp.own_cs, lds_ = tp.own_ds;
+        float qv[NQ > 0 ? NQ : 1], qdv[NDF > 0 ? NDF : 1];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) qv[k] = WF(q)[lcs + k];
+#pragma unroll
+        for (int k = 0; k < NDF; ++k) qdv[k] = WF(qd)[lds_ + k];
+        // ---- dof role: tau (sim.py:1421-1502)
+        float t = 0.0f - sdot(Sd, F);
+        if (hinge) {
+            float limit_f = 0.0f;
+            if (q_d < lower) limit_f = lke * (lower - q_d);
+            if (q_d > upper) limit_f = lke * (upper - q_d);
+            t = t - tke * (q_d - target) - tkd * qd_d + act_d + limit_f - lkd * qd_d;
+        } else if (dtype == DSIM_JOINT_BALL) {
+            t = t - qd_d * tkd - q_d * tke;
+        }
+        // ---- qdd = H^-1 tau: tau_j travels by v_readlane (the order of dsim_dot_n: j ascending, acc += a_j b_j)
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < nd; ++j) acc += hrow[j] * ex.bcast(t, j);
+        if (is_dof) {
+            WF(tau)[lane] = t;
+            WF(qdd)[lane] = acc;
+        }
+        // ---- qdd of a link's dofs -> the link's lane
+        float av[NDF > 0 ? NDF : 1];
+#pragma unroll
+        for (int k = 0; k < NDF; ++k) av[k] = ex.shfl(acc, lds_ + k);
+        // ---- link role: semi-implicit Euler (sim.py:1505-1636); arithmetic, hand-over of the checkpoint copy, stores
+        float qdn = 0.f, qn = 0.f;
+        v3 w = zero3(), pn = zero3(), vn = zero3();
+        q4 rn = mkq(0.f, 0.f, 0.f, 1.f);
+        const bool hinge_l = ltype == DSIM_JOINT_PRISMATIC || ltype == DSIM_JOINT_REVOLUTE;
+        const bool quat_l = ltype == DSIM_JOINT_BALL || ltype == DSIM_JOINT_FREE, fr = ltype == DSIM_JOINT_FREE;
+        if (hinge_l) {
+            qdn = qdv[0] + av[0] * h;
+            qn = qv[0] + qdn * h;
+        }
+        if constexpr ((MASK & (DSIM_TM(DSIM_JOINT_BALL) | DSIM_TM(DSIM_JOINT_FREE))) != 0) {
+            if (quat_l) {
+                w = mk3(qdv[0], qdv[1], qdv[2]) + mk3(av[0], av[1], av[2]) * h;
+                q4 r;
+                if constexpr ((MASK & DSIM_TM(DSIM_JOINT_FREE)) != 0) {
+                    if (fr) {
+                        vn = mk3(qdv[3], qdv[4], qdv[5]) + mk3(av[3], av[4], av[5]) * h;
+                        const v3 p = mk3(qv[0], qv[1], qv[2]);
+                        pn = p + (vn + cross(w, p)) * h;
+                        r = mkq(qv[3], qv[4], qv[5], qv[6]);
+                    } else {
+                        r = mkq(qv[0], qv[1], qv[2], qv[3]);
+                    }
+                } else {
+                    r = mkq(qv[0], qv[1], qv[2], qv[3]);
+                }
+                const q4 dr = qmul_v(w, r) * 0.5f;
+                const q4 rt = r + dr * h;
+                const float il = dsim_inv_len(qdot(rt, rt));
+                if (il > 0.0f) rn = rt * il;
+            }
+        }
+        ex.mid();   // tau, qdd of all dofs are in LDS (f_tot since the kinematics): the others copy the rest of the row
+        if (is_link) {
+            float *q = WF(q), *qd = WF(qd);
+            if (hinge_l) {
+                qd[lds_] = qdn;
+                q[lcs] = qn;
+            }
+            if constexpr ((MASK & (DSIM_TM(DSIM_JOINT_BALL) | DSIM_TM(DSIM_JOINT_FREE))) != 0) {
+                if (quat_l) {
+                    if (fr) {
+                        st3(q + lcs, pn);
+                        st3(qd + lds_ + 3, vn);
+                    }
+                    stq(q + lcs + (fr ? 3 : 0), rn);
+                    st3(qd + lds_, w);
+                }
+            }
+        }
+    }, [&](int lane) {
+        ex.mid();
+        if (g_row) {
+            dsim_ckpt_store_row<Ctx, NLR, 2>(c, lane, g_row);
+            if (update_mass && g_hinv)
+                for (int k = lane; k < nd * nd; k += NLR) g_hinv[k] = WF(hinv)[k];
+        }
+    });
+}
+
 // ---- checkpoint = what the adjoint launch needs from the forward launch, kept in HBM instead of recomputed ----
 // per environment: [substeps][save_words] saved blocks (q, qd, X_sj, X_sc, COM, S, v_j, v, a, inertias, f_tot, qdd of the
 // substep) followed by [groups][hinv_words] inverses of the mass matrix (one per refresh).  288 GB of HBM are otherwise
@@ -2203,6 +2335,11 @@ DSIM_FN void dsim_fwd_substep(const Ctx& c, Exec& ex, bool update_mass, float* g
         if (update_mass) dsim_fwd_mass(c, ex);   // H depends on the kinematics only
         if constexpr (!DsimWaveDyn<Ctx, Exec>::sums_inside) dsim_fwd_ftot(c, ex);
         dsim_fwd_dynamics_wave(c, ex, g_row, g_hinv, update_mass);
+        return;
+    }
+    if constexpr (DsimWideDyn<Ctx, Exec>::value) {
+        if (update_mass) dsim_fwd_mass(c, ex);   // H depends on the kinematics only
+        dsim_fwd_dynamics_wide(c, ex, g_row, g_hinv, update_mass);
         return;
     }
     dsim_fwd_tau(c, ex);
@@ -3544,8 +3681,15 @@ template <class Ctx, class Exec> DSIM_FN void dsim_bwd_recompute_forward(const C
 }
 
 // nx: DsimWideOverlap only (the body level brings the next substep's checkpoint row in, see DsimNextRow)
-template <class Ctx, class Exec> DSIM_FN void dsim_bwd_substep(const Ctx& c, Exec& ex, bool update_mass, const DsimNextRow& nx = DsimNextRow{}) {
+// g_lit_aH (dsim_step_backward_literal only; null everywhere else, folded away): where the refresh substep leaves the accumulated
+// cotangent of the mass matrix [nd][nd] before the mass-matrix adjoint consumes it (dsim_literal.hpp)
+template <class Ctx, class Exec> DSIM_FN void dsim_bwd_substep(const Ctx& c, Exec& ex, bool update_mass, const DsimNextRow& nx = DsimNextRow{},
+                                                               float* g_lit_aH = nullptr) {
     dsim_bwd_joint_space(c, ex, update_mass);
+    if (update_mass && g_lit_aH)
+        ex.fire([&](int lane) {
+            for (int k = lane; k < c.d.nd * c.d.nd; k += Exec::NL) g_lit_aH[k] = WF(aH)[k];
+        });
     if (update_mass) dsim_bwd_mass(c, ex);
     if constexpr (DsimRowTree<Ctx, Exec>::value) dsim_bwd_bodies_rowtree(c, ex, update_mass, nx);
     else dsim_bwd_bodies(c, ex, update_mass);
@@ -3563,7 +3707,9 @@ template <class Ctx, class Exec>
 DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm_freq, const float* g_ckpt,
                                     const float* g_act, const float* g_mact, const float* g_gq_out,
                                     const float* g_gqd_out, float* g_gq_in, float* g_gqd_in, float* g_gact,
-                                    float* g_gmact) {
+                                    float* g_gmact, float* g_lit = nullptr) {
+    // g_lit (dsim_step_backward_literal): this environment's [nq + nd + nd * nd] words -- the cotangents of the FIRST substep's
+    // outputs (q_1, qd_1) and the mass-matrix cotangent of the first group, what dsim_literal.hpp contracts its tangent with
     const int nq = c.d.nq, nd = c.d.nd, M = c.d.M;
     ex.begin_request();
     ex.begin();
@@ -3639,7 +3785,12 @@ DSIM_FN void dsim_sim_step_backward(const Ctx& c, Exec& ex, int substeps, int mm
                 nx.hv = (s == s0 && g > 0) ? dsim_ckpt_hinv(c, const_cast<float*>(g_ckpt), substeps, g - 1) : nullptr;
                 nx.after = s > 1 ? g_ckpt + (size_t)(s - 2) * dsim_row(c) : nullptr;
             }
-            dsim_bwd_substep(c, ex, s == s0, nx);  // aq / aqd (== aqn / aqdn, same LDS words) now belong to substep s - 1
+            if (g_lit && s == 0)
+                ex.fire([&](int lane) {
+                    for (int k = lane; k < nq; k += Exec::NL) g_lit[k] = WF(aqn)[k];
+                    for (int k = lane; k < nd; k += Exec::NL) g_lit[nq + k] = WF(aqdn)[k];
+                });
+            dsim_bwd_substep(c, ex, s == s0, nx, (g_lit && s == 0) ? g_lit + nq + nd : nullptr);  // aq / aqd (== aqn / aqdn, same LDS words) now belong to substep s - 1
         }
     }
     ex.run([&](int lane) {

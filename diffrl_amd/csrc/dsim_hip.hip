@@ -27,6 +27,8 @@
 #define DSIM_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 #include "dsim_core.hpp"
+#define DSIM_LIT_FN __device__ inline
+#include "dsim_literal.hpp"
 #ifdef DSIM_STATIC_LAYOUTS_FILE   // (python -m diffrl_amd.specialise --header-out: a generated header outside the tree)
 #include DSIM_STATIC_LAYOUTS_FILE
 #else
@@ -810,7 +812,7 @@ __global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1)), DSIM_WIDE_WAV
                                                            const float* __restrict__ mact,
                                                            const float* __restrict__ gq_out,
                                                            const float* __restrict__ gqd_out, float* gq_in,
-                                                           float* gqd_in, float* gact, float* gmact) {
+                                                           float* gqd_in, float* gact, float* gmact, float* lit) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int e = dsim_env_index<MODE>();
     if (e >= k.n_envs) return;
@@ -819,7 +821,35 @@ __global__ __launch_bounds__((DSIM_NL * NW * (MODE == 1 ? 2 : 1)), DSIM_WIDE_WAV
     const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
     dsim_sim_step_backward(c, ex, k.substeps, k.mm_freq, ckpt + (size_t)e * k.ckpt_stride, act + e * nd,
                            M ? mact + e * M : nullptr, gq_out + e * nq, gqd_out + e * nd, gq_in + e * nq,
-                           gqd_in + e * nd, gact ? gact + e * nd : nullptr, (gmact && M) ? gmact + e * M : nullptr);
+                           gqd_in + e * nd, gact ? gact + e * nd : nullptr, (gmact && M) ? gmact + e * M : nullptr,
+                           lit ? lit + (size_t)e * (nq + nd + nd * nd) : nullptr);
+}
+
+// dsim_step_backward_literal, second launch: gq_in[quaternion block of joint j] += rho_j q_j (dsim_literal.hpp).  One thread per
+// (environment, link); threads of links without a quaternion joint leave at once.  Run-time layout for every model.
+// row_words: floats of one substep's checkpoint row in the model's checkpoint mode (both modes start a row with q, qd).
+__global__ __launch_bounds__(64) void dsim_literal_radial_kernel(KCommonT<DsimOff, DsimDims> k, int row_words,
+                                                                  const float* __restrict__ ckpt, const float* __restrict__ act,
+                                                                  const float* __restrict__ mact, const float* __restrict__ lit,
+                                                                  float* gq_in) {
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x), L = k.d.L;
+    const int e = t / L, i = t - e * L;
+    if (e >= k.n_envs) return;
+    dsim_lit::Consts c;
+    c.cb = k.cblob;
+    c.o = k.o;
+    c.d = k.d;
+    const int type = c.I(k.o.jtype, i);
+    if (type != DSIM_JOINT_BALL && type != DSIM_JOINT_FREE) return;
+    const size_t nq = k.d.nq, nd = k.d.nd, M = k.d.M;
+    const float* row = ckpt + (size_t)e * k.ckpt_stride;                  // the first substep's row: (q, qd) as handed in
+    const float* hinv = row + (size_t)k.substeps * (size_t)row_words;      // the first group's H^-1
+    const float* l = lit + (size_t)e * (nq + nd + nd * nd);
+    // (the arrays of a row are padded to 16 bytes each: qd starts at its layout offset, not at nq)
+    const float rho = dsim_lit::radial(c, row, row + (k.o.qd - k.o.q), act + e * nd, M ? mact + e * M : nullptr, k.h, hinv, l, l + nq, l + nq + nd, i);
+    const int qs = c.I(k.o.qstart, i) + (type == DSIM_JOINT_FREE ? 3 : 0);
+    float* g = gq_in + (size_t)e * nq + qs;
+    for (int j = 0; j < 4; ++j) g[j] += rho * row[qs + j];
 }
 
 template <class O, class D, int NW, bool LEAN, int MODE>
@@ -1247,7 +1277,7 @@ int make_spec(const dsim_model* m, const dsim_env_spec* e, DsimEnvSpec& sp) {
 extern "C" {
 
 const char* dsim_last_error(void) { return g_err.c_str(); }
-int dsim_version(void) { return 106; }
+int dsim_version(void) { return 107; }
 
 int dsim_model_create(const dsim_model_desc* desc, dsim_model** out) {
     if (!desc || !out) return fail(DSIM_ERR_INVALID, "null argument");
@@ -1440,9 +1470,9 @@ int dsim_step_forward(const dsim_model* m, int n_envs, const float* q_in, const 
     });
 }
 
-int dsim_step_backward(const dsim_model* m, int n_envs, const float* ckpt, const float* act, const float* muscle_act,
-                       float dt, int substeps, int mm_freq, const float* gq_out, const float* gqd_out, float* gq_in,
-                       float* gqd_in, float* gact, float* gmuscle_act, void* hip_stream) {
+static int step_backward(const dsim_model* m, int n_envs, const float* ckpt, const float* act, const float* muscle_act,
+                         float dt, int substeps, int mm_freq, const float* gq_out, const float* gqd_out, float* gq_in,
+                         float* gqd_in, float* gact, float* gmuscle_act, float* lit, void* hip_stream) {
     int rc = check_common(m, n_envs, dt, substeps, mm_freq);
     if (rc) return rc;
     if (!ckpt || !act || !gq_out || !gqd_out || !gq_in || !gqd_in)
@@ -1457,11 +1487,43 @@ int dsim_step_backward(const dsim_model* m, int n_envs, const float* ckpt, const
             constexpr int MODE = decltype(mode_c)::value, EPB = MODE == DSIM_MODE_PAIR ? 2 : 1;
             hipLaunchKernelGGL((dsim_bwd_kernel<decltype(o), decltype(d), NW, LEAN, MODE>), dim3((n_envs + EPB - 1) / EPB),
                            dim3(DSIM_NL * NW * (MODE == DSIM_MODE_HELPER ? 2 : 1)), ((size_t)m->lay.o.total_words * EPB - (size_t)m->lay.o.const_words * (EPB - 1)) * 4, st, k, ckpt, act, muscle_act, gq_out, gqd_out, gq_in, gqd_in,
-                           gact, gmuscle_act);
+                           gact, gmuscle_act, lit);
             return 0;
         });
         return launched("launch dsim_bwd_kernel");
     });
+}
+
+int dsim_step_backward(const dsim_model* m, int n_envs, const float* ckpt, const float* act, const float* muscle_act,
+                       float dt, int substeps, int mm_freq, const float* gq_out, const float* gqd_out, float* gq_in,
+                       float* gqd_in, float* gact, float* gmuscle_act, void* hip_stream) {
+    return step_backward(m, n_envs, ckpt, act, muscle_act, dt, substeps, mm_freq, gq_out, gqd_out, gq_in, gqd_in, gact, gmuscle_act,
+                         nullptr, hip_stream);
+}
+
+int64_t dsim_literal_scratch_floats(const dsim_model* m) {
+    if (!m) return 0;
+    const int64_t nq = m->lay.d.nq, nd = m->lay.d.nd;
+    return nq + nd + nd * nd;
+}
+
+int dsim_step_backward_literal(const dsim_model* m, int n_envs, const float* ckpt, const float* act, const float* muscle_act,
+                               float dt, int substeps, int mm_freq, const float* gq_out, const float* gqd_out, float* gq_in,
+                               float* gqd_in, float* gact, float* gmuscle_act, float* scratch, void* hip_stream) {
+    if (!m) return fail(DSIM_ERR_INVALID, "null model");
+    if (!scratch) return fail(DSIM_ERR_INVALID, "null scratch (n_envs x dsim_literal_scratch_floats(m) floats)");
+    if (m->lay.d.L > DSIM_LIT_LMAX || m->lay.d.nd > DSIM_LIT_NDMAX)
+        return fail(DSIM_ERR_LIMIT, "dsim_step_backward_literal handles models of up to " + std::to_string(DSIM_LIT_LMAX) + " links and " +
+                                        std::to_string(DSIM_LIT_NDMAX) + " dofs");
+    int rc = step_backward(m, n_envs, ckpt, act, muscle_act, dt, substeps, mm_freq, gq_out, gqd_out, gq_in, gqd_in, gact, gmuscle_act,
+                           scratch, hip_stream);
+    if (rc) return rc;
+    if ((m->lay.d.tmask & (DSIM_TM(DSIM_JOINT_BALL) | DSIM_TM(DSIM_JOINT_FREE))) == 0) return DSIM_OK;   // no quaternion coordinates
+    auto k = make_k(m, m->lay.o, m->lay.d, n_envs, dt, substeps, mm_freq);
+    const long long threads = (long long)n_envs * m->lay.d.L;
+    hipLaunchKernelGGL(dsim_literal_radial_kernel, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(hip_stream), k,
+                       m->row_words(), ckpt, act, muscle_act, scratch, gq_in);
+    return launched("launch dsim_literal_radial_kernel");
 }
 
 int dsim_env_step_forward(const dsim_model* m, const dsim_env_spec* env, int n_envs, const float* q_in,

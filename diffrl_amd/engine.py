@@ -175,7 +175,9 @@ class Engine:
             raise capi.DsimError("checkpoint of shape %s does not match this model / step geometry (%d floats per environment "
                                  "in '%s' mode on %s, contiguous rows)" % (tuple(ckpt.shape), words, self.ckpt_mode, self.device))
 
-    def backward(self, ckpt, act, mact, dt, substeps, mm_freq, gq_out, gqd_out):
+    def backward(self, ckpt, act, mact, dt, substeps, mm_freq, gq_out, gqd_out, literal=False):
+        """literal: dsim_step_backward_literal -- the quaternion blocks of the returned gq carry the component along the quaternion
+        that the reference's literal adjoint has (one more small launch; default: the wrench form, no such component)"""
         self._check_ckpt(ckpt, substeps, mm_freq)
         n = ckpt.shape[0]
         gq_out = gq_out.contiguous()
@@ -186,10 +188,17 @@ class Engine:
         gm = torch.empty(n * self.n_muscles, dtype=torch.float32, device=self.device) if self.n_muscles else None
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            self._ck(self._lib.dsim_step_backward(self._h, n, _ptr(ckpt), _ptr(act),
-                                                    _ptr(mact) if self.n_muscles else None, C.c_float(dt), substeps,
-                                                    mm_freq, _ptr(gq_out), _ptr(gqd_out), _ptr(gq), _ptr(gqd),
-                                                    _ptr(gact), _ptr(gm), st))
+            if literal:
+                scratch = torch.empty((n, int(self._lib.dsim_literal_scratch_floats(self._h))), dtype=torch.float32, device=self.device)
+                self._ck(self._lib.dsim_step_backward_literal(self._h, n, _ptr(ckpt), _ptr(act),
+                                                                _ptr(mact) if self.n_muscles else None, C.c_float(dt), substeps,
+                                                                mm_freq, _ptr(gq_out), _ptr(gqd_out), _ptr(gq), _ptr(gqd),
+                                                                _ptr(gact), _ptr(gm), _ptr(scratch), st))
+            else:
+                self._ck(self._lib.dsim_step_backward(self._h, n, _ptr(ckpt), _ptr(act),
+                                                        _ptr(mact) if self.n_muscles else None, C.c_float(dt), substeps,
+                                                        mm_freq, _ptr(gq_out), _ptr(gqd_out), _ptr(gq), _ptr(gqd),
+                                                        _ptr(gact), _ptr(gm), st))
         return gq, gqd, gact, gm
 
 
@@ -340,7 +349,8 @@ class SimStep(torch.autograd.Function):
             gq_out = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=ckpt.device)
         if gqd_out is None:
             gqd_out = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=ckpt.device)
+        from .dflex import config
         gq, gqd, gact, gm = e.backward(ckpt, act, mact if ctx.has_mact else None, ctx.dt, ctx.substeps, ctx.mm_freq,
-                                       gq_out, gqd_out)
+                                       gq_out, gqd_out, literal=config.literal_quat_grad)
         return (None, None, None, None, gq.view(ctx.shapes[0]), gqd.view(ctx.shapes[1]), gact.view(ctx.shapes[2]),
                 gm.view(ctx.shapes[3]) if ctx.has_mact else None)

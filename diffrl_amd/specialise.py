@@ -190,7 +190,7 @@ def source_hash():
     """hash of the kernel sources a library is built from (the layout tables excepted: a user library brings its own)"""
     import hashlib
     h = hashlib.sha1()
-    for f in ("dsim_core.hpp", "dsim_hip.hip", "dsim_math.hpp", "dsim_layout.hpp", os.path.join("..", "..", "include", "dsim.h")):
+    for f in ("dsim_core.hpp", "dsim_hip.hip", "dsim_math.hpp", "dsim_layout.hpp", "dsim_literal.hpp", os.path.join("..", "..", "include", "dsim.h")):
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:12]
 

@@ -159,24 +159,37 @@ int dsim_model_status(dsim_model* m, int* first_env);
  * adjoint.h:129-190 and vec3.h:204-222.
  *
  * Defined on unit quaternions only, like the forward call whose checkpoint it consumes (precondition at dsim_step_forward).
- * ONE STATED DEVIATION from what the reference's SimulateFunc.backward (sim.py:2127-2154) returns: for every quaternion
- * block of joint_q (free joint: q[cs+3 .. cs+6], ball joint: q[cs .. cs+3]) gq_in has NO component along the quaternion
- * itself.  The reference differentiates its rotation formulas literally (quat.h:232-288 adj_mul / adj_rotate,
- * spatial.h:740-798), also in the direction in which |quat| changes, where those formulas are not rotations; that "radial"
- * component depends on how mathematically identical formulas happen to be written, is annihilated by the integrator's
- * quaternion normalisation (sim.py:1552, 1616) in every upstream propagation -- gradients of rollouts w.r.t. actions are
- * unaffected and match the reference as they stand -- and is exactly zero here, where a pose cotangent is a world-frame wrench
- * (DESIGN.md section 3).  So: gq_in == reference's gq_in minus, per quaternion block, (u . g_ref) u with u = quat / |quat|;
- * every other output (all non-quaternion coordinates of gq_in, gqd_in, gact, gmuscle_act) equals the reference's to the fp32
- * tolerance.  Size of the dropped part on the reference recordings: 32 % / 16 % / 8 % of max |gq_in| (Ant / Humanoid /
- * SNUHumanoid).  A caller that needs the reference's literal value at this boundary -- none of the reference's algorithms does -- cannot
- * get it from this library.  tests/test_gpu_parity.py::test_unprojected_gq_differs_from_the_reference_by_its_radial_part_only
- * asserts the three statements above on the HIP kernels' raw output. */
+ * QUATERNION COORDINATES, TWO FORMS.  For every quaternion block of joint_q (free joint: q[cs+3 .. cs+6], ball joint:
+ * q[cs .. cs+3]) the reference's SimulateFunc.backward (sim.py:2127-2154) returns a cotangent WITH a component along the
+ * quaternion itself: it differentiates its rotation formulas literally (quat.h:232-288 adj_mul / adj_rotate,
+ * spatial.h:740-798), also in the direction in which |quat| changes, where those formulas are not rotations.  That "radial"
+ * component is annihilated by the integrator's quaternion normalisation (sim.py:1552, 1616) in every upstream propagation --
+ * gradients of rollouts w.r.t. actions do not depend on it -- and the adjoint kernels, where a pose cotangent is a world-frame
+ * wrench, do not produce it:
+ *   dsim_step_backward           gq_in == reference's gq_in minus, per quaternion block, (u . g_ref) u with u = quat / |quat|
+ *                                (32 % / 16 % / 8 % of max |gq_in| on the Ant / Humanoid / SNUHumanoid recordings); every other
+ *                                output (all non-quaternion coordinates of gq_in, gqd_in, gact, gmuscle_act) equals the
+ *                                reference's to the fp32 tolerance.  The hot path: what DFlexEnv.step and SHAC use.
+ *   dsim_step_backward_literal   gq_in == reference's gq_in, quaternion blocks included (measured against the reference's
+ *                                recordings, UN-projected: 1.1e-6 / 5.8e-6 / 7.4e-6 max-norm relative, Ant / Humanoid /
+ *                                SNUHumanoid).  The same adjoint launch + one small launch that evaluates the radial component
+ *                                rho_j = dL/d eps_j under q_j -> (1 + eps_j) q_j in forward mode through the reference's literal
+ *                                formulas of the first substep (csrc/dsim_literal.hpp) and adds rho_j q_j.  scratch:
+ *                                [N][dsim_literal_scratch_floats(m)] floats of device memory the two launches hand over in
+ *                                (the first substep's output cotangents and the first mass-matrix group's cotangent).
+ *                                Models of up to 24 links / 28 dofs (DSIM_ERR_LIMIT beyond).
+ * tests/test_gpu_parity.py asserts both statements on the HIP kernels' raw output. */
 int dsim_step_backward(const dsim_model* m, int n_envs,
                        const float* ckpt, const float* act, const float* muscle_act,
                        float dt, int substeps, int mm_freq,
                        const float* gq_out, const float* gqd_out,
                        float* gq_in, float* gqd_in, float* gact, float* gmuscle_act, void* hip_stream);
+int64_t dsim_literal_scratch_floats(const dsim_model* m);
+int dsim_step_backward_literal(const dsim_model* m, int n_envs,
+                               const float* ckpt, const float* act, const float* muscle_act,
+                               float dt, int substeps, int mm_freq,
+                               const float* gq_out, const float* gqd_out,
+                               float* gq_in, float* gqd_in, float* gact, float* gmuscle_act, float* scratch, void* hip_stream);
 
 /* Derived body transforms of a joint state: X_sc[N][L][7] (link frames in the world, what eval_rigid_fk writes to
  * State.body_X_sc, sim.py:1638-1678) and, if X_sm is not NULL, X_sm[N][L][7] = X_sc o X_cm (State.body_X_sm: the bodies'

@@ -12,6 +12,7 @@
 
 #define DSIM_FN static inline
 #include "../../diffrl_amd/csrc/dsim_core.hpp"
+#include "../../diffrl_amd/csrc/dsim_literal.hpp"
 #ifdef DSIM_STATIC_LAYOUTS_FILE   // (a generated header with user models: tests/inject/dsim_static_layouts_user.hpp, see the Makefile)
 #include DSIM_STATIC_LAYOUTS_FILE
 #else
@@ -333,6 +334,63 @@ extern "C" int dsim_emu_step_backward(const dsim_model_desc* m, int n_envs, cons
                                gq_in + (size_t)e * nq, gqd_in + (size_t)e * nd, gact ? gact + (size_t)e * nd : nullptr,
                                (gmact && M) ? gmact + (size_t)e * M : nullptr);
     }
+    return 0;
+}
+
+// dsim_step_backward_literal on the host: the adjoint phases with the export of (gq_1, gqd_1, adj H), then the forward-mode
+// tangent of the first substep (diffrl_amd/csrc/dsim_literal.hpp) link by link, exactly what dsim_literal_radial_kernel does
+extern "C" int dsim_emu_step_backward_literal(const dsim_model_desc* m, int n_envs, const float* ckpt, const float* act,
+                                              const float* mact, float dt, int substeps, int mm_freq, const float* gq_out,
+                                              const float* gqd_out, float* gq_in, float* gqd_in, float* gact, float* gmact,
+                                              float* lit_out) {   // lit_out: [n_envs][nq + nd + nd * nd] or null (tests)
+    DsimLayout lay;
+    if (!dsim_build_layout(*m, lay).empty()) return -1;
+    const int nq = lay.d.nq, nd = lay.d.nd, M = lay.d.M, L = lay.d.L;
+    if (L > DSIM_LIT_LMAX || nd > DSIM_LIT_NDMAX) return -4;
+    HostExec ex;
+    const size_t stride = dsim_ckpt_words(lay.o.save_words, nq, nd, substeps, mm_freq);
+    std::vector<float> lit((size_t)nq + nd + (size_t)nd * nd);
+    dsim_lit::Consts cc;
+    cc.cb = lay.cblob.data();
+    cc.o = lay.o;
+    cc.d = lay.d;
+    for (int e = 0; e < n_envs; ++e) {
+        std::vector<float> lds;
+        DsimCtx c;
+        make_ctx(lay, lds, c, dt / float(substeps));
+        const float* row = ckpt + (size_t)e * stride;
+        dsim_sim_step_backward(c, ex, substeps, mm_freq, row, act + (size_t)e * nd, M ? mact + (size_t)e * M : nullptr,
+                               gq_out + (size_t)e * nq, gqd_out + (size_t)e * nd, gq_in + (size_t)e * nq, gqd_in + (size_t)e * nd,
+                               gact ? gact + (size_t)e * nd : nullptr, (gmact && M) ? gmact + (size_t)e * M : nullptr, lit.data());
+        const float* hinv = row + (size_t)substeps * lay.o.save_words;
+        if (lit_out) memcpy(lit_out + (size_t)e * lit.size(), lit.data(), sizeof(float) * lit.size());
+        for (int i = 0; i < L; ++i) {
+            const int type = cc.I(lay.o.jtype, i);
+            if (type != DSIM_JOINT_BALL && type != DSIM_JOINT_FREE) continue;
+            const float rho = dsim_lit::radial(cc, row, row + (lay.o.qd - lay.o.q), act + (size_t)e * nd, M ? mact + (size_t)e * M : nullptr,
+                                               dt / float(substeps), hinv, lit.data(), lit.data() + nq, lit.data() + nq + nd, i);
+            const int qs = cc.I(lay.o.qstart, i) + (type == DSIM_JOINT_FREE ? 3 : 0);
+            for (int j = 0; j < 4; ++j) gq_in[(size_t)e * nq + qs + j] += rho * row[qs + j];
+        }
+    }
+    return 0;
+}
+
+// test helper: tangents (d tau [nd], d qdd [nd], d H [nd][nd]) of the first substep along the radial direction of link `jl`'s quaternion
+extern "C" int dsim_emu_literal_tangents(const dsim_model_desc* m, const float* q, const float* qd, const float* act, const float* mact,
+                                         float h, const float* hinv, int jl, float* out, const float* lit, float* rho_out) {
+    DsimLayout lay;
+    if (!dsim_build_layout(*m, lay).empty()) return -1;
+    const int nq = lay.d.nq, nd = lay.d.nd;
+    dsim_lit::Consts cc;
+    cc.cb = lay.cblob.data();
+    cc.o = lay.o;
+    cc.d = lay.d;
+    std::vector<float> z((size_t)nq + nd + (size_t)nd * nd, 0.f);
+    for (int k = 0; k < 2 * nd + nd * nd; ++k) out[k] = 0.f;
+    const float* l = lit ? lit : z.data();
+    const float rho = dsim_lit::radial(cc, q, qd, act, mact, h, hinv, l, l + nq, l + nq + nd, jl, out);
+    if (rho_out) *rho_out = rho;
     return 0;
 }
 

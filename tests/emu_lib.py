@@ -110,15 +110,18 @@ def emu_forward(t, q, qd, act, mact, dt, substeps, mm_freq, want_ckpt=False):
     return qo, qdo, ck
 
 
-def emu_backward(t, ckpt, act, mact, dt, substeps, mm_freq, gq_out, gqd_out):
+def emu_backward(t, ckpt, act, mact, dt, substeps, mm_freq, gq_out, gqd_out, literal=False, lit_out=None):
+    """literal: dsim_step_backward_literal -- the quaternion blocks of gq carry the reference's radial component too"""
     desc, keep = make_desc(t)
     N = act.shape[0]
     ckpt, act, gq_out, gqd_out = _c(ckpt), _c(act), _c(gq_out), _c(gqd_out)
     mact = _c(mact) if mact is not None else np.zeros((N, 0), np.float32)
     gq, gqd, ga, gm = np.zeros_like(gq_out), np.zeros_like(gqd_out), np.zeros_like(act), np.zeros_like(mact)
-    rc = emu().dsim_emu_step_backward(C.byref(desc), C.c_int(N), _p(ckpt), _p(act), _p(mact), C.c_float(dt),
-                                      C.c_int(substeps), C.c_int(mm_freq), _p(gq_out), _p(gqd_out), _p(gq), _p(gqd),
-                                      _p(ga), _p(gm))
+    fn = emu().dsim_emu_step_backward_literal if literal else emu().dsim_emu_step_backward
+    extra = (_p(lit_out),) if literal else ()
+    rc = fn(C.byref(desc), C.c_int(N), _p(ckpt), _p(act), _p(mact), C.c_float(dt),
+            C.c_int(substeps), C.c_int(mm_freq), _p(gq_out), _p(gqd_out), _p(gq), _p(gqd),
+            _p(ga), _p(gm), *extra)
     assert rc == 0
     return dict(gq=gq, gqd=gqd, gact=ga, gmact=gm)
 

@@ -125,3 +125,32 @@ def test_forward_is_defined_on_unit_quaternions_only():
     assert 1e-3 < err[1.001] < 2e-2                # measured 5.3e-3
     assert 1e-2 < err[1.01] < 0.2                  # measured 4.7e-2
     assert err[1.0] < err[1.00005] < err[1.001] < err[1.01]
+
+
+@pytest.mark.parametrize("env", ["ant", "humanoid", "snu"])
+def test_literal_backward_on_the_host_harness_equals_the_reference_unprojected(env):
+    """dsim_step_backward_literal, host side: the adjoint phases hand (gq_1, gqd_1, adj H) to the forward-mode tangent of the first
+    substep (diffrl_amd/csrc/dsim_literal.hpp), which adds the component along each quaternion that the reference's literal
+    adjoint has (quat.h:232-288, spatial.h:740-798).  UN-projected against the reference's recordings (1e-3 stated; measured
+    1.1e-6 / 5.8e-6 / 7.4e-6) and, with random cotangents and a step whose first mass-matrix group ends inside the step, against
+    the oracle's reference-order adjoint."""
+    from emu_lib import emu_backward, emu_forward
+    from oracle_lib import golden, oracle_backward, relerr, template_from_golden
+    t, g = template_from_golden(env), golden(env + "_step")
+    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
+    mact = g.get("muscle_act_in")
+    qo, qdo, ck = emu_forward(t, g["q_in"], g["qd_in"], g["act_in"], mact, dt, S, mm, want_ckpt=True)
+    plain = emu_backward(t, ck, g["act_in"], mact, dt, S, mm, g["gq_out"], g["gqd_out"])
+    lit = emu_backward(t, ck, g["act_in"], mact, dt, S, mm, g["gq_out"], g["gqd_out"], literal=True)
+    assert relerr(lit["gq"], g["gq_in"]) < 1e-4 and relerr(plain["gq"], g["gq_in"]) > 0.03
+    for k in ("gqd", "gact", "gmact"):
+        assert np.array_equal(lit[k], plain[k])
+    rng = np.random.default_rng(1)
+    gq, gqd = rng.normal(0, 1, g["q_in"].shape).astype(np.float32), rng.normal(0, 1, g["qd_in"].shape).astype(np.float32)
+    n = min(4, g["q_in"].shape[0])
+    for S2, mm2 in ((1, 1), (3, 2)):
+        dt2 = dt * S2 / S
+        o = oracle_backward(t, g["q_in"][:n], g["qd_in"][:n], g["act_in"][:n], mact[:n] if mact is not None else None, dt2, S2, mm2, gq[:n], gqd[:n])
+        qo, qdo, ck = emu_forward(t, g["q_in"][:n], g["qd_in"][:n], g["act_in"][:n], mact[:n] if mact is not None else None, dt2, S2, mm2, want_ckpt=True)
+        r = emu_backward(t, ck, g["act_in"][:n], mact[:n] if mact is not None else None, dt2, S2, mm2, gq[:n], gqd[:n], literal=True)
+        assert relerr(r["gq"], o["gq"]) < 1e-3, (S2, mm2)

@@ -77,6 +77,93 @@ def test_unprojected_gq_differs_from_the_reference_by_its_radial_part_only(env, 
     assert rad_ref > 0.01      # (the recordings do exercise it)
 
 
+@pytest.mark.parametrize("env", ["ant", "humanoid", "snu"])
+def test_literal_backward_equals_the_reference_unprojected(env, dev):
+    """SURVEY 8(a) row SimulateFunc + Tape reverse sweep, literally: dsim_step_backward_literal (Engine.backward(literal=True),
+    dflex.config.literal_quat_grad) returns the reference's joint_q cotangent INCLUDING the component along each quaternion
+    (quat.h:232-288, spatial.h:740-798) -- compared with the reference's recording as it stands, no projection anywhere,
+    stated tolerance 1e-3 (measured ~1e-6); the other outputs are those of the plain call, bit for bit"""
+    t, eng = _engine(env, dev)
+    g = golden(env + "_step")
+    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
+    T = lambda a: torch.tensor(a, device=dev).reshape(-1)  # noqa: E731
+    mact = T(g["muscle_act_in"]) if "muscle_act_in" in g else None
+    qo, qdo, ck = eng.forward(T(g["q_in"]), T(g["qd_in"]), T(g["act_in"]), mact, dt, S, mm, True)
+    plain = eng.backward(ck, T(g["act_in"]), mact, dt, S, mm, T(g["gq_out"]), T(g["gqd_out"]))
+    lit = eng.backward(ck, T(g["act_in"]), mact, dt, S, mm, T(g["gq_out"]), T(g["gqd_out"]), literal=True)
+    torch.cuda.synchronize()
+    n = g["q_in"].shape[0]
+    e = relerr(lit[0].cpu().numpy().reshape(n, -1), g["gq_in"])
+    print("%s: un-projected |gq_literal - gq_reference| / max|gq_reference| = %.2e (plain call: %.2e)"
+          % (env, e, relerr(plain[0].cpu().numpy().reshape(n, -1), g["gq_in"])))
+    assert e < 1e-3
+    for a, b in zip(plain[1:], lit[1:]):
+        assert (a is None and b is None) or torch.equal(a, b)
+    # the two calls differ in the quaternion blocks only, and there by a multiple of the quaternion
+    d = (lit[0] - plain[0]).cpu().numpy().reshape(n, -1)
+    for i in range(t.n_links):
+        ty, cs = int(t.joint_type[i]), int(t.joint_q_start[i])
+        sl = slice(cs + 3, cs + 7) if ty == 4 else (slice(cs, cs + 4) if ty == 2 else None)
+        if sl is None:
+            continue
+        u = g["q_in"][:, sl]
+        rho = (d[:, sl] * u).sum(1, keepdims=True)
+        assert np.abs(d[:, sl] - rho * u).max() <= 1e-5 * max(1.0, np.abs(d[:, sl]).max())
+        d[:, sl] = 0.0
+    assert np.abs(d).max() == 0.0
+
+
+@pytest.mark.parametrize("env,n", [("ant", 96), ("humanoid", 12), ("snu", 8)])
+def test_literal_backward_vs_oracle_batch(env, n, dev):
+    """seeded perturbations of the golden states, random cotangents, a step geometry whose first mass-matrix group is shorter than
+    the step: the literal call against the scalar oracle's reference-order adjoint, un-projected"""
+    t, eng = _engine(env, dev)
+    g = golden(env + "_step")
+    S, mm, dt = 6, 4, 6 * float(g["dt"]) / int(g["substeps"])
+    rng = np.random.default_rng(9)
+    idx = rng.integers(0, g["q_in"].shape[0], n)
+    q = g["q_in"][idx] + rng.normal(0, 0.01, (n, t.n_q)).astype(np.float32)
+    for i in range(t.n_links):
+        ty, cs = int(t.joint_type[i]), int(t.joint_q_start[i])
+        sl = slice(cs + 3, cs + 7) if ty == 4 else (slice(cs, cs + 4) if ty == 2 else None)
+        if sl is not None:
+            q[:, sl] /= np.linalg.norm(q[:, sl], axis=1, keepdims=True)
+    qd = g["qd_in"][idx] + rng.normal(0, 0.05, (n, t.n_qd)).astype(np.float32)
+    act = g["act_in"][idx] * rng.uniform(0.5, 1.0, (n, 1)).astype(np.float32)
+    mact = g["muscle_act_in"][idx] * rng.uniform(0.5, 1.0, (n, 1)).astype(np.float32) if "muscle_act_in" in g else None
+    gq, gqd = rng.normal(0, 1, (n, t.n_q)).astype(np.float32), rng.normal(0, 1, (n, t.n_qd)).astype(np.float32)
+    o = oracle_backward(t, q, qd, act, mact, dt, S, mm, gq, gqd)
+    T = lambda a: torch.tensor(a, device=dev).reshape(-1)  # noqa: E731
+    qo, qdo, ck = eng.forward(T(q), T(qd), T(act), T(mact) if mact is not None else None, dt, S, mm, True)
+    r = eng.backward(ck, T(act), T(mact) if mact is not None else None, dt, S, mm, T(gq), T(gqd), literal=True)
+    torch.cuda.synchronize()
+    assert relerr(r[0].cpu().numpy().reshape(n, -1), o["gq"]) < 1e-3
+    assert relerr(r[1].cpu().numpy().reshape(n, -1), o["gqd"]) < 1e-3
+
+
+def test_simstep_honours_literal_quat_grad(dev):
+    """dflex.config.literal_quat_grad: SemiImplicitIntegrator.forward's autograd node returns the literal cotangent"""
+    from diffrl_amd.dflex import config
+    from diffrl_amd.engine import SimStep
+    t, eng = _engine("ant", dev)
+    g = golden("ant_step")
+    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
+    n = g["q_in"].shape[0]
+    out = {}
+    for flag in (False, True):
+        config.literal_quat_grad = flag
+        try:
+            q = torch.tensor(g["q_in"], device=dev).reshape(-1).requires_grad_(True)
+            qd = torch.tensor(g["qd_in"], device=dev).reshape(-1).requires_grad_(True)
+            a = torch.tensor(g["act_in"], device=dev).reshape(-1).requires_grad_(True)
+            qo, qdo = SimStep.apply(eng, dt, S, mm, q, qd, a, None)
+            ((qo * torch.tensor(g["gq_out"], device=dev).reshape(-1)).sum() + (qdo * torch.tensor(g["gqd_out"], device=dev).reshape(-1)).sum()).backward()
+            out[flag] = q.grad.cpu().numpy().reshape(n, -1)
+        finally:
+            config.literal_quat_grad = False
+    assert relerr(out[True], g["gq_in"]) < 1e-3 and relerr(out[False], g["gq_in"]) > 0.05
+
+
 @pytest.mark.parametrize("env,n", [("cartpole", 256), ("ant", 192), ("humanoid", 24), ("snu", 16)])
 def test_step_vs_oracle_batch(env, n, dev):
     """seeded perturbations of the golden states; sizes the scalar oracle finishes in seconds"""

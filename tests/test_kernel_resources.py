@@ -29,9 +29,13 @@ def kernels():
 
 
 def test_no_kernel_uses_scratch_memory(kernels):
-    bad = [(k["name"][:90], k["private_segment_fixed_size"]) for k in kernels if k.get("private_segment_fixed_size", 0) != 0]
+    # (dsim_literal_radial_kernel is the one exception by design: the opt-in second launch of dsim_step_backward_literal, plain
+    # sequential code of ONE substep per thread on local arrays -- a correctness path, csrc/dsim_literal.hpp -- not a step kernel)
+    hot = [k for k in kernels if "dsim_literal_radial_kernel" not in k["name"]]
+    assert len(hot) == len(kernels) - 1
+    bad = [(k["name"][:90], k["private_segment_fixed_size"]) for k in hot if k.get("private_segment_fixed_size", 0) != 0]
     assert not bad, bad
-    assert all(k.get("vgpr_spill_count", 0) == 0 for k in kernels)
+    assert all(k.get("vgpr_spill_count", 0) == 0 for k in hot)
 
 
 def test_helper_kernels_fit_two_waves_per_simd(kernels):
