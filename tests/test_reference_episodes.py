@@ -18,8 +18,11 @@ EP_RULES = {"ant": (True, False), "humanoid": (True, True), "snu": (True, True),
 TERM_H = {"ant": 0.27, "humanoid": 0.74, "snu": 0.46, "hopper": -0.45}
 # sampled environments of the full-size recordings that may need a probed tolerance.  Round 6: gradients recorded for every 2nd
 # Humanoid environment (512 sampled; round 5: every 8th, 8 of 128 probed) and every 4th SNUHumanoid environment (128 sampled;
-# round 5: every 16th, 1 of 32 probed); budgets = the counts measured at the shipped kernels plus a margin (PLACEHOLDER until measured)
-FULLSIZE_PROBE_BUDGET = {"humanoid": 48, "snu": 12}
+# round 5: every 16th, 1 of 32 probed).  Measured at the shipped kernels: Humanoid 37 of 512 (7.2 %; the same 6.25 % of round 5's
+# sample within counting noise; largest error 9.7e-3 with a reference-order sensitivity of 9.7e-3), SNUHumanoid 6 of 128 (4.7 %);
+# budgets = those counts plus a margin of a fifth (a re-association of the arithmetic may move an environment across a branch
+# boundary; a regression of the adjoint moves ALL of them)
+FULLSIZE_PROBE_BUDGET = {"humanoid": 45, "snu": 8}
 # Ant 1024 x 32 (BASELINE.json configs[1]), gradients of every 2nd environment (512 sampled; round 5 -- every 8th before, where all
 # 128 passed at 1e-3): measured at the shipped kernels 3 of 512 above 1e-3 (4.9e-3, 3.7e-3, 2.7e-3 -- the same three with every
 # division and square root correctly rounded; 15-17 with a one-step v_rsq_f32 in the integrator, which is why it is not used there:
