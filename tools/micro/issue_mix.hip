@@ -61,6 +61,29 @@ template <int MODE> __global__ void k(long long* out, float* sink, int iters, in
             REP32(a = 1.0f / (a * 1.0001f + 2.0f);)
         } else if (MODE == 12) {  // correctly rounded sqrtf
             REP32(a = sqrtf(a * 1.0001f + 2.0f);)
+        } else if (MODE == 13) {  // 4 INDEPENDENT plain FMAs (four accumulators)
+            REP32(asm volatile("v_fma_f32 v40, v40, %1, %2\n v_fma_f32 v41, v41, %1, %2\n v_fma_f32 v42, v42, %1, %2\n v_fma_f32 v43, v43, %1, %2"
+                               : "+v"(a) : "v"(b), "v"(c) : "v40", "v41", "v42", "v43");)
+        } else if (MODE == 14) {  // 4 dependent PACKED FMAs: v_pk_fma_f32 on even-aligned register pairs (8 fp32 FMAs)
+            REP32(asm volatile("v_pk_fma_f32 v[40:41], v[40:41], v[44:45], v[46:47]\n v_pk_fma_f32 v[40:41], v[40:41], v[44:45], v[46:47]\n"
+                               "v_pk_fma_f32 v[40:41], v[40:41], v[44:45], v[46:47]\n v_pk_fma_f32 v[40:41], v[40:41], v[44:45], v[46:47]"
+                               : "+v"(a) : "v"(b), "v"(c) : "v40", "v41", "v44", "v45", "v46", "v47");)
+        } else if (MODE == 15) {  // 4 INDEPENDENT packed FMAs (four accumulator pairs: 8 fp32 FMAs)
+            REP32(asm volatile("v_pk_fma_f32 v[40:41], v[40:41], v[48:49], v[50:51]\n v_pk_fma_f32 v[42:43], v[42:43], v[48:49], v[50:51]\n"
+                               "v_pk_fma_f32 v[44:45], v[44:45], v[48:49], v[50:51]\n v_pk_fma_f32 v[46:47], v[46:47], v[48:49], v[50:51]"
+                               : "+v"(a) : "v"(b), "v"(c) : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51");)
+        } else if (MODE == 16) {  // packed multiply / add, dependent: 2 x (v_pk_mul_f32 + v_pk_add_f32)
+            REP32(asm volatile("v_pk_mul_f32 v[40:41], v[40:41], v[44:45]\n v_pk_add_f32 v[40:41], v[40:41], v[46:47]\n"
+                               "v_pk_mul_f32 v[40:41], v[40:41], v[44:45]\n v_pk_add_f32 v[40:41], v[40:41], v[46:47]"
+                               : "+v"(a) : "v"(b), "v"(c) : "v40", "v41", "v44", "v45", "v46", "v47");)
+        } else if (MODE == 17) {  // packed FMA with a BROADCAST scalar operand (op_sel_hi: both halves take the low register): a * s + b on pairs
+            REP32(asm volatile("v_pk_fma_f32 v[40:41], v[40:41], v[44:45], v[46:47] op_sel_hi:[1,0,1]\n v_pk_fma_f32 v[40:41], v[40:41], v[44:45], v[46:47] op_sel_hi:[1,0,1]\n"
+                               "v_pk_fma_f32 v[40:41], v[40:41], v[44:45], v[46:47] op_sel_hi:[1,0,1]\n v_pk_fma_f32 v[40:41], v[40:41], v[44:45], v[46:47] op_sel_hi:[1,0,1]"
+                               : "+v"(a) : "v"(b), "v"(c) : "v40", "v41", "v44", "v45", "v46", "v47");)
+        } else if (MODE == 18) {  // 2 moves + 1 packed FMA: what packing costs when the operands are NOT already an aligned pair
+            REP32(asm volatile("v_mov_b32 v44, %1\n v_mov_b32 v45, %2\n v_pk_fma_f32 v[40:41], v[40:41], v[44:45], v[46:47]\n"
+                               "v_mov_b32 v44, %1\n v_mov_b32 v45, %2\n v_pk_fma_f32 v[40:41], v[40:41], v[44:45], v[46:47]"
+                               : "+v"(a) : "v"(b), "v"(c) : "v40", "v41", "v44", "v45", "v46", "v47");)
         }
     }
     long long t1 = clock64();
@@ -95,6 +118,12 @@ int main() {
         run<10>("4 x (s_waitcnt lgkmcnt(0), nothing outstanding + v_fma)", blocks, out, sink, iters, 9);
         run<11>("1.0f / x, correctly rounded (+ the v_fma feeding it)", blocks, out, sink, iters, 9);
         run<12>("sqrtf(x), correctly rounded (+ the v_fma feeding it)", blocks, out, sink, iters, 9);
+        run<13>("4 INDEPENDENT v_fma (four accumulators)", blocks, out, sink, iters, 9);
+        run<14>("4 dependent v_pk_fma_f32 (8 fp32 FMAs on aligned pairs)", blocks, out, sink, iters, 9);
+        run<15>("4 INDEPENDENT v_pk_fma_f32 (8 fp32 FMAs)", blocks, out, sink, iters, 9);
+        run<16>("2 x (v_pk_mul_f32 + v_pk_add_f32), dependent", blocks, out, sink, iters, 9);
+        run<17>("4 dependent v_pk_fma_f32 with a broadcast operand (op_sel_hi)", blocks, out, sink, iters, 9);
+        run<18>("2 x (2 v_mov into a pair + v_pk_fma_f32): packing from scattered registers", blocks, out, sink, iters, 9);
     }
     return 0;
 }
