@@ -390,7 +390,7 @@ def compact_line(full, side_file=None):
                                "sample": (cb.get("sample") or "")[:120],
                                "single_thread": (cb.get("single_thread") or {}).get("value"),
                                "reference_recorded": (cb.get("reference_recorded") or {}).get("value"),
-                               "reference_unavailable": cb.get("reference_unavailable")}
+                               "reference_unavailable": (cb.get("reference_unavailable") or None) and cb["reference_unavailable"][:160]}
     if full.get("other_configs"):
         oc = []
         for o in full["other_configs"]:

@@ -28,9 +28,15 @@ sys.path.insert(0, HERE)
 
 # the survey's measurement of the reference's own CPU path in the build container
 REFERENCE_RECORDED = {"ant": {"value": 696.5, "unit": "env-steps/s", "cores": 8, "kernel_threads": 1,
-                              "source": "BASELINE.md section 2: reference CPU path, Ant 1024 envs x H=32 fwd+bwd, 8 vCPU container"}}
+                              "source": "BASELINE.md section 2: reference CPU path, Ant 1024 envs x H=32 fwd+bwd, 8 vCPU container",
+                              # this script's own reference leg in the build container, round 6 (bounded sample 256 envs x H=8)
+                              "round6_sample": {"value": 1036.3, "file": "profiles/r06_cpu_baseline_reference.json"}}}
 REF_SAMPLE = {"ant": (256, 8), "humanoid": (32, 4), "snu": (16, 4), "cartpole": (64, 16), "hopper": (256, 8), "cheetah": (256, 8)}
 MM_FREQ = {"ant": 16, "humanoid": 48, "snu": 8, "cartpole": 4, "hopper": 16, "cheetah": 16}
+
+
+def ref_root():
+    return os.environ.get("DIFFRL_REFERENCE", "/root/reference")
 
 
 def port_leg(name, seconds, threads):
@@ -147,6 +153,14 @@ def main():
             out["note"] = note
         if name in REFERENCE_RECORDED:
             out["reference_recorded"] = REFERENCE_RECORDED[name]
+        # why kind is "port" on this box: the reference is a Python package (its kernels are C++ that its own
+        # code generator writes from Python functions at import time, dflex/dflex/adjoint.py:1749-1898); a Python reference may not
+        # travel to the GPU box in any form -- source, bytecode or the .so its generator builds -- and /root/reference does not
+        # exist there.  Where the checkout IS present (the build container) this script times the reference itself (kind
+        # "reference"; profiles/r06_cpu_baseline_reference.json is that run).
+        out["reference_unavailable"] = note or ("no reference checkout on this box (%s): a Python reference cannot travel; its own CPU "
+                                                "path is timed where the checkout exists (profiles/r06_cpu_baseline_reference.json)"
+                                                % ref_root())
     else:
         # the port's figure next to the reference's, same run (half the budget)
         p = port_leg(name, max(2.0, seconds / 2), threads)
