@@ -414,3 +414,35 @@ def test_lean_checkpoint_mode(env, dev):
         if k != "ckpt":
             assert np.array_equal(res["full"][k], res["lean"][k]), k
     assert res["lean"]["ckpt"].shape[1] == words["lean"] < 0.2 * words["full"]
+
+
+@pytest.mark.parametrize("env", ["ant", "snu"])
+def test_literal_backward_in_the_lean_checkpoint_mode(env, dev):
+    """the literal call reads (q, qd) from the head of the first substep's row and the first group's inverse: both checkpoint modes
+    have them at their own row strides -- same result (the adjoint's part bit for bit, the radial part from the same inputs)"""
+    from diffrl_amd.engine import Engine
+    t = template_from_golden(env)
+    g = golden(env + "_step")
+    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
+    T = lambda a: torch.tensor(a, device=dev).reshape(-1)  # noqa: E731
+    mact = T(g["muscle_act_in"]) if "muscle_act_in" in g else None
+    out = {}
+    for mode in ("full", "lean"):
+        eng = Engine(t, dev, ckpt_mode=mode)
+        qo, qdo, ck = eng.forward(T(g["q_in"]), T(g["qd_in"]), T(g["act_in"]), mact, dt, S, mm, True)
+        out[mode] = eng.backward(ck, T(g["act_in"]), mact, dt, S, mm, T(g["gq_out"]), T(g["gqd_out"]), literal=True)[0].cpu().numpy()
+    n = g["q_in"].shape[0]
+    assert relerr(out["lean"].reshape(n, -1), g["gq_in"]) < 1e-3 and relerr(out["full"].reshape(n, -1), out["lean"].reshape(n, -1)) < 1e-6
+
+
+def test_literal_backward_without_quaternion_joints_is_the_plain_call(dev):
+    """a model without free / ball joints has no quaternion coordinates: the second launch is skipped, the outputs are the plain ones"""
+    t, eng = _engine("cartpole", dev)
+    g = golden("cartpole_step")
+    S, mm, dt = int(g["substeps"]), int(g["mm_freq"]), float(g["dt"])
+    T = lambda a: torch.tensor(a, device=dev).reshape(-1)  # noqa: E731
+    qo, qdo, ck = eng.forward(T(g["q_in"]), T(g["qd_in"]), T(g["act_in"]), None, dt, S, mm, True)
+    a = eng.backward(ck, T(g["act_in"]), None, dt, S, mm, T(g["gq_out"]), T(g["gqd_out"]))
+    b = eng.backward(ck, T(g["act_in"]), None, dt, S, mm, T(g["gq_out"]), T(g["gqd_out"]), literal=True)
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(a[:3], b[:3]))
