@@ -291,6 +291,14 @@ def ensure_library(t, cache_dir=None, log=None):
         try:
             if os.path.exists(out):   # another process built it while this one waited
                 return out
+            import time
+            for f in os.listdir(cache_dir):   # half-written libraries of processes that exited while their background compile ran
+                fp = os.path.join(cache_dir, f)
+                if ".so.tmp" in f and time.time() - os.path.getmtime(fp) > 3600:
+                    try:
+                        os.remove(fp)
+                    except OSError:
+                        pass
             header = os.path.join(cache_dir, "dsim_static_layouts_%s.hpp" % name)
             open(header, "w").write(render([(name, t)]))
             tmp = out + ".tmp%d" % os.getpid()
