@@ -13,8 +13,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-# env, environments, (forward, adjoint) launch in ms at round 5
-RECORDED = [("ant", 1024, 0.0524, 0.0529), ("humanoid", 1024, 0.1818, 0.1801), ("snu", 512, 0.2230, 0.2339)]
+# env, environments, (forward, adjoint) launch in ms at round 6 (gpurun_out/r06_bench_final.json; round 5: 0.0524 / 0.0529, 0.1818 / 0.1801,
+# 0.2230 / 0.2339)
+RECORDED = [("ant", 1024, 0.0524, 0.0530), ("humanoid", 1024, 0.1817, 0.1762), ("snu", 512, 0.2211, 0.2329)]
 MARGIN = 1.15
 HEADLINE_FLOOR = 9.2e6   # env-steps/s, Ant 1024 envs x H=32, forward + adjoint through DFlexEnv.step (bench.py's timed submission)
 
