@@ -13,7 +13,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-# env, environments, (forward, adjoint) launch in ms at round 6 (gpurun_out/r06_bench_final.json; round 5: 0.0524 / 0.0529, 0.1818 / 0.1801,
+# env, environments, (forward, adjoint) launch in ms at round 6 (profiles/r06_bench_final.json; round 5: 0.0524 / 0.0529, 0.1818 / 0.1801,
 # 0.2230 / 0.2339)
 RECORDED = [("ant", 1024, 0.0524, 0.0530), ("humanoid", 1024, 0.1817, 0.1762), ("snu", 512, 0.2211, 0.2329)]
 MARGIN = 1.15
