@@ -25,7 +25,7 @@ class Engine:
         half the speed).  True / $DSIM_AUTO_SPECIALISE=1: a kernel set of its own, compiled with hipcc on first use and cached
         next to the library (diffrl_amd.specialise.ensure_library: about a minute, once per model and source version; the
         constructor waits for it).  "background" (the default when None and $DSIM_AUTO_SPECIALISE is unset or "background"): the
-        cached set if there is one; otherwise this Engine runs the generic kernels while a daemon thread compiles the set, and
+        cached set if there is one; otherwise this Engine runs the generic kernels while a detached child process compiles the set, and
         the next Engine of the model picks it up.  False / $DSIM_AUTO_SPECIALISE=0: nothing is compiled or swapped at run time.
         A failed build, a missing hipcc or a library that turns out not to hold the set: a warning, the generic kernels stay."""
         self.template = template

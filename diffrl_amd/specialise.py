@@ -214,43 +214,88 @@ def cached_library(t, cache_dir=None):
         return None
 
 
+class _Job:
+    """a background compile in flight: a thread of this process, or a DETACHED child process (join / is_alive of either)"""
+    def __init__(self, thread=None, proc=None):
+        self.thread, self.proc = thread, proc
+        self.daemon = True
+
+    def is_alive(self):
+        return self.thread.is_alive() if self.thread is not None else self.proc.poll() is None
+
+    def join(self, timeout=None):
+        if self.thread is not None:
+            self.thread.join(timeout)
+        else:
+            try:
+                self.proc.wait(timeout)
+            except subprocess.TimeoutExpired:
+                pass
+
+
+def _spawn_thread(t, key, cache_dir, log):
+    """the compile in a daemon thread of this process (tests; dies with the process)"""
+    import threading
+
+    def work():
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("always")
+            try:
+                ensure_library(t, cache_dir, log)
+            except Exception as ex:   # (a background convenience must never take the process down)
+                print("[diffrl_amd.specialise] background compile failed: %s" % ex, file=sys.stderr, flush=True)
+    th = threading.Thread(target=work, name="dsim-specialise-" + key, daemon=True)
+    th.start()
+    return _Job(thread=th)
+
+
+def _spawn_process(t, key, cache_dir, log):
+    """the compile in a DETACHED child process (`python -m diffrl_amd.specialise --ensure <template>`): it finishes -- lock, hipcc,
+    rename into the cache -- whether or not this process is still there, so that a script shorter than the compile still leaves
+    the library for its next run instead of starting the same compile again every time"""
+    cdir = cache_dir or os.environ.get("DSIM_USER_LIBS") or USER_LIBS
+    os.makedirs(cdir, exist_ok=True)
+    tpath = os.path.join(cdir, "template_%s.npz" % key)
+    tmp = tpath + ".tmp%d.npz" % os.getpid()
+    t.save(tmp)
+    os.replace(tmp, tpath)
+    cmd = [sys.executable, "-m", "diffrl_amd.specialise", tpath, "--ensure", "--cache-dir", cdir]
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(HERE)] + [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep) if p]))
+    return _Job(proc=subprocess.Popen(cmd, env=env, stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, start_new_session=True))
+
+
+_spawn_background = _spawn_process
+
+
 def ensure_library_background(t, cache_dir=None, log=None):
     """The default of Engine(...) when hipcc is on PATH: the cached library of this model if there is one, else None -- and a
-    daemon thread that compiles it (ensure_library: same lock, same cache), so that the NEXT Engine of this model picks it up
-    while this one runs the generic kernels.  Returns (path or None, thread or None); wait(t) joins a compile in flight."""
-    import threading
+    background compile of it (ensure_library: same lock, same cache; a detached child process, _spawn_process), so that the NEXT
+    Engine of this model picks it up while this one runs the generic kernels.  Returns (path or None, job or None); wait(t) joins
+    a compile in flight."""
     path = cached_library(t, cache_dir)
     if path is not None or shutil.which("hipcc") is None:
         return path, None
     import hashlib
     key = hashlib.sha1(",".join(str(v) for v in flat_table(*layout(t))).encode()).hexdigest()[:12]
-    th = _background.get(key)
-    if th is None or not th.is_alive():
-        def work():
-            import warnings
-            with warnings.catch_warnings():
-                warnings.simplefilter("always")
-                try:
-                    ensure_library(t, cache_dir, log)
-                except Exception as ex:   # (a background convenience must never take the process down)
-                    print("[diffrl_amd.specialise] background compile failed: %s" % ex, file=sys.stderr, flush=True)
-        th = threading.Thread(target=work, name="dsim-specialise-" + key, daemon=True)
-        _background[key] = th
-        th.start()
-    return None, th
+    job = _background.get(key)
+    if job is None or not job.is_alive():
+        job = _spawn_background(t, key, cache_dir, log)
+        _background[key] = job
+    return None, job
 
 
 def wait(t=None, timeout=None):
     """joins the background compile of template t (all of them when t is None); True when none is left running"""
     import hashlib
     if t is None:
-        ths = list(_background.values())
+        jobs = list(_background.values())
     else:
         key = hashlib.sha1(",".join(str(v) for v in flat_table(*layout(t))).encode()).hexdigest()[:12]
-        ths = [_background[key]] if key in _background else []
-    for th in ths:
-        th.join(timeout)
-    return not any(th.is_alive() for th in ths)
+        jobs = [_background[key]] if key in _background else []
+    for j in jobs:
+        j.join(timeout)
+    return not any(j.is_alive() for j in jobs)
 
 
 def ensure_library(t, cache_dir=None, log=None):
@@ -330,7 +375,10 @@ def ensure_library(t, cache_dir=None, log=None):
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m diffrl_amd.specialise", description=__doc__.split("\n\n")[0])
     ap.add_argument("template", help=".npz written by ArticulationTemplate.save()")
-    ap.add_argument("--name", required=True, help="name of the kernel set (letters / digits)")
+    ap.add_argument("--name", help="name of the kernel set (letters / digits)")
+    ap.add_argument("--ensure", action="store_true", help="(what the default Engine(...) runs in the background) compile this model's "
+                                                          "kernel set into the cache unless it is there already, and print its path")
+    ap.add_argument("--cache-dir", help="(with --ensure) the cache directory (default $DSIM_USER_LIBS, else csrc/user_libs/)")
     ap.add_argument("--header-out", help="write the generated header here instead of csrc/dsim_static_layouts.hpp (the in-tree header "
                                          "and csrc/user_models/ stay untouched)")
     ap.add_argument("--lib-out", help="build this library instead of csrc/libdsim_hip.so (use it with DSIM_LIB=<path>)")
@@ -340,6 +388,12 @@ def main(argv=None):
                     help="(with --header-out) further user models for the same header / the same --only library; may be repeated")
     a = ap.parse_args(argv)
     t = ArticulationTemplate.load(a.template)
+    if a.ensure:
+        path = ensure_library(t, a.cache_dir)
+        print(path or "no library (hipcc missing or the build failed): the generic kernels stay")
+        return 0 if path else 1
+    if not a.name:
+        ap.error("--name is required (or --ensure)")
     models = shipped_templates()
     # everything that can refuse the request is checked BEFORE anything is written: a bad name must not leave a template in
     # csrc/user_models/ that breaks every later regeneration (tools/gen_static_layouts.py included)

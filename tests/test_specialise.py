@@ -257,6 +257,7 @@ def test_background_specialisation_returns_at_once_and_hands_the_library_to_the_
     monkeypatch.setattr(specialise, "build_library", slow_build)
     monkeypatch.setattr(specialise.shutil, "which", lambda x: "/usr/bin/" + x)
     monkeypatch.setattr(specialise, "_background", {})
+    monkeypatch.setattr(specialise, "_spawn_background", specialise._spawn_thread)   # (the product spawns a detached process: below)
     user = ArticulationTemplate.load(FIXTURE)
     assert specialise.ensure_library_background(template_from_golden("ant"), cache_dir=str(tmp_path)) == (capi.LIB_PATH, None)
     p, th = specialise.ensure_library_background(user, cache_dir=str(tmp_path), log=lambda m: None)
@@ -271,6 +272,34 @@ def test_background_specialisation_returns_at_once_and_hands_the_library_to_the_
     monkeypatch.setattr(specialise.shutil, "which", lambda x: None)   # no compiler: nothing starts, nothing warns
     monkeypatch.setattr(specialise, "source_hash", lambda: "3" * 12)
     assert specialise.ensure_library_background(user, cache_dir=str(tmp_path)) == (None, None)
+
+
+def test_background_compile_is_a_detached_process_that_outlives_its_parent(tmp_path):
+    """the product's background job is `python -m diffrl_amd.specialise <template> --ensure`: a child in its own session, so that a
+    script shorter than the compile still leaves the library for its next run.  hipcc is a stub here (a shell script on PATH that
+    writes its -o target after a second); the parent process exits at once, the library appears anyway."""
+    import stat
+    import time
+    fake = tmp_path / "bin"
+    fake.mkdir()
+    sh = fake / "hipcc"
+    sh.write_text("#!/bin/sh\nsleep 1\nwhile [ $# -gt 0 ]; do if [ \"$1\" = \"-o\" ]; then shift; echo stub > \"$1\"; fi; shift; done\n")
+    sh.chmod(sh.stat().st_mode | stat.S_IEXEC)
+    cache = tmp_path / "cache"
+    code = ("import sys; sys.path.insert(0, %r); from diffrl_amd import specialise as s; from diffrl_amd.template import ArticulationTemplate as T; "
+            "p, job = s.ensure_library_background(T.load(%r), cache_dir=%r); assert p is None and job is not None and job.proc is not None; print('spawned')"
+            % (ROOT, FIXTURE, str(cache)))
+    e = dict(os.environ, PATH=str(fake) + os.pathsep + os.environ["PATH"])
+    e.pop("DSIM_LIB", None)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "spawned" in r.stdout, (r.stdout, r.stderr[-800:])
+    deadline = time.time() + 60   # the parent is gone; the detached child finishes the job
+    libs = []
+    while time.time() < deadline and not libs:
+        libs = [f for f in os.listdir(cache) if f.startswith("libdsim_U") and f.endswith(".so")]
+        time.sleep(0.2)
+    assert libs, os.listdir(cache)
+    assert not [f for f in os.listdir(cache) if ".so.tmp" in f]
 
 
 _AUTO_SCRIPT = r'''
