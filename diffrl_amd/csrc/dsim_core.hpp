@@ -1801,10 +1801,52 @@ template <class Ctx, class Exec> struct DsimWaveGj {
         else return false;
     }();
 };
+// the mass matrix filled from its upper triangle (specialised kernels; -DDSIM_NO_SYM_FILL builds round 5's full fill for A/B runs)
+// One-wave mappings only: measured (tools/ab_min.py, profiles/r06_experiments.txt item 7) Ant forward -1.5 %, Humanoid -1.6 %; the
+// four-wave SNUHumanoid kernel +5 % (576 entries are 3 passes of its 256 lanes already; the folded index arithmetic and the
+// second store cost it more than the third pass did).
+template <class Ctx, class Exec> struct DsimSymFill {
+    static constexpr bool value = []() {
+#ifdef DSIM_NO_SYM_FILL
+        return false;
+#else
+        return DsimIsStatic<Ctx>::value && Exec::NL <= DSIM_NL;
+#endif
+    }();
+};
 // H = J^T M J in composite-rigid-body form + armature, inverted in place (Gauss-Jordan, SPD, no pivoting)
 template <class Ctx, class Exec> DSIM_FN void dsim_fwd_mass(const Ctx& c, Exec& ex) {
     const int nd = c.d.nd;
     dsim_fwd_composite(c, ex);
+    if constexpr (DsimSymFill<Ctx, Exec>::value) {
+        // H is symmetric: the entries on and above the diagonal are evaluated (nd (nd + 1) / 2 items instead of nd^2: Ant 2 passes
+        // of a wavefront instead of 4, Humanoid 7 instead of 12) and stored twice.  The upper triangle is dealt to the lanes as a
+        // folded rectangle -- row r (nd - r entries) and row nd - 1 - r (r + 1 entries) share one row of nd + 1 items -- so that
+        // an item's (a, b) is a division by a compile-time constant and two selects.  Dofs are numbered parents first, so a <= b
+        // never has link(a) strictly below link(b): rel is 0 or 1 there.  (The entries below the diagonal of one link's own dofs
+        // used to be S_b . (Ic S_a) instead of S_a . (Ic S_b): equal numbers, rounded differently; now H is symmetric to the bit.)
+        constexpr int ND = decltype(c.d)::nd, NDE = ND + (ND & 1), W = NDE + 1, NT = (NDE / 2) * W;
+        ex.run([&](int lane) {
+#pragma unroll
+            for (int p = 0; p < (NT + Exec::NL - 1) / Exec::NL; ++p) {
+                const int it = lane + Exec::NL * p;
+                const int r = it / W, cc = it - W * r;
+                const bool lo = cc < NDE - r;
+                const int a = lo ? r : NDE - 1 - r, b = lo ? r + cc : (NDE - 1 - r) + (cc - (NDE - r));
+                const bool on = it < NT && b < ND;   // (odd nd: the folded rectangle of nd + 1 has a spare row and column)
+                const int ai = on ? a : 0, bi = on ? b : 0;
+                const int rl = CI(rel)[ai * ND + bi];
+                const sv6 Sa = ldsv(WF(S) + 6 * ai), Fb = ldsv(WF(F) + 6 * bi);
+                const float arm = CF(arm)[ai];
+                float hv = rl != 0 ? sdot(Sa, Fb) : 0.f;
+                if (a == b) hv += arm;
+                if (on) {
+                    WF(hinv)[a * ND + b] = hv;
+                    WF(hinv)[b * ND + a] = hv;
+                }
+            }
+        });
+    } else
     ex.run([&](int lane) {
         for (int it = lane; it < nd * nd; it += Exec::NL) {
             const int a = it / nd, b = it - nd * a;
