@@ -40,6 +40,10 @@ class Engine:
         if specialise is None:
             v = os.environ.get("DSIM_AUTO_SPECIALISE", "background").lower()
             specialise = False if v in ("", "0", "off") else ("background" if v in ("background", "bg") else True)
+            # (a developer override of the library -- A/B builds with a subset of the kernel sets -- is measured as it is: no
+            # background swap behind its back)
+            if specialise == "background" and os.environ.get("DSIM_LIB"):
+                specialise = False
         h = self._create()
         if specialise and int(self._lib.dsim_model_variant(h)) == 0 and os.environ.get("DSIM_FORCE_GENERIC", "0") in ("", "0"):
             import warnings
